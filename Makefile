@@ -1,0 +1,34 @@
+# Top-level build: libmisift.so (HIP kernels + C-ABI, hipcc, gfx950 only),
+# libcudasift.so (C++ drop-in shim over the C-ABI, plain g++), the oracle (test infra).
+ROCM     ?= /opt/rocm
+HIPCC    ?= $(ROCM)/bin/hipcc
+CXX      ?= g++
+CSRC     := cudasift_amd/csrc
+BUILD    := build
+# -ffp-contract=off: fused multiply-adds are written explicitly (arithmetic contract with oracle/)
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) \
+            -Wno-unused-result -Wno-unused-value
+HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_points.hip \
+            $(CSRC)/kernels_match.hip $(CSRC)/misift_host.hip $(CSRC)/homography.hip
+HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
+
+all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+cudasift_amd/libmisift.so: $(HIPOBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIPOBJS)
+
+cudasift_amd/libcudasift.so: $(CSRC)/shim_cudasift.cpp include/cudaSift.h include/cudaImage.h include/misift.h cudasift_amd/libmisift.so
+	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -o $@ $(CSRC)/shim_cudasift.cpp -Lcudasift_amd -lmisift -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -rf $(BUILD) cudasift_amd/libmisift.so cudasift_amd/libcudasift.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark: 1920x1080 SIFT frames/s (+ 100k x 100k match Mpairs/s).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per
+GPU with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the env, backend "nccl" = RCCL).
+
+A step = one pass of the hot path (ExtractSift: LowPass -> pyramid -> DoG -> extrema -> orientation ->
+descriptors -> count read-back, mainSift.cpp:58-67 parameters) over one batch of FRAMES_PER_GPU
+synthetic 1920x1080 frames already resident in HBM, followed — when N > 1 — by the RCCL gather of the
+valid SiftPoint records to rank 0 (BASELINE config 4).  Per-GPU work is fixed as N grows ("weak").
+Rank 0 prints ONE JSON line; `value` is whole-job frames/s.
+
+torch is used for device memory, streams and torch.distributed only; all compute goes through the
+C-ABI of libmisift.so (cudasift_amd.capi).  The oracle is used only for the `cpu_baseline` leg.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 1920, 1080
+NUM_OCTAVES, INIT_BLUR, THRESH, MAX_PTS = 5, 1.0, 3.0, 32768
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def octave_pixels(w, h, n):
+    out = []
+    for _ in range(n):
+        out.append(w * h)
+        w //= 2
+        h //= 2
+    return out          # finest first
+
+
+def algorithmic_bytes_per_frame():
+    """fp32, each intermediate written once and read once."""
+    N = octave_pixels(W, H, NUM_OCTAVES)
+    lowpass = 8 * N[0]
+    scaledown = sum(4 * N[i] + 4 * N[i + 1] for i in range(NUM_OCTAVES - 1))
+    laplace = sum(32 * n for n in N)
+    findpoints = sum(28 * n for n in N)
+    return {"lowpass": lowpass, "scaledown": scaledown, "laplace": laplace, "detect": findpoints,
+            "dog_detect": laplace + findpoints}
+
+
+def gen_frames_torch(torch, nframes, first, device):
+    """tests/synth.py recipe on the GPU (torch.fft): equal-energy octave bands of Gaussian noise."""
+    import math
+    g = torch.Generator(device=device)
+    fy = torch.fft.fftfreq(H, device=device)[:, None]
+    fx = torch.fft.rfftfreq(W, device=device)[None, :]
+    r2 = fx * fx + fy * fy
+    frames = torch.empty((nframes, H, W), dtype=torch.float32, device=device)
+    for f in range(nframes):
+        g.manual_seed(0x51F7 + first + f)
+        acc = torch.zeros((H, W), dtype=torch.float32, device=device)
+        for j in range(6):
+            w = torch.randn((H, W), generator=g, device=device, dtype=torch.float32)
+            sigma = 2.0 ** j
+            gk = torch.exp(-2.0 * (math.pi ** 2) * (sigma ** 2) * r2)
+            b = torch.fft.irfft2(torch.fft.rfft2(w) * gk, s=(H, W))
+            acc += b / b.std()
+        frames[f] = torch.clamp(128.0 + 26.0 * acc / acc.std(), 0.0, 255.0)
+    return frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--match-n", type=int, default=100000)
+    ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--unfused", action="store_true", help="separate laplace/detect kernels (DoG planes in HBM)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch                     # first: libmisift.so then binds to torch's HIP runtime
+    import torch.distributed as dist
+    from cudasift_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    B = args.frames_per_gpu
+    stream = torch.cuda.current_stream()
+    ctx = capi.Context(local_rank, stream.cuda_stream)
+    ctx.set_options(quiet=1, fused=0 if args.unfused else 1)
+
+    # ---------------- inputs resident in HBM before the timed region
+    frames = gen_frames_torch(torch, B, rank * B, device)                   # [B,1080,1920], pitch 1920
+    S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
+    scratch = torch.empty((B * S,), dtype=torch.float32, device=device)
+    pts = torch.zeros((B * MAX_PTS * 576,), dtype=torch.uint8, device=device)
+    counts = (C.c_int * B)()
+    torch.cuda.synchronize()
+
+    from cudasift_amd.dist import gather_sift_records
+
+    def step():
+        capi.check(capi.lib().misift_extract_batch(ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
+                                                   INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
+                                                   MAX_PTS, counts), "misift_extract_batch")
+        n = np.frombuffer(counts, dtype=np.int32)
+        if world > 1:
+            gather_sift_records(dist, torch, pts.view(B, MAX_PTS * 576), n, rank, world, device)
+        return n
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        n = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kp_per_frame = float(np.mean(n))
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = 1e3 * dt / args.steps
+    fps = world * B * args.steps / dt
+
+    # ---------------- per-kernel durations (HIP events on the launch stream) for the roofline
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    psteps = max(2, min(args.steps, 5))
+    for _ in range(psteps):
+        capi.check(capi.lib().misift_extract_batch(ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
+                                                   INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
+                                                   MAX_PTS, counts), "misift_extract_batch")
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    alg = algorithmic_bytes_per_frame()
+    kernels = {}
+    for name, p in prof.items():
+        per_step_ms = p["total_ms"] / psteps
+        e = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": p["calls"] // psteps}
+        if name in alg:
+            e["alg_GBps"] = round(alg[name] * B / (per_step_ms * 1e-3) / 1e9, 1)
+        kernels[name] = e
+    dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k]["ms_per_step"])
+    dom_ms = kernels[dom]["ms_per_step"]
+    dom_launches = max(1, kernels[dom]["launches_per_step"])
+    achieved = alg[dom] * B / (dom_ms * 1e-3) / 1e9
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": int(alg[dom] * B / dom_launches),
+                "avg_launch_ms": round(dom_ms / dom_launches, 4),
+                "pipeline_alg_GBps": round(197.2e6 * fps / world / 1e9, 1),
+                "pipeline_frac": round(197.2e6 * fps / world / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---------------- matcher: n x n x 128 brute force on fp32 MFMA, row-block split over ranks
+    match = None
+    if not args.no_match:
+        nm = args.match_n // (32 * world) * (32 * world)
+        rows = nm // world
+        rec = np.dtype(capi.POINT_DTYPE)
+        gm = torch.Generator(device=device)
+        gm.manual_seed(12345 + rank)
+
+        def make_set(n):
+            t = torch.zeros((n, 144), dtype=torch.float32, device=device)
+            d = torch.rand((n, 128), generator=gm, device=device, dtype=torch.float32)
+            t[:, 16:] = d * (128.0 ** 0.5 / d.sum(dim=1, keepdim=True))       # match.cu:945-957 recipe
+            return t
+        set1 = make_set(nm) if world == 1 else None
+        shard2 = make_set(rows)
+        if world == 1:
+            set2 = shard2
+            my1 = set1
+            row0 = 0
+        else:
+            my1 = make_set(rows)          # this rank's row block of set 1 (rows [rank*rows, ...))
+            set2 = torch.empty((nm, 144), dtype=torch.float32, device=device)
+            row0 = 0
+        torch.cuda.synchronize()
+
+        def mstep():
+            if world > 1:
+                dist.all_gather_into_tensor(set2, shard2)                     # set-2 descriptors over xGMI
+            capi.check(capi.lib().misift_match_rows(ctx.h, my1.data_ptr(), row0, rows, set2.data_ptr(), nm),
+                       "misift_match_rows")
+        mstep()
+        barrier()
+        msteps = 3
+        t0 = time.perf_counter()
+        for _ in range(msteps):
+            mstep()
+        barrier()
+        mdt = (time.perf_counter() - t0) / msteps
+        if world > 1:
+            tmax = torch.tensor([mdt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            mdt = float(tmax.item())
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        mstep()
+        mp = ctx.profile_read()
+        ctx.profile_enable(False)
+        kms = mp.get("match_mfma", {"total_ms": 0.0})["total_ms"]
+        flops = 2.0 * 128 * rows * nm
+        match = {"metric": "match Mpairs/s", "value": round(nm * float(nm) / mdt / 1e6, 1), "n1": nm, "n2": nm,
+                 "ms": round(mdt * 1e3, 3), "split": "row-block x%d" % world,
+                 "roofline": {"kernel": "match_mfma", "bound": "mfma",
+                              "achieved": round(flops / (kms * 1e-3) / 1e12, 2) if kms > 0 else None,
+                              "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": round(flops / (kms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if kms > 0 else None,
+                              "kernel_ms": round(kms, 3)}}
+
+    # ---------------- CPU baseline (rank 0, N = 1 only): the oracle port on a bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import pyoracle as orc
+        host = frames[:args.cpu_frames].cpu().numpy()
+        orc.extract(host[0], NUM_OCTAVES, INIT_BLUR, THRESH)      # warm-up (page-in, OpenMP pool)
+        t0 = time.perf_counter()
+        tot = 0
+        for f in range(args.cpu_frames):
+            _, nn, _ = orc.extract(host[f], NUM_OCTAVES, INIT_BLUR, THRESH)
+            tot += nn
+        cdt = time.perf_counter() - t0
+        cpu = {"value": round(args.cpu_frames / cdt, 3), "unit": "frames/s", "cores": os.cpu_count(),
+               "kind": "port",
+               "sample": "%d of the same synthetic 1920x1080 frames, oracle/sift_oracle.c with OpenMP "
+                         "(OpenCV cv::SIFT is not installed on this image)" % args.cpu_frames,
+               "keypoints_per_frame": round(tot / args.cpu_frames, 1)}
+
+    if rank == 0:
+        out = {"metric": "1920x1080 SIFT frames/sec", "value": round(fps, 1), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": "batch of %d synthetic 1920x1080 frames per GPU (BASELINE config 4: 512 "
+                                      "frames over 8 GPUs), ExtractSift 5 octaves initBlur 1.0 thresh 3.0 "
+                                      "maxPts 32768, frames resident in HBM, count read-back%s" %
+                                      (B, " + RCCL gather of SiftData to rank 0" if world > 1 else ""),
+                          "frames_per_gpu": B, "path": "unfused" if args.unfused else "fused dog+detect",
+                          "keypoints_per_frame": round(kp_per_frame, 1)},
+               "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,372 @@
+"""ctypes binding of the C-ABI in include/misift.h (libmisift.so).
+
+Thin by design: every method is one C call plus argument marshalling.  There is NO
+CPU fallback — if the HIP library is missing or fails to load, importing the
+binding's `lib()` raises, and every GPU entry point fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmisift.so")
+
+POINT_DTYPE = np.dtype([
+    ("xpos", "<f4"), ("ypos", "<f4"), ("scale", "<f4"), ("sharpness", "<f4"),
+    ("edgeness", "<f4"), ("orientation", "<f4"), ("score", "<f4"), ("ambiguity", "<f4"),
+    ("match", "<i4"), ("match_xpos", "<f4"), ("match_ypos", "<f4"), ("match_error", "<f4"),
+    ("subsampling", "<f4"), ("empty", "<f4", (3,)), ("data", "<f4", (128,)),
+])
+assert POINT_DTYPE.itemsize == 576
+
+
+class Options(C.Structure):
+    _fields_ = [("texfrac_bits", C.c_int), ("fix_numpts", C.c_int), ("match_full", C.c_int),
+                ("match_exact_top2", C.c_int), ("quiet", C.c_int), ("fused", C.c_int)]
+
+
+class MisiftError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); also the list the symbol-export test checks against the header
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_ip, _fp, _up = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint)
+SIGNATURES = {
+    "misift_device_count": (_i, []),
+    "misift_device_info": (_i, [_i, C.c_char_p, _i, _ip, _ip, C.POINTER(_sz), _ip, _ip]),
+    "misift_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "misift_ctx_destroy": (None, [_vp]),
+    "misift_ctx_set_stream": (_i, [_vp, _vp]),
+    "misift_ctx_sync": (_i, [_vp]),
+    "misift_last_error": (C.c_char_p, []),
+    "misift_default_options": (None, [C.POINTER(Options)]),
+    "misift_set_options": (_i, [_vp, C.POINTER(Options)]),
+    "misift_get_options": (_i, [_vp, C.POINTER(Options)]),
+    "misift_malloc": (_i, [_sz, C.POINTER(_vp)]),
+    "misift_free": (_i, [_vp]),
+    "misift_memset": (_i, [_vp, _vp, _i, _sz]),
+    "misift_copy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "misift_copy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "misift_image_alloc": (_i, [_i, _i, C.POINTER(_vp), _ip]),
+    "misift_upload_2d": (_i, [_vp, _vp, _i, _vp, _i, _i, _i]),
+    "misift_download_2d": (_i, [_vp, _vp, _i, _vp, _i, _i, _i]),
+    "misift_download_fields": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "misift_scratch_floats": (_sz, [_i, _i, _i, _i]),
+    "misift_extract": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _f, _i, _vp, _vp, _i, _ip]),
+    "misift_extract_batch": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _ip]),
+    "misift_extract_batch_async": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp]),
+    "misift_get_counters": (_i, [_vp, _i, _up]),
+    "misift_set_counters": (_i, [_vp, _i, _up]),
+    "misift_lowpass": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f]),
+    "misift_scaledown": (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
+    "misift_scaleup": (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
+    "misift_laplace_taps": (_i, [_i, _fp]),
+    "misift_laplace": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "misift_reset_counters": (_i, [_vp, _i]),
+    "misift_findpoints": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, _f, _i, _vp, _i]),
+    "misift_dog_findpoints": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _i]),
+    "misift_orientations": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i]),
+    "misift_descriptors": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _i]),
+    "misift_rescale_positions": (_i, [_vp, _vp, _i, _f]),
+    "misift_match": (_i, [_vp, _vp, _i, _vp, _i]),
+    "misift_match_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
+    "misift_find_homography": (_i, [_vp, _vp, _i, _fp, _ip, _i, _f, _f, _f]),
+    "misift_timer_start": (_i, [_vp]),
+    "misift_timer_stop_ms": (_i, [_vp, _fp]),
+    "misift_profile_enable": (_i, [_vp, _i]),
+    "misift_profile_reset": (_i, [_vp]),
+    "misift_profile_read": (_i, [_vp, _i, _vp, _fp, _ip, _ip]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmisift.so (raises if it is missing: the HIP path is the only path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MisiftError("HIP extension %s is not built — run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` or `make`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise MisiftError("%s failed (rc=%d): %s" % (what, rc, lib().misift_last_error().decode()))
+
+
+def device_count():
+    return lib().misift_device_count()
+
+
+def scratch_floats(width, height, num_octaves=5, scale_up=False):
+    return int(lib().misift_scratch_floats(width, height, num_octaves, int(scale_up)))
+
+
+def laplace_taps(num_octaves):
+    k = np.zeros(8 * 12 * 16, np.float32)
+    check(lib().misift_laplace_taps(num_octaves, k.ctypes.data_as(_fp)), "misift_laplace_taps")
+    return k
+
+
+class DevBuf:
+    """A raw HBM allocation owned through misift_malloc/misift_free."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().misift_malloc(nbytes, C.byref(p)), "misift_malloc")
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def free(self):
+        if self.ptr:
+            lib().misift_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per device (+ optional hipStream_t given as an int)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        check(lib().misift_ctx_create(device, stream, C.byref(h)), "misift_ctx_create")
+        self.h = h.value
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().misift_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- options
+    def get_options(self):
+        o = Options()
+        check(lib().misift_get_options(self.h, C.byref(o)), "misift_get_options")
+        return o
+
+    def set_options(self, **kw):
+        o = self.get_options()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise KeyError(k)
+            setattr(o, k, int(v))
+        check(lib().misift_set_options(self.h, C.byref(o)), "misift_set_options")
+
+    def sync(self):
+        check(lib().misift_ctx_sync(self.h), "misift_ctx_sync")
+
+    # ---- memory helpers
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = DevBuf(max(arr.nbytes, 16))
+        if arr.nbytes:
+            check(lib().misift_copy_h2d(self.h, buf.ptr, arr.ctypes.data, arr.nbytes), "misift_copy_h2d")
+        return buf
+
+    def download(self, buf, shape, dtype):
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            check(lib().misift_copy_d2h(self.h, out.ctypes.data, buf.ptr if isinstance(buf, DevBuf) else buf,
+                                        out.nbytes), "misift_copy_d2h")
+        return out
+
+    def upload_image(self, img, pitch=None):
+        """Host [h,w] float32 -> pitched device image.  Returns (DevBuf, pitch_floats)."""
+        img = np.ascontiguousarray(img, np.float32)
+        h, w = img.shape
+        if pitch is None:
+            pitch = (w + 127) // 128 * 128
+        buf = DevBuf(4 * pitch * h)
+        check(lib().misift_upload_2d(self.h, buf.ptr, pitch, img.ctypes.data, w, w, h), "misift_upload_2d")
+        return buf, pitch
+
+    def download_image(self, ptr, w, h, pitch):
+        out = np.empty((h, w), np.float32)
+        check(lib().misift_download_2d(self.h, out.ctypes.data, w, ptr, pitch, w, h), "misift_download_2d")
+        return out
+
+    def zeros(self, nbytes):
+        buf = DevBuf(nbytes)
+        check(lib().misift_memset(self.h, buf.ptr, 0, nbytes), "misift_memset")
+        self.sync()
+        return buf
+
+    # ---- counters
+    def get_counters(self, frame=0):
+        c = (C.c_uint * 17)()
+        check(lib().misift_get_counters(self.h, frame, c), "misift_get_counters")
+        return np.array(list(c), np.uint32)
+
+    def set_counters(self, counters, frame=0):
+        c = (C.c_uint * 17)(*[int(v) for v in counters])
+        check(lib().misift_set_counters(self.h, frame, c), "misift_set_counters")
+
+    # ---- stage-level calls on host arrays (upload, run, download) — used by the parity tests
+    def lowpass(self, img, sigma):
+        h, w = img.shape
+        src, p = self.upload_image(img)
+        dst = DevBuf(4 * p * h)
+        check(lib().misift_lowpass(self.h, src.ptr, w, h, p, dst.ptr, p, sigma), "misift_lowpass")
+        return self.download_image(dst.ptr, w, h, p)
+
+    def scaledown(self, img):
+        h, w = img.shape
+        src, p = self.upload_image(img)
+        w2, h2 = w // 2, h // 2
+        p2 = (w2 + 127) // 128 * 128
+        dst = DevBuf(4 * p2 * max(h2, 1))
+        check(lib().misift_scaledown(self.h, src.ptr, w, h, p, dst.ptr, p2), "misift_scaledown")
+        return self.download_image(dst.ptr, w2, h2, p2)
+
+    def scaleup(self, img):
+        h, w = img.shape
+        src, p = self.upload_image(img)
+        p2 = (2 * w + 127) // 128 * 128
+        dst = DevBuf(4 * p2 * 2 * h)
+        check(lib().misift_scaleup(self.h, src.ptr, w, h, p, dst.ptr, p2), "misift_scaleup")
+        return self.download_image(dst.ptr, 2 * w, 2 * h, p2)
+
+    def laplace(self, base, num_octaves, octave):
+        h, w = base.shape
+        src, p = self.upload_image(base)
+        dog = DevBuf(4 * 7 * p * h)
+        check(lib().misift_laplace(self.h, src.ptr, w, h, p, num_octaves, octave, dog.ptr), "misift_laplace")
+        planes = self.download(dog, (7, h, p), np.float32)
+        return np.ascontiguousarray(planes[:, :, :w])
+
+    def findpoints(self, dog, thresh, subsampling=1.0, lowest_scale=0.0, max_pts=32768, octave=1,
+                   edge_limit=10.0):
+        """Unfused detect+refine on host DoG planes [7,h,w]. Returns (points, n)."""
+        _, h, w = dog.shape
+        p = (w + 127) // 128 * 128
+        padded = np.zeros((7, h, p), np.float32)
+        padded[:, :, :w] = dog
+        d = self.upload(padded)
+        pts = self.zeros(576 * max_pts)
+        check(lib().misift_reset_counters(self.h, max_pts), "misift_reset_counters")
+        check(lib().misift_findpoints(self.h, d.ptr, w, h, p, thresh, edge_limit, lowest_scale, subsampling,
+                                      octave, pts.ptr, max_pts), "misift_findpoints")
+        cnt = self.get_counters()
+        n = int(min(cnt[2 * octave], max_pts))
+        return self.download(pts, (max_pts,), POINT_DTYPE), n
+
+    def dog_findpoints(self, base, num_octaves, octave, thresh, subsampling=1.0, lowest_scale=0.0,
+                       max_pts=32768, edge_limit=10.0):
+        """Fused DoG+detect+refine on a host base image. Returns (points, n)."""
+        h, w = base.shape
+        src, p = self.upload_image(base)
+        pts = self.zeros(576 * max_pts)
+        check(lib().misift_reset_counters(self.h, max_pts), "misift_reset_counters")
+        check(lib().misift_dog_findpoints(self.h, src.ptr, w, h, p, num_octaves, octave, thresh, edge_limit,
+                                          lowest_scale, subsampling, pts.ptr, max_pts), "misift_dog_findpoints")
+        cnt = self.get_counters()
+        n = int(min(cnt[2 * octave], max_pts))
+        return self.download(pts, (max_pts,), POINT_DTYPE), n
+
+    def orient_and_describe(self, base, pts, first, last, octave, subsampling=1.0, max_pts=None):
+        """Run orientation + descriptor kernels on host points [first,last) of one octave.
+        Returns (points, counters) with duplicates appended from `last`."""
+        h, w = base.shape
+        if max_pts is None:
+            max_pts = len(pts)
+        src, p = self.upload_image(base)
+        d = self.upload(pts)
+        cnt = np.zeros(17, np.uint32)
+        cnt[2 * octave - 1] = first
+        cnt[2 * octave] = last
+        cnt[2 * octave + 1] = last
+        check(lib().misift_reset_counters(self.h, max_pts), "misift_reset_counters")
+        self.set_counters(cnt)
+        check(lib().misift_orientations(self.h, src.ptr, w, h, p, octave, d.ptr, max_pts), "misift_orientations")
+        check(lib().misift_descriptors(self.h, src.ptr, w, h, p, subsampling, octave, d.ptr, max_pts),
+              "misift_descriptors")
+        return self.download(d, (len(pts),), POINT_DTYPE), self.get_counters()
+
+    # ---- whole path
+    def extract(self, img, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, scale_up=False,
+                max_pts=32768, scratch=True):
+        """ExtractSift on a host image.  Returns (points[max_pts], numPts, counters[17])."""
+        h, w = img.shape
+        src, p = self.upload_image(img)
+        sc = DevBuf(4 * scratch_floats(w, h, num_octaves, scale_up)) if scratch else None
+        pts = self.zeros(576 * max_pts)
+        n = C.c_int(0)
+        check(lib().misift_extract(self.h, src.ptr, w, h, p, num_octaves, init_blur, thresh, lowest_scale,
+                                   int(scale_up), sc.ptr if sc else None, pts.ptr, max_pts, C.byref(n)),
+              "misift_extract")
+        return self.download(pts, (max_pts,), POINT_DTYPE), n.value, self.get_counters()
+
+    def extract_batch(self, imgs, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, max_pts=32768):
+        """imgs: [B,h,w] host array.  Returns (points[B,max_pts], numPts[B])."""
+        imgs = np.ascontiguousarray(imgs, np.float32)
+        B, h, w = imgs.shape
+        p = (w + 127) // 128 * 128
+        padded = np.zeros((B, h, p), np.float32)
+        padded[:, :, :w] = imgs
+        d = self.upload(padded)
+        S = scratch_floats(w, h, num_octaves, False)
+        sc = DevBuf(4 * S * B)
+        pts = self.zeros(576 * max_pts * B)
+        n = (C.c_int * B)()
+        check(lib().misift_extract_batch(self.h, d.ptr, B, h * p, w, h, p, num_octaves, init_blur, thresh,
+                                         lowest_scale, sc.ptr, pts.ptr, max_pts, n), "misift_extract_batch")
+        return self.download(pts, (B, max_pts), POINT_DTYPE), np.array(list(n), np.int32)
+
+    def match(self, pts1, n1, pts2, n2, row_begin=0, row_count=None):
+        """MatchSiftData on host structured arrays; returns the updated copy of pts1."""
+        d1 = self.upload(pts1)
+        d2 = self.upload(pts2)
+        if row_count is None:
+            check(lib().misift_match(self.h, d1.ptr, n1, d2.ptr, n2), "misift_match")
+        else:
+            check(lib().misift_match_rows(self.h, d1.ptr, row_begin, row_count, d2.ptr, n2), "misift_match_rows")
+        return self.download(d1, (len(pts1),), POINT_DTYPE)
+
+    def find_homography(self, dpts_ptr, npts, num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0):
+        H = (C.c_float * 9)()
+        nm = C.c_int(0)
+        check(lib().misift_find_homography(self.h, dpts_ptr, npts, H, C.byref(nm), num_loops, min_score,
+                                           max_ambiguity, thresh), "misift_find_homography")
+        return np.array(list(H), np.float32).reshape(3, 3), nm.value
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        check(lib().misift_profile_enable(self.h, int(on)), "misift_profile_enable")
+
+    def profile_reset(self):
+        check(lib().misift_profile_reset(self.h), "misift_profile_reset")
+
+    def profile_read(self):
+        cap = 32
+        names = C.create_string_buffer(32 * cap)
+        ms = (C.c_float * cap)()
+        calls = (C.c_int * cap)()
+        n = C.c_int(0)
+        check(lib().misift_profile_read(self.h, cap, C.cast(names, C.c_void_p), ms, calls, C.byref(n)),
+              "misift_profile_read")
+        out = {}
+        for i in range(n.value):
+            nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
+            out[nm] = {"total_ms": float(ms[i]), "calls": int(calls[i])}
+        return out

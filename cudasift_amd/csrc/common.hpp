@@ -1,0 +1,204 @@
+// common.hpp — shared definitions of libmisift.so (gfx950 only).
+//
+// Streaming-kernel vocabulary used throughout:
+//   quad     : 4 horizontally adjacent pixels held by one lane as a float4
+//   strip    : the 64 quads (256 px) one wavefront owns; lanes 0 and 63 are
+//              halo lanes for the radius-4 filters, so a strip emits 62 quads
+//   segment  : the run of image rows one wavefront walks down, keeping its
+//              filter windows in VGPRs (no LDS staging of image tiles needed:
+//              R = 4 px is exactly one quad, so neighbours are a DPP shift away)
+//   item     : (frame, strip, segment) — one wavefront's unit of work
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "misift.h"
+
+#define NUM_SCALES 5
+#define NUM_BLURS  8          // NUM_SCALES + 3 (cudaSiftD.h:33 LAPLACE_S)
+#define NUM_DOG    7
+#define CNT_STRIDE 32         // uints per frame in the counter block
+#define CNT_MAXPTS 17         // slot holding maxPts (reference d_MaxNumPoints)
+#define CNT_CAND   20         // CNT_CAND + octave : candidate count of that octave
+#define CNT_CANDOVF 28        // candidates dropped because the list was full
+#define CNT_PTOVF  29         // points dropped because maxPts was reached
+
+struct alignas(16) SiftPointD {   // device view of the 576-byte record
+  float xpos, ypos, scale, sharpness, edgeness, orientation, score, ambiguity;
+  int   match;
+  float match_xpos, match_ypos, match_error, subsampling;
+  float empty[3];
+  float data[128];
+};
+static_assert(sizeof(SiftPointD) == MISIFT_POINT_BYTES, "record size");
+
+struct Taps5 { float k[5]; };                    // k[0] = centre tap
+struct LaplaceTaps { float k[NUM_BLURS][5]; };   // per blur scale, k[.][0] = centre
+
+// Geometry of one batched streaming launch.
+struct StripGeom {
+  int width, height, pitch;        // source image
+  int nstrips, nsegs, seg_rows;    // decomposition
+  int nframes;
+  long long frame_stride;          // floats between frames of the source
+};
+
+// ---------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Lane i receives lane i-1's value (lane 0 receives 0): DPP wave_shr:1.
+__device__ __forceinline__ float lane_from_left(float x)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+// Lane i receives lane i+1's value (lane 63 receives 0): DPP wave_shl:1.
+__device__ __forceinline__ float lane_from_right(float x)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float4 quad_from_left(float4 v)
+{
+  return make_float4(lane_from_left(v.x), lane_from_left(v.y), lane_from_left(v.z), lane_from_left(v.w));
+}
+__device__ __forceinline__ float4 quad_from_right(float4 v)
+{
+  return make_float4(lane_from_right(v.x), lane_from_right(v.y), lane_from_right(v.z), lane_from_right(v.w));
+}
+
+// The dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md).  Remap so
+// that the blocks sharing an XCD (and its private 4 MiB L2) are consecutive
+// logical blocks, i.e. spatial neighbours.  Bijective for any nb; speed only.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb)
+{
+  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, i = b >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + i;
+}
+
+// Symmetric 9-tap dot product: centre tap first, then outward (explicit fmaf chain;
+// arithmetic contract shared with oracle/sift_oracle.c conv9()).
+__device__ __forceinline__ float conv9(const float k0, const float k1, const float k2, const float k3,
+                                       const float k4, float c, float p1, float p2, float p3, float p4)
+{
+  float s = k0 * c;
+  s = __builtin_fmaf(k1, p1, s);
+  s = __builtin_fmaf(k2, p2, s);
+  s = __builtin_fmaf(k3, p3, s);
+  s = __builtin_fmaf(k4, p4, s);
+  return s;
+}
+
+// Load the quad of pixels [4q, 4q+3] of one image row with clamp-to-edge columns.
+// `aligned` rows (pitch % 4 == 0, base 16-byte aligned) use one dwordx4 load in the interior.
+__device__ __forceinline__ float4 load_quad(const float *row, int q, int width, bool aligned)
+{
+  const int x = 4 * q;
+  if (aligned && x >= 0 && x + 3 < width) return *reinterpret_cast<const float4 *>(row + x);
+  const int w1 = width - 1;
+  return make_float4(row[clampi(x, 0, w1)], row[clampi(x + 1, 0, w1)], row[clampi(x + 2, 0, w1)],
+                     row[clampi(x + 3, 0, w1)]);
+}
+
+// tex2D<float>() of a pitch2D texture with clamp addressing and linear filtering
+// (cudaSiftH.cu:196-205).  frac8: round the weights to 8 fractional bits like the
+// CUDA texture unit.  Same operation sequence as oracle tex2d().
+__device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch, float x, float y, bool frac8)
+{
+  float xb = x - 0.5f, yb = y - 0.5f;
+  float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (frac8) {
+    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+  }
+  fx = fminf(fmaxf(fx, -2.0f), (float)w);
+  fy = fminf(fmaxf(fy, -2.0f), (float)h);
+  const int ix = (int)fx, iy = (int)fy;
+  const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
+  const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+  const float t00 = img[(size_t)y0 * pitch + x0], t10 = img[(size_t)y0 * pitch + x1];
+  const float t01 = img[(size_t)y1 * pitch + x0], t11 = img[(size_t)y1 * pitch + x1];
+  const float ia = 1.0f - a, ib = 1.0f - b;
+  float v = (ia * ib) * t00;
+  v = __builtin_fmaf(a * ib, t10, v);
+  v = __builtin_fmaf(ia * b, t01, v);
+  v = __builtin_fmaf(a * b, t11, v);
+  return v;
+}
+
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------- host side
+struct ProfEntry {
+  char name[32];
+  float total_ms;
+  int calls;
+};
+
+struct misift_ctx {
+  int device;
+  hipStream_t stream;
+  misift_options opt;
+  unsigned int *d_counters;     // [cap_frames][CNT_STRIDE]
+  unsigned int *h_counters;     // pinned mirror
+  int cap_frames;
+  unsigned int *d_cand;         // candidate lists [cap_frames][cand_cap]
+  size_t cand_cap;              // entries per frame
+  float *d_own_scratch;         // scratch allocated on behalf of the caller (NULL tempMemory)
+  size_t own_scratch_floats;
+  void *d_match_tmp;            // matcher partial results
+  size_t match_tmp_bytes;
+  int num_cus;
+  hipEvent_t ev0, ev1;
+  // per-kernel profiling (HIP events on the context stream)
+  bool profile;
+  ProfEntry prof[32];
+  int nprof;
+  hipEvent_t pev[2];
+};
+
+void misift_set_error(const char *fmt, ...);
+int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap);
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      misift_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return MISIFT_EHIP;                                                                    \
+    }                                                                                        \
+  } while (0)
+
+// Launch bookkeeping: optional per-kernel event timing + launch error check.
+struct LaunchScope {
+  misift_ctx *ctx;
+  const char *name;
+  LaunchScope(misift_ctx *c, const char *n);
+  int finish();   // returns MISIFT_OK / MISIFT_EHIP
+};
+
+// kernel launch wrappers (defined in the .hip files)
+int launch_lowpass(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
+                   long long dst_frame_stride, const float k9[9]);
+int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
+                     long long dst_frame_stride, const float k5[5]);
+int launch_scaleup(misift_ctx *ctx, const float *src, int w, int h, int spitch, float *dst, int dpitch);
+int launch_laplace(misift_ctx *ctx, const float *base, const StripGeom &g, float *dog,
+                   long long dog_frame_stride, const LaplaceTaps &taps);
+int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long long dog_frame_stride,
+                  float thresh, int octave);
+int launch_dog_detect(misift_ctx *ctx, const float *base, const StripGeom &g, const LaplaceTaps &taps,
+                      float thresh, int octave);
+int launch_refine(misift_ctx *ctx, const float *dog, long long dog_frame_stride, const float *base,
+                  long long base_frame_stride, const LaplaceTaps *taps, int w, int h, int pitch, int nframes,
+                  float edge_limit, float factor, float lowest_scale, float subsampling, int octave,
+                  SiftPointD *pts, int max_pts);
+int launch_orient(misift_ctx *ctx, const float *base, long long base_frame_stride, int w, int h, int pitch,
+                  int nframes, int octave, SiftPointD *pts, int max_pts);
+int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride, int w, int h, int pitch,
+                 int nframes, float subsampling, int octave, SiftPointD *pts, int max_pts);
+int launch_rescale(misift_ctx *ctx, SiftPointD *pts, int npts, float scale);
+int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2);
+int launch_selftest(misift_ctx *ctx);

@@ -1,0 +1,514 @@
+// kernels_dog.hip — difference-of-Gaussians and scale-space extrema for gfx950.
+//
+//   laplace_kernel     replaces LaplaceMultiMem   (reference cudaSiftD.cu:1753-1793, host cudaSiftH.cu:460-487)
+//   detect_kernel      replaces the 3x3x3 extremum search of FindPointsMultiNew (cudaSiftD.cu:1292-1366)
+//   dog_detect_kernel  = laplace + detect fused: the 7 DoG planes never touch HBM
+//   refine_kernel      replaces the edge test / sub-pixel refinement / append of
+//                      FindPointsMultiNew (cudaSiftD.cu:1379-1430); in the fused path it
+//                      recomputes the 3x3x3 DoG neighbourhood of each candidate from the
+//                      octave base image with the same fmaf chains (bit-identical values)
+//
+// Streaming design (see common.hpp): a wavefront walks down a 256-px strip; the
+// 9-row raw window, the 8 vertical blur results and (fused path) a 3-row window
+// of all 7 DoG planes live in VGPRs; horizontal neighbours come from adjacent
+// lanes by DPP.  Unfused laplace is HBM-write-bound (4 B read + 28 B written per
+// px); unfused detect is HBM-read-bound (28 B/px); the fused kernel reads 4 B/px
+// and is VALU-bound.
+//
+// Compiled with -ffp-contract=off: every multiply-add below that is meant to be
+// fused is an explicit __builtin_fmaf, exactly as in oracle/sift_oracle.c.
+#include <string.h>
+#include <math.h>
+#include "common.hpp"
+
+#define WAVES_PER_BLOCK 4
+#define OUT_LANES 62
+
+struct ItemCoord { int frame, strip, seg; bool valid; };
+
+__device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
+{
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const long long item = (long long)lb * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
+  ItemCoord c;
+  c.valid = item < nitems;
+  c.seg = (int)(item % g.nsegs);
+  const long long r = item / g.nsegs;
+  c.strip = (int)(r % g.nstrips);
+  c.frame = (int)(r / g.nstrips);
+  return c;
+}
+
+__device__ __forceinline__ void store_quad(float *row, int q, int width, bool aligned, float4 v)
+{
+  const int x = 4 * q;
+  if (aligned && x + 3 < width) {
+    *reinterpret_cast<float4 *>(row + x) = v;
+  } else {
+    if (x < width) row[x] = v.x;
+    if (x + 1 < width) row[x + 1] = v.y;
+    if (x + 2 < width) row[x + 2] = v.z;
+    if (x + 3 < width) row[x + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// Vertical 9-tap of one blur scale on a quad column, then the horizontal 9-tap
+// using the neighbouring lanes' vertical results.
+__device__ __forceinline__ float4 blur_quad(const float *k, float4 c, float4 p1, float4 p2, float4 p3, float4 p4)
+{
+  const float k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3], k4 = k[4];
+  float4 v;
+  v.x = conv9(k0, k1, k2, k3, k4, c.x, p1.x, p2.x, p3.x, p4.x);
+  v.y = conv9(k0, k1, k2, k3, k4, c.y, p1.y, p2.y, p3.y, p4.y);
+  v.z = conv9(k0, k1, k2, k3, k4, c.z, p1.z, p2.z, p3.z, p4.z);
+  v.w = conv9(k0, k1, k2, k3, k4, c.w, p1.w, p2.w, p3.w, p4.w);
+  const float4 l = quad_from_left(v);
+  const float4 r = quad_from_right(v);
+  float4 h;
+  h.x = conv9(k0, k1, k2, k3, k4, v.x, l.w + v.y, l.z + v.z, l.y + v.w, l.x + r.x);
+  h.y = conv9(k0, k1, k2, k3, k4, v.y, v.x + v.z, l.w + v.w, l.z + r.x, l.y + r.y);
+  h.z = conv9(k0, k1, k2, k3, k4, v.z, v.y + v.w, v.x + r.x, l.w + r.y, l.z + r.z);
+  h.w = conv9(k0, k1, k2, k3, k4, v.w, v.z + r.x, v.y + r.y, v.x + r.z, l.w + r.w);
+  return h;
+}
+
+// ------------------------------------------------------------------ Laplace
+__global__ __launch_bounds__(256) void laplace_kernel(const float *__restrict__ base, StripGeom g,
+                                                      float *__restrict__ dog, long long dog_frame_stride,
+                                                      LaplaceTaps taps, int aligned)
+{
+  const ItemCoord it = decode_item(g);
+  if (!it.valid) return;
+  const int lane = threadIdx.x & 63;
+  const int q = it.strip * OUT_LANES + lane - 1;
+  const float *img = base + (long long)it.frame * g.frame_stride;
+  float *out = dog + (long long)it.frame * dog_frame_stride;
+  const size_t plane = (size_t)g.height * g.pitch;
+  const int y0 = it.seg * g.seg_rows;
+  const int y1 = min(y0 + g.seg_rows, g.height);
+  const bool al = aligned != 0;
+  auto ld = [&](int y) -> float4 {
+    return load_quad(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al);
+  };
+  float4 r0 = ld(y0 - 4), r1 = ld(y0 - 3), r2 = ld(y0 - 2), r3 = ld(y0 - 1), r4 = ld(y0);
+  float4 r5 = ld(y0 + 1), r6 = ld(y0 + 2), r7 = ld(y0 + 3), r8;
+  const bool writer = lane >= 1 && lane <= OUT_LANES && 4 * q < g.width;
+  for (int y = y0; y < y1; y++) {
+    r8 = ld(y + 4);
+    const float4 p1 = add4(r3, r5), p2 = add4(r2, r6), p3 = add4(r1, r7), p4 = add4(r0, r8);
+    float4 old = blur_quad(taps.k[0], r4, p1, p2, p3, p4);
+#pragma unroll
+    for (int s = 1; s < NUM_BLURS; s++) {
+      const float4 res = blur_quad(taps.k[s], r4, p1, p2, p3, p4);
+      if (writer) store_quad(out + (size_t)(s - 1) * plane + (size_t)y * g.pitch, q, g.width, al, sub4(res, old));
+      old = res;
+    }
+    r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8;
+  }
+}
+
+// ------------------------------------------------------------------- detect
+// One row of one DoG plane as seen by a lane: its quad plus the pixel left of it
+// and the pixel right of it.
+struct Row6 { float l, x, y, z, w, r; };
+
+__device__ __forceinline__ Row6 make_row6(float4 c)
+{
+  Row6 o;
+  o.x = c.x; o.y = c.y; o.z = c.z; o.w = c.w;
+  o.l = lane_from_left(c.w);
+  o.r = lane_from_right(c.x);
+  return o;
+}
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+struct Col6 { float v[6]; };
+
+// 3x3x3 strict-extremum test of the centre row `b` (rows a, b, c = y-1, y, y+1) of
+// all 7 planes; returns a 20-bit mask, bit (5*i + s) set when pixel i of the quad is a
+// candidate at DoG scale s (centre plane s+1).  Equivalent to the 26-neighbour test of
+// the reference (cudaSiftD.cu:1337-1360): box minima of the planes below/above, ring
+// minimum of the centre plane.
+__device__ __forceinline__ unsigned extrema_mask(const Row6 (&a)[NUM_DOG], const Row6 (&b)[NUM_DOG],
+                                                 const Row6 (&c)[NUM_DOG], float thresh)
+{
+  float bmin[NUM_DOG][4], bmax[NUM_DOG][4];     // 3x3 box min/max per plane and pixel
+  float cmin[NUM_DOG][6], cmax[NUM_DOG][6];     // 3-row column min/max
+#pragma unroll
+  for (int p = 0; p < NUM_DOG; p++) {
+    const float av[6] = {a[p].l, a[p].x, a[p].y, a[p].z, a[p].w, a[p].r};
+    const float bv[6] = {b[p].l, b[p].x, b[p].y, b[p].z, b[p].w, b[p].r};
+    const float cv[6] = {c[p].l, c[p].x, c[p].y, c[p].z, c[p].w, c[p].r};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      cmin[p][j] = min3f(av[j], bv[j], cv[j]);
+      cmax[p][j] = max3f(av[j], bv[j], cv[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      bmin[p][i] = min3f(cmin[p][i], cmin[p][i + 1], cmin[p][i + 2]);
+      bmax[p][i] = max3f(cmax[p][i], cmax[p][i + 1], cmax[p][i + 2]);
+    }
+  }
+  unsigned mask = 0;
+#pragma unroll
+  for (int s = 0; s < NUM_SCALES; s++) {
+    const int p = s + 1;
+    const float av[6] = {a[p].l, a[p].x, a[p].y, a[p].z, a[p].w, a[p].r};
+    const float bv[6] = {b[p].l, b[p].x, b[p].y, b[p].z, b[p].w, b[p].r};
+    const float cv[6] = {c[p].l, c[p].x, c[p].y, c[p].z, c[p].w, c[p].r};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float v = bv[i + 1];
+      // ring of 8 in the centre plane: left/right columns (3 rows each) + above/below
+      float rmin = fminf(fminf(cmin[p][i], cmin[p][i + 2]), fminf(av[i + 1], cv[i + 1]));
+      float rmax = fmaxf(fmaxf(cmax[p][i], cmax[p][i + 2]), fmaxf(av[i + 1], cv[i + 1]));
+      const float minv = min3f(rmin, bmin[p - 1][i], bmin[p + 1][i]);
+      const float maxv = max3f(rmax, bmax[p - 1][i], bmax[p + 1][i]);
+      const bool cand = (v < fminf(-thresh, minv)) | (v > fmaxf(thresh, maxv));
+      mask |= (cand ? 1u : 0u) << (5 * i + s);
+    }
+  }
+  return mask;
+}
+
+// Append the candidates of one quad row to the frame's candidate list.
+// code = x | y << 14 | s << 28.
+__device__ __forceinline__ void push_candidates(unsigned mask, int q, int y, int width, unsigned *cnt,
+                                                unsigned *list, unsigned cap, int octave)
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = 4 * q + i;
+#pragma unroll
+    for (int s = 0; s < NUM_SCALES; s++) {
+      if (((mask >> (5 * i + s)) & 1u) && x < width) {
+        const unsigned idx = atomicAdd(&cnt[CNT_CAND + octave], 1u);
+        if (idx < cap) list[idx] = (unsigned)x | ((unsigned)y << 14) | ((unsigned)s << 28);
+        else atomicAdd(&cnt[CNT_CANDOVF], 1u);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ dog, StripGeom g,
+                                                     long long dog_frame_stride, float thresh, int octave,
+                                                     unsigned *__restrict__ counters, unsigned *__restrict__ cand,
+                                                     unsigned cand_cap, int aligned)
+{
+  const ItemCoord it = decode_item(g);
+  if (!it.valid) return;
+  const int lane = threadIdx.x & 63;
+  const int q = it.strip * OUT_LANES + lane - 1;
+  const float *planes = dog + (long long)it.frame * dog_frame_stride;
+  const size_t plane = (size_t)g.height * g.pitch;
+  unsigned *cnt = counters + (size_t)it.frame * CNT_STRIDE;
+  unsigned *list = cand + (size_t)it.frame * cand_cap;
+  const int y0 = it.seg * g.seg_rows;
+  const int y1 = min(y0 + g.seg_rows, g.height);
+  const bool al = aligned != 0;
+  const bool tester = lane >= 1 && lane <= OUT_LANES && 4 * q < g.width;
+
+  Row6 ra[NUM_DOG], rb[NUM_DOG], rc[NUM_DOG];
+  auto ldrow = [&](Row6 (&dst)[NUM_DOG], int y) {
+    const size_t off = (size_t)clampi(y, 0, g.height - 1) * g.pitch;
+#pragma unroll
+    for (int p = 0; p < NUM_DOG; p++) dst[p] = make_row6(load_quad(planes + p * plane + off, q, g.width, al));
+  };
+  ldrow(ra, y0 - 1);
+  ldrow(rb, y0);
+  for (int y = y0; y < y1; y++) {
+    ldrow(rc, y + 1);
+    // wave-uniform early-out: nothing in this row of the strip exceeds the threshold
+    float amax = 0.0f;
+#pragma unroll
+    for (int p = 1; p <= NUM_SCALES; p++)
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(rb[p].x), fabsf(rb[p].y)), fmaxf(fabsf(rb[p].z), fabsf(rb[p].w))));
+    if (__any(amax > thresh)) {
+      const unsigned mask = extrema_mask(ra, rb, rc, thresh);
+      if (tester && mask) push_candidates(mask, q, y, g.width, cnt, list, cand_cap, octave);
+    }
+#pragma unroll
+    for (int p = 0; p < NUM_DOG; p++) { ra[p] = rb[p]; rb[p] = rc[p]; }
+  }
+}
+
+// ------------------------------------------------------- fused DoG + detect
+__global__ __launch_bounds__(256) void dog_detect_kernel(const float *__restrict__ base, StripGeom g,
+                                                         LaplaceTaps taps, float thresh, int octave,
+                                                         unsigned *__restrict__ counters,
+                                                         unsigned *__restrict__ cand, unsigned cand_cap, int aligned)
+{
+  const ItemCoord it = decode_item(g);
+  if (!it.valid) return;
+  const int lane = threadIdx.x & 63;
+  // one extra halo quad on each side: blur halo (lanes 0,63) + DoG neighbour halo (lanes 1,62)
+  const int q = it.strip * (OUT_LANES - 2) + lane - 2;
+  const float *img = base + (long long)it.frame * g.frame_stride;
+  unsigned *cnt = counters + (size_t)it.frame * CNT_STRIDE;
+  unsigned *list = cand + (size_t)it.frame * cand_cap;
+  const int y0 = it.seg * g.seg_rows;
+  const int y1 = min(y0 + g.seg_rows, g.height);
+  const bool al = aligned != 0;
+  const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
+  auto ld = [&](int y) -> float4 {
+    return load_quad(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al);
+  };
+  Row6 ra[NUM_DOG], rb[NUM_DOG], rc[NUM_DOG];
+  // DoG row yy needs raw rows yy-4 .. yy+4.  Produce DoG rows y0-1 and y0 first, then stream.
+  float4 r0, r1, r2, r3, r4, r5, r6, r7, r8;
+  auto dogrow = [&](Row6 (&dst)[NUM_DOG]) {
+    const float4 p1 = add4(r3, r5), p2 = add4(r2, r6), p3 = add4(r1, r7), p4 = add4(r0, r8);
+    float4 old = blur_quad(taps.k[0], r4, p1, p2, p3, p4);
+#pragma unroll
+    for (int s = 1; s < NUM_BLURS; s++) {
+      const float4 res = blur_quad(taps.k[s], r4, p1, p2, p3, p4);
+      dst[s - 1] = make_row6(sub4(res, old));
+      old = res;
+    }
+  };
+  // Rows are clamped at the image border exactly like the oracle: DoG row -1 == DoG row 0
+  // because every raw row index is clamped before the vertical filter... which is NOT the
+  // same as clamping the DoG row index.  The reference clamps the DoG row index
+  // (cudaSiftD.cu:1332-1333), so rows outside the image reuse the clamped centre row.
+  const int ya = clampi(y0 - 1, 0, g.height - 1);
+  r0 = ld(ya - 4); r1 = ld(ya - 3); r2 = ld(ya - 2); r3 = ld(ya - 1); r4 = ld(ya);
+  r5 = ld(ya + 1); r6 = ld(ya + 2); r7 = ld(ya + 3); r8 = ld(ya + 4);
+  dogrow(ra);
+  if (ya != y0) {       // advance the raw window by one row
+    r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8; r8 = ld(y0 + 4);
+  }
+  dogrow(rb);
+  for (int y = y0; y < y1; y++) {
+    if (y + 1 <= g.height - 1) {
+      r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8; r8 = ld(y + 5);
+      dogrow(rc);
+    } else {
+#pragma unroll
+      for (int p = 0; p < NUM_DOG; p++) rc[p] = rb[p];   // DoG row index clamped to height-1
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int p = 1; p <= NUM_SCALES; p++)
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(rb[p].x), fabsf(rb[p].y)), fmaxf(fabsf(rb[p].z), fabsf(rb[p].w))));
+    if (__any(amax > thresh)) {
+      const unsigned mask = extrema_mask(ra, rb, rc, thresh);
+      if (tester && mask) push_candidates(mask, q, y, g.width, cnt, list, cand_cap, octave);
+    }
+#pragma unroll
+    for (int p = 0; p < NUM_DOG; p++) { ra[p] = rb[p]; rb[p] = rc[p]; }
+  }
+}
+
+// ------------------------------------------------------------------- refine
+struct RefineParams {
+  int width, height, pitch, nframes;
+  float edge_limit, factor, lowest_scale, subsampling;
+  float scmul[NUM_SCALES];     // powf(2, s/NUM_SCALES), computed on the host like the oracle
+  int octave, max_pts;
+  unsigned cand_cap;
+};
+
+// 3x3 neighbourhood of 4 consecutive blur scales around (x, y), recomputed from the octave
+// base image with the blur chains of blur_quad() / oracle orc_laplace (vertical pass first,
+// then horizontal; clamp-to-edge), so the values are bit-identical to the streamed DoG.
+__device__ __forceinline__ void blur_patch(const float *img, int w, int h, int pitch, const float (&tk)[4][5],
+                                           int x, int y, float (&b)[4][3][3])
+{
+  float vres[4][3][11];                 // vertical results: [blur][row y-1..y+1][col x-5..x+5]
+#pragma unroll
+  for (int cx = 0; cx < 11; cx++) {
+    const float *col = img + clampi(x + cx - 5, 0, w - 1);
+    float r[11];                        // rows y-5 .. y+5 (clamped)
+#pragma unroll
+    for (int j = 0; j < 11; j++) r[j] = col[(size_t)clampi(y + j - 5, 0, h - 1) * pitch];
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+      const float c = r[dy + 4];
+      const float p1 = r[dy + 3] + r[dy + 5], p2 = r[dy + 2] + r[dy + 6];
+      const float p3 = r[dy + 1] + r[dy + 7], p4 = r[dy + 0] + r[dy + 8];
+#pragma unroll
+      for (int bs = 0; bs < 4; bs++)
+        vres[bs][dy][cx] = conv9(tk[bs][0], tk[bs][1], tk[bs][2], tk[bs][3], tk[bs][4], c, p1, p2, p3, p4);
+    }
+  }
+#pragma unroll
+  for (int bs = 0; bs < 4; bs++)
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++) {
+        const float *v = &vres[bs][dy][dx];     // v[4] is the centre column
+        b[bs][dy][dx] = conv9(tk[bs][0], tk[bs][1], tk[bs][2], tk[bs][3], tk[bs][4], v[4], v[3] + v[5],
+                              v[2] + v[6], v[1] + v[7], v[0] + v[8]);
+      }
+}
+
+template <bool FROM_BASE>
+__global__ __launch_bounds__(64) void refine_kernel(const float *__restrict__ src, long long src_frame_stride,
+                                                    LaplaceTaps taps, RefineParams P,
+                                                    unsigned *__restrict__ counters,
+                                                    const unsigned *__restrict__ cand, SiftPointD *__restrict__ pts)
+{
+  const int frame = blockIdx.y;
+  unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const unsigned *list = cand + (size_t)frame * P.cand_cap;
+  SiftPointD *out = pts + (size_t)frame * P.max_pts;
+  const float *img = src + (long long)frame * src_frame_stride;
+  const int o = P.octave;
+  // counter protocol of cudaSiftD.cu:1297-1300: octave o starts where octave o-1 ended
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned start = cnt[2 * o - 1];
+    atomicMax(&cnt[2 * o + 0], start);
+    atomicMax(&cnt[2 * o + 1], start);
+  }
+  const unsigned ncand = min(cnt[CNT_CAND + o], P.cand_cap);
+  const size_t plane = (size_t)P.height * P.pitch;
+  for (unsigned ci = blockIdx.x * blockDim.x + threadIdx.x; ci < ncand; ci += gridDim.x * blockDim.x) {
+    const unsigned code = list[ci];
+    const int x = code & 0x3fff, y = (code >> 14) & 0x3fff, s = code >> 28;
+    float d[3][3][3];       // [plane s..s+2][dy][dx]
+    if (FROM_BASE) {
+      float tk[4][5];                    // taps of blur scales s .. s+3 (static selects, no dynamic indexing)
+#pragma unroll
+      for (int bs = 0; bs < 4; bs++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          float t = taps.k[bs][j];
+#pragma unroll
+          for (int ss = 1; ss < NUM_SCALES; ss++) t = (s == ss) ? taps.k[ss + bs][j] : t;
+          tk[bs][j] = t;
+        }
+      float b[4][3][3];
+      blur_patch(img, P.width, P.height, P.pitch, tk, x, y, b);
+#pragma unroll
+      for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++) d[p][dy][dx] = b[p + 1][dy][dx] - b[p][dy][dx];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++)
+            d[p][dy][dx] = img[(size_t)(s + p) * plane + (size_t)(y + dy - 1) * P.pitch + (x + dx - 1)];
+    }
+    // cudaSiftD.cu:1383-1417, same expression order as oracle orc_findpoints()
+    const float val = d[1][1][1];
+    const float dxx = 2.0f * val - d[1][1][0] - d[1][1][2];
+    const float dyy = 2.0f * val - d[1][0][1] - d[1][2][1];
+    const float dxy = 0.25f * (d[1][2][2] + d[1][0][0] - d[1][0][2] - d[1][2][0]);
+    const float tra = dxx + dyy;
+    const float det = dxx * dyy - dxy * dxy;
+    if (!(tra * tra < P.edge_limit * det)) continue;
+    const float edge = (tra * tra) / det;
+    const float dx = 0.5f * (d[1][1][2] - d[1][1][0]);
+    const float dy = 0.5f * (d[1][2][1] - d[1][0][1]);
+    const float ds = 0.5f * (d[0][1][1] - d[2][1][1]);
+    const float dss = 2.0f * val - d[2][1][1] - d[0][1][1];
+    const float dxs = 0.25f * (d[2][1][2] + d[0][1][0] - d[0][1][2] - d[2][1][0]);
+    const float dys = 0.25f * (d[2][2][1] + d[0][0][1] - d[2][0][1] - d[0][2][1]);
+    const float idxx = dyy * dss - dys * dys;
+    const float idxy = dys * dxs - dxy * dss;
+    const float idxs = dxy * dys - dyy * dxs;
+    const float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
+    const float idyy = dxx * dss - dxs * dxs;
+    const float idys = dxy * dxs - dxx * dys;
+    const float idss = dxx * dyy - dxy * dxy;
+    float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
+    float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
+    float pds = idet * (idxs * dx + idys * dy + idss * ds);
+    if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
+      pdx = dx / dxx;
+      pdy = dy / dyy;
+      pds = ds / dss;
+    }
+    const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
+    float scm = P.scmul[0];
+#pragma unroll
+    for (int j = 1; j < NUM_SCALES; j++) scm = (s == j) ? P.scmul[j] : scm;
+    const float sc = scm * exp2f(pds * P.factor);
+    if (!(sc >= P.lowest_scale)) continue;
+    atomicMax(&cnt[2 * o + 0], cnt[2 * o - 1]);
+    const unsigned idx = atomicAdd(&cnt[2 * o + 0], 1u);
+    if (idx >= (unsigned)P.max_pts) { atomicAdd(&cnt[CNT_PTOVF], 1u); continue; }
+    SiftPointD *p = &out[idx];
+    p->xpos = x + pdx;
+    p->ypos = y + pdy;
+    p->scale = sc;
+    p->sharpness = val + dval;
+    p->edgeness = edge;
+    p->subsampling = P.subsampling;
+  }
+}
+
+// ------------------------------------------------------------- host wrappers
+static inline bool is_aligned16(const void *p, int pitch) { return (((uintptr_t)p) & 15) == 0 && (pitch & 3) == 0; }
+
+static inline dim3 grid_for(const StripGeom &g)
+{
+  const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
+  return dim3((unsigned)((nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+}
+
+int launch_laplace(misift_ctx *ctx, const float *base, const StripGeom &g, float *dog,
+                   long long dog_frame_stride, const LaplaceTaps &taps)
+{
+  const int al = is_aligned16(base, g.pitch) && is_aligned16(dog, g.pitch) && (g.frame_stride & 3) == 0 &&
+                 (dog_frame_stride & 3) == 0;
+  LaunchScope ls(ctx, "laplace");
+  hipLaunchKernelGGL(laplace_kernel, grid_for(g), dim3(256), 0, ctx->stream, base, g, dog, dog_frame_stride,
+                     taps, al);
+  return ls.finish();
+}
+
+int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long long dog_frame_stride,
+                  float thresh, int octave)
+{
+  const int al = is_aligned16(dog, g.pitch) && (dog_frame_stride & 3) == 0;
+  LaunchScope ls(ctx, "detect");
+  hipLaunchKernelGGL(detect_kernel, grid_for(g), dim3(256), 0, ctx->stream, dog, g, dog_frame_stride, thresh,
+                     octave, ctx->d_counters, ctx->d_cand, (unsigned)ctx->cand_cap, al);
+  return ls.finish();
+}
+
+int launch_dog_detect(misift_ctx *ctx, const float *base, const StripGeom &g, const LaplaceTaps &taps,
+                      float thresh, int octave)
+{
+  const int al = is_aligned16(base, g.pitch) && (g.frame_stride & 3) == 0;
+  LaunchScope ls(ctx, "dog_detect");
+  hipLaunchKernelGGL(dog_detect_kernel, grid_for(g), dim3(256), 0, ctx->stream, base, g, taps, thresh, octave,
+                     ctx->d_counters, ctx->d_cand, (unsigned)ctx->cand_cap, al);
+  return ls.finish();
+}
+
+int launch_refine(misift_ctx *ctx, const float *dog, long long dog_frame_stride, const float *base,
+                  long long base_frame_stride, const LaplaceTaps *taps, int w, int h, int pitch, int nframes,
+                  float edge_limit, float factor, float lowest_scale, float subsampling, int octave,
+                  SiftPointD *pts, int max_pts)
+{
+  RefineParams P;
+  P.width = w; P.height = h; P.pitch = pitch; P.nframes = nframes;
+  P.edge_limit = edge_limit; P.factor = factor; P.lowest_scale = lowest_scale; P.subsampling = subsampling;
+  for (int s = 0; s < NUM_SCALES; s++) P.scmul[s] = powf(2.0f, (float)s / NUM_SCALES);
+  P.octave = octave; P.max_pts = max_pts; P.cand_cap = (unsigned)ctx->cand_cap;
+  LaplaceTaps t;
+  if (taps) t = *taps; else memset(&t, 0, sizeof(t));
+  const dim3 grid(64, nframes);
+  LaunchScope ls(ctx, "refine");
+  if (dog)
+    hipLaunchKernelGGL(refine_kernel<false>, grid, dim3(64), 0, ctx->stream, dog, dog_frame_stride, t, P,
+                       ctx->d_counters, ctx->d_cand, pts);
+  else
+    hipLaunchKernelGGL(refine_kernel<true>, grid, dim3(64), 0, ctx->stream, base, base_frame_stride, t, P,
+                       ctx->d_counters, ctx->d_cand, pts);
+  return ls.finish();
+}

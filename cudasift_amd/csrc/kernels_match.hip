@@ -1,0 +1,231 @@
+// kernels_match.hip — brute-force descriptor matching on the fp32 matrix cores of gfx950.
+//
+//   match_kernel + match_merge_kernel replace CleanMatches (reference matching.cu:289-293)
+//   and FindMaxCorr10 (matching.cu:301-397), host MatchSiftData (matching.cu:1090-1206).
+//
+// The only dense contraction of the pipeline: S = D1 (n1 x 128) * D2^T (128 x n2), then a
+// per-row (max, second max, argmax).  Each wavefront keeps its 32 rows of D1 for the whole
+// K = 128 in VGPRs (64 registers) and sweeps 32-column tiles of D2 staged through
+// double-buffered LDS, one v_mfma_f32_32x32x2_f32 per k-pair with k ascending — so every
+// score is bit-identical to the reference's sequential fp32 FMA chain (matching.cu:343-346;
+// MI355X f32 MFMA == k-ordered fmaf chain).  The running top-2 is kept per lane, i.e. per
+// column residue (p2 mod 32); residues 4c..4c+3 form the reference's "class" c = (p2 mod 32)/4
+// (thread row iy of FindMaxCorr10), so the reference's lossy 8-class runner-up merge
+// (matching.cu:375-390) can be reproduced exactly — or replaced by the exact second best.
+// Columns are split into chunks across workgroups to fill 256 CUs; a small merge kernel
+// combines the per-chunk class triples and writes score/match/ambiguity/match_xpos/ypos.
+#include "common.hpp"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define MT_ROWS_PER_BLOCK 128
+#define MT_BSTRIDE 129           // floats per staged column: odd => conflict-free ds_read_b32 across 32 columns
+#define MT_TILE 32
+
+struct MatchGeom {
+  int row_begin, row_count;      // rows of set 1 handled by this launch
+  int n1_total;
+  int n2, ncols;                 // set-2 size, columns that take part (32*floor(n2/32) or n2)
+  int ntiles, nchunks, tiles_per_chunk;
+};
+
+// partial results: [row][chunk][3][8] : max, second, index per class
+#define MT_PART_WORDS 24
+
+__device__ __forceinline__ void top2_update(float sc, int p2, float &mx, float &sec, int &ix)
+{
+  // reference update rule (matching.cu:352-360): strict '>' so the earliest column wins ties
+  if (sc > mx) { sec = mx; mx = sc; ix = p2; }
+  else if (sc > sec) sec = sc;
+}
+
+// exact merge of two top-2 summaries of disjoint column sets (ties -> smaller column index,
+// which is what one ascending scan over the union would produce)
+__device__ __forceinline__ void top2_merge(float &mx, float &sec, int &ix, float omx, float osec, int oix)
+{
+  if (omx > mx || (omx == mx && oix >= 0 && (ix < 0 || oix < ix))) {
+    const float nsec = fmaxf(mx, osec);
+    mx = omx; ix = oix; sec = nsec;
+  } else {
+    sec = fmaxf(sec, omx);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restrict__ pts1,
+                                                       const SiftPointD *__restrict__ pts2, MatchGeom G,
+                                                       float *__restrict__ partial)
+{
+  __shared__ float Bs[2][MT_TILE * MT_BSTRIDE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int half = lane >> 5, col = lane & 31;
+  const unsigned item = xcd_remap(blockIdx.x, gridDim.x);
+  const int rb = item / G.nchunks, chunk = item % G.nchunks;
+  const int tile0 = chunk * G.tiles_per_chunk;
+  const int tile1 = min(tile0 + G.tiles_per_chunk, G.ntiles);
+
+  // ---- A fragment: row (lane&31) of this wave, k = 2t + half, t = 0..63
+  const int row_local = rb * MT_ROWS_PER_BLOCK + wave * 32 + col;          // within [0,row_count)
+  const int row_ld = G.row_begin + min(row_local, G.row_count - 1);
+  float a[64];
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(pts1[row_ld].data);
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+      const float4 v = src[j];
+      a[2 * j] = half ? v.y : v.x;
+      a[2 * j + 1] = half ? v.w : v.z;
+    }
+  }
+  // ---- per-lane running top-2 for 16 rows (accumulator register r <-> row (r&3)+8*(r>>2)+4*half)
+  float mx[16], sec[16];
+  int ix[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { mx[r] = 0.0f; sec[r] = 0.0f; ix[r] = -1; }
+
+  // ---- B staging: thread -> (column scol + 8j, float4 index f4)
+  const int scol = tid >> 5, f4 = tid & 31;
+  float4 stage[4];
+  auto gload = [&](int tile) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p2 = min(tile * MT_TILE + scol + 8 * j, G.n2 - 1);
+      stage[j] = reinterpret_cast<const float4 *>(pts2[p2].data)[f4];
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float *d = &Bs[buf][(scol + 8 * j) * MT_BSTRIDE + 4 * f4];
+      d[0] = stage[j].x; d[1] = stage[j].y; d[2] = stage[j].z; d[3] = stage[j].w;
+    }
+  };
+
+  if (tile0 < tile1) {
+    gload(tile0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int tile = tile0; tile < tile1; tile++) {
+    const int buf = (tile - tile0) & 1;
+    if (tile + 1 < tile1) gload(tile + 1);
+    const float *bcol = &Bs[buf][col * MT_BSTRIDE + half];
+    floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 64; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcol[2 * t], acc, 0, 0, 0);
+    const int p2 = tile * MT_TILE + col;
+    if (p2 < G.ncols) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) top2_update(acc[r], p2, mx[r], sec[r], ix[r]);
+    }
+    if (tile + 1 < tile1) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- reduce the 4 residues of a class (lanes 4c..4c+3 of the same half): exact merge
+#pragma unroll
+  for (int m = 1; m <= 2; m <<= 1) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float omx = __shfl_xor(mx[r], m, 64), osec = __shfl_xor(sec[r], m, 64);
+      const int oix = __shfl_xor(ix[r], m, 64);
+      top2_merge(mx[r], sec[r], ix[r], omx, osec, oix);
+    }
+  }
+  if ((lane & 3) == 0) {
+    const int cls = col >> 2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int rl = rb * MT_ROWS_PER_BLOCK + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (rl < G.row_count) {
+        float *p = partial + ((size_t)rl * G.nchunks + chunk) * MT_PART_WORDS;
+        p[cls] = mx[r];
+        p[8 + cls] = sec[r];
+        reinterpret_cast<int *>(p)[16 + cls] = ix[r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict__ pts1,
+                                                          const SiftPointD *__restrict__ pts2, MatchGeom G,
+                                                          const float *__restrict__ partial, int exact_top2)
+{
+  const int rl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rl >= G.row_count) return;
+  float cmax[8], csec[8];
+  int cidx[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) { cmax[c] = 0.0f; csec[c] = 0.0f; cidx[c] = -1; }
+  for (int ch = 0; ch < G.nchunks; ch++) {
+    const float *p = partial + ((size_t)rl * G.nchunks + ch) * MT_PART_WORDS;
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+      top2_merge(cmax[c], csec[c], cidx[c], p[c], p[8 + c], reinterpret_cast<const int *>(p)[16 + c]);
+  }
+  float max_score, sec_score;
+  int index;
+  if (exact_top2) {
+    max_score = cmax[0]; sec_score = csec[0]; index = cidx[0];
+#pragma unroll
+    for (int c = 1; c < 8; c++) top2_merge(max_score, sec_score, index, cmax[c], csec[c], cidx[c]);
+  } else {
+    // the reference's final merge, literally (matching.cu:375-390)
+    max_score = cmax[0]; sec_score = csec[0]; index = cidx[0];
+#pragma unroll
+    for (int y = 0; y < 8; y++)
+      if (index != cidx[y]) {
+        if (cmax[y] > max_score) {
+          sec_score = fmaxf(max_score, sec_score);
+          max_score = cmax[y];
+          index = cidx[y];
+        } else if (cmax[y] > sec_score)
+          sec_score = cmax[y];
+      }
+  }
+  SiftPointD *o = &pts1[G.row_begin + rl];
+  o->score = max_score;
+  o->match = index;
+  o->match_xpos = index >= 0 ? pts2[index].xpos : 0.0f;   // never reads sift2[-1] (Appendix B #9)
+  o->match_ypos = index >= 0 ? pts2[index].ypos : 0.0f;
+  o->ambiguity = sec_score / (max_score + 1e-6f);
+}
+
+int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2)
+{
+  if (row_count <= 0 || n2 <= 0) return MISIFT_OK;
+  MatchGeom G;
+  G.row_begin = row_begin; G.row_count = row_count; G.n1_total = row_begin + row_count;
+  G.n2 = n2;
+  G.ncols = ctx->opt.match_full ? n2 : MT_TILE * (n2 / MT_TILE);
+  G.ntiles = (G.ncols + MT_TILE - 1) / MT_TILE;
+  const int nrb = (row_count + MT_ROWS_PER_BLOCK - 1) / MT_ROWS_PER_BLOCK;
+  const int slots = 2 * ctx->num_cus;
+  int nchunks = (24 * slots + nrb - 1) / nrb;
+  int maxchunks = G.ntiles / 4;
+  if (maxchunks < 1) maxchunks = 1;
+  if (nchunks > maxchunks) nchunks = maxchunks;
+  if (nchunks < 1) nchunks = 1;
+  G.tiles_per_chunk = G.ntiles > 0 ? (G.ntiles + nchunks - 1) / nchunks : 1;
+  nchunks = G.ntiles > 0 ? (G.ntiles + G.tiles_per_chunk - 1) / G.tiles_per_chunk : 1;
+  G.nchunks = nchunks;
+  const size_t need = (size_t)row_count * nchunks * MT_PART_WORDS * sizeof(float);
+  if (need > ctx->match_tmp_bytes) {
+    if (ctx->d_match_tmp) HIP_TRY(hipFree(ctx->d_match_tmp));
+    ctx->d_match_tmp = nullptr; ctx->match_tmp_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->d_match_tmp, need));
+    ctx->match_tmp_bytes = need;
+  }
+  float *partial = reinterpret_cast<float *>(ctx->d_match_tmp);
+  {
+    LaunchScope ls(ctx, "match_mfma");
+    hipLaunchKernelGGL(match_kernel, dim3(nrb * nchunks), dim3(256), 0, ctx->stream, pts1, pts2, G, partial);
+    int rc = ls.finish();
+    if (rc) return rc;
+  }
+  {
+    LaunchScope ls(ctx, "match_merge");
+    hipLaunchKernelGGL(match_merge_kernel, dim3((row_count + 255) / 256), dim3(256), 0, ctx->stream, pts1, pts2,
+                       G, partial, ctx->opt.match_exact_top2);
+    return ls.finish();
+  }
+}

@@ -1,0 +1,303 @@
+// kernels_points.hip — per-keypoint kernels for gfx950 (one wavefront per keypoint).
+//
+//   orient_kernel   replaces ComputeOrientationsCONST       (reference cudaSiftD.cu:972-1057, host cudaSiftH.cu:353-369)
+//   descr_kernel    replaces ExtractSiftDescriptorsCONSTNew (reference cudaSiftD.cu:308-417 + FastAtan2 :295-306,
+//                                                            host cudaSiftH.cu:371-382)
+//   rescale_kernel  replaces RescalePositions               (reference cudaSiftD.cu:753-761)
+//
+// The reference uses 121- and 128-thread blocks (32-lane warps, texture unit
+// fetches).  Here a 64-lane wavefront owns a keypoint: 121 orientation samples
+// = 2 per lane, 256 descriptor samples = 4 per lane; bilinear "texture" fetches
+// are manual (tex2d in common.hpp, optional 8-bit weight quantisation like the
+// CUDA texture unit); histograms live in a wave-private LDS slice updated with
+// native ds_add_f32; the norms are 64-lane butterfly reductions.  Four
+// wavefronts share a workgroup only to fill the CU — they never synchronise.
+#include "common.hpp"
+
+#define WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// ------------------------------------------------------------- orientation
+__global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ base, long long base_frame_stride,
+                                                     int w, int h, int pitch, int octave,
+                                                     unsigned *__restrict__ counters, SiftPointD *__restrict__ pts,
+                                                     int max_pts, int frac8)
+{
+  __shared__ float s_hist[WAVES_PER_BLOCK][64];
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  const float *img = base + (long long)frame * base_frame_stride;
+  unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  SiftPointD *sift = pts + (size_t)frame * max_pts;
+  float *hist = s_hist[wave];
+  float *gauss = s_gauss[wave];
+  const bool q8 = frac8 != 0;
+
+  const int fstPts = (int)min(cnt[2 * octave - 1], (unsigned)max_pts);
+  const int totPts = (int)min(cnt[2 * octave + 0], (unsigned)max_pts);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&cnt[2 * octave + 1], cnt[2 * octave + 0]);
+
+  for (int bx = fstPts + blockIdx.x * WAVES_PER_BLOCK + wave; bx < totPts; bx += gridDim.x * WAVES_PER_BLOCK) {
+    const float scale = sift[bx].scale;
+    const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
+    if (lane < 11) gauss[lane] = expf(i2sigma2 * (lane - 5) * (lane - 5));
+    hist[lane] = 0.0f;
+    wave_sync();
+    const float xp = sift[bx].xpos - 4.5f;
+    const float yp = sift[bx].ypos - 4.5f;
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+      const int tx = lane + 64 * rep;
+      if (tx < 121) {
+        const int yd = tx / 11;
+        const int xd = tx - yd * 11;
+        const float xf = xp + xd;
+        const float yf = yp + yd;
+        const float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q8) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q8);
+        const float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q8) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q8);
+        int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+        if (bin > 31) bin = 0;
+        const float grad = sqrtf(dx * dx + dy * dy);
+        atomicAdd(&hist[bin], grad * gauss[xd] * gauss[yd]);
+      }
+    }
+    wave_sync();
+    const int t = lane & 31;
+    const int x1m = (t >= 1 ? t - 1 : t + 31), x1p = (t <= 30 ? t + 1 : t - 31);
+    const int x2m = (t >= 2 ? t - 2 : t + 30), x2p = (t <= 29 ? t + 2 : t - 30);
+    if (lane < 32)
+      hist[t + 32] = 6.0f * hist[t] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
+    wave_sync();
+    if (lane < 32) {
+      const float v = hist[32 + t];
+      hist[t] = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
+    }
+    wave_sync();
+    if (lane == 0) {
+      float maxval1 = 0.0f, maxval2 = 0.0f;
+      int i1 = -1, i2 = -1;
+      for (int i = 0; i < 32; i++) {
+        const float v = hist[i];
+        if (v > maxval1) {
+          maxval2 = maxval1; maxval1 = v; i2 = i1; i1 = i;
+        } else if (v > maxval2) {
+          maxval2 = v; i2 = i;
+        }
+      }
+      if (i1 < 0) {
+        sift[bx].orientation = 0.0f;                  // empty histogram
+      } else {
+        const float val1 = hist[32 + ((i1 + 1) & 31)];
+        const float val2 = hist[32 + ((i1 + 31) & 31)];
+        const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
+        sift[bx].orientation = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+        if (maxval2 > 0.8f * maxval1) {
+          const float v1 = hist[32 + ((i2 + 1) & 31)];
+          const float v2 = hist[32 + ((i2 + 31) & 31)];
+          const float peak2 = i2 + 0.5f * (v1 - v2) / (2.0f * maxval2 - v1 - v2);
+          atomicMax(&cnt[2 * octave + 1], cnt[2 * octave + 0]);
+          const unsigned idx = atomicAdd(&cnt[2 * octave + 1], 1u);
+          if (idx < (unsigned)max_pts) {
+            sift[idx].xpos = sift[bx].xpos;
+            sift[idx].ypos = sift[bx].ypos;
+            sift[idx].scale = sift[bx].scale;
+            sift[idx].sharpness = sift[bx].sharpness;
+            sift[idx].edgeness = sift[bx].edgeness;
+            sift[idx].orientation = 11.25f * (peak2 < 0.0f ? peak2 + 32.0f : peak2);
+            sift[idx].subsampling = sift[bx].subsampling;
+          } else {
+            atomicAdd(&cnt[CNT_PTOVF], 1u);
+          }
+        }
+      }
+    }
+    wave_sync();
+  }
+}
+
+// -------------------------------------------------------------- descriptors
+__device__ __forceinline__ float fast_atan2(float y, float x)
+{
+  const float absx = fabsf(x), absy = fabsf(y);
+  const float mx = fmaxf(absx, absy), mn = fminf(absx, absy);
+  if (mx == 0.0f) return 0.0f;
+  const float a = mn / mx;
+  const float s = a * a;
+  float r = ((-0.0464964749f * s + 0.15931422f) * s - 0.327622764f) * s * a + a;
+  r = (absy > absx ? 1.57079637f - r : r);
+  r = (x < 0 ? 3.14159274f - r : r);
+  r = (y < 0 ? -r : r);
+  return r;
+}
+
+__device__ __forceinline__ void vote(float *buffer, int idx, float val)
+{
+  if (idx >= 0 && idx < 128) atomicAdd(&buffer[idx], val);
+}
+
+__global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ base, long long base_frame_stride,
+                                                    int w, int h, int pitch, float subsampling, int octave,
+                                                    const unsigned *__restrict__ counters,
+                                                    SiftPointD *__restrict__ pts, int max_pts, int frac8)
+{
+  __shared__ float s_buf[WAVES_PER_BLOCK][128];
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  const float *img = base + (long long)frame * base_frame_stride;
+  const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  SiftPointD *sift = pts + (size_t)frame * max_pts;
+  float *buffer = s_buf[wave];
+  float *gauss = s_gauss[wave];
+  const bool q8 = frac8 != 0;
+  if (lane < 16) gauss[lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
+
+  const int fstPts = (int)min(cnt[2 * octave - 1], (unsigned)max_pts);
+  const int totPts = (int)min(cnt[2 * octave + 1], (unsigned)max_pts);
+  for (int bx = fstPts + blockIdx.x * WAVES_PER_BLOCK + wave; bx < totPts; bx += gridDim.x * WAVES_PER_BLOCK) {
+    buffer[lane] = 0.0f;
+    buffer[lane + 64] = 0.0f;
+    wave_sync();
+    const float px = sift[bx].xpos, py = sift[bx].ypos, pscale = sift[bx].scale;
+    const float theta = 2.0f * 3.1415f / 360.0f * sift[bx].orientation;
+    const float sina = sinf(theta);
+    const float cosa = cosf(theta);
+    const float scale = 12.0f / 16.0f * pscale;
+    const float ssina = scale * sina;
+    const float scosa = scale * cosa;
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+      const int id = lane + 64 * rep;
+      const int tx = id & 15, y = id >> 4;
+      const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
+      const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+      const float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q8) -
+                       tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, q8);
+      const float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, q8) -
+                       tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q8);
+      const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+      float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+
+      const int hori = (tx + 2) / 4 - 1;
+      const float horf = (tx - 1.5f) / 4.0f - hori;
+      const float ihorf = 1.0f - horf;
+      const int veri = (y + 2) / 4 - 1;
+      const float verf = (y - 1.5f) / 4.0f - veri;
+      const float iverf = 1.0f - verf;
+      const int angi = (int)angf;
+      const int angp = (angi < 7 ? angi + 1 : 0);
+      angf -= angi;
+      const float iangf = 1.0f - angf;
+
+      const int hist = 8 * (4 * veri + hori);
+      const int p1 = angi + hist;
+      const int p2 = angp + hist;
+      if (tx >= 2) {
+        const float grad1 = ihorf * grad;
+        if (y >= 2) {
+          const float grad2 = iverf * grad1;
+          vote(buffer, p1, iangf * grad2);
+          vote(buffer, p2, angf * grad2);
+        }
+        if (y <= 13) {
+          const float grad2 = verf * grad1;
+          vote(buffer, p1 + 32, iangf * grad2);
+          vote(buffer, p2 + 32, angf * grad2);
+        }
+      }
+      if (tx <= 13) {
+        const float grad1 = horf * grad;
+        if (y >= 2) {
+          const float grad2 = iverf * grad1;
+          vote(buffer, p1 + 8, iangf * grad2);
+          vote(buffer, p2 + 8, angf * grad2);
+        }
+        if (y <= 13) {
+          const float grad2 = verf * grad1;
+          vote(buffer, p1 + 40, iangf * grad2);
+          vote(buffer, p2 + 40, angf * grad2);
+        }
+      }
+    }
+    wave_sync();
+    // normalise, clamp at 0.2, normalise again (reference cudaSiftD.cu:390-409)
+    const float b0 = buffer[lane], b1 = buffer[lane + 64];
+    const float tsum1 = wave_sum(b0 * b0 + b1 * b1);
+    const float rs1 = 1.0f / sqrtf(tsum1);
+    const float c0 = fminf(b0 * rs1, 0.2f), c1 = fminf(b1 * rs1, 0.2f);
+    const float tsum2 = wave_sum(c0 * c0 + c1 * c1);
+    const float rs2 = 1.0f / sqrtf(tsum2);
+    sift[bx].data[lane] = c0 * rs2;
+    sift[bx].data[lane + 64] = c1 * rs2;
+    if (lane == 0) {
+      sift[bx].xpos = px * subsampling;
+      sift[bx].ypos = py * subsampling;
+      sift[bx].scale = pscale * subsampling;
+    }
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------ rescale
+__global__ void rescale_kernel(SiftPointD *pts, int npts, float scale)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npts) {
+    pts[i].xpos *= scale;
+    pts[i].ypos *= scale;
+    pts[i].scale *= scale;
+  }
+}
+
+// ------------------------------------------------------------- host wrappers
+static inline int points_grid_x(misift_ctx *ctx, int nframes)
+{
+  // enough wavefronts to cover a few thousand keypoints per frame while keeping
+  // the total near a few waves per SIMD when many frames are batched
+  int per_frame = (ctx->num_cus * 8 + nframes - 1) / nframes;
+  if (per_frame < 8) per_frame = 8;
+  if (per_frame > 512) per_frame = 512;
+  return per_frame;
+}
+
+int launch_orient(misift_ctx *ctx, const float *base, long long base_frame_stride, int w, int h, int pitch,
+                  int nframes, int octave, SiftPointD *pts, int max_pts)
+{
+  LaunchScope ls(ctx, "orient");
+  hipLaunchKernelGGL(orient_kernel, dim3(points_grid_x(ctx, nframes), nframes), dim3(256), 0, ctx->stream, base,
+                     base_frame_stride, w, h, pitch, octave, ctx->d_counters, pts, max_pts,
+                     ctx->opt.texfrac_bits == 8 ? 1 : 0);
+  return ls.finish();
+}
+
+int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride, int w, int h, int pitch,
+                 int nframes, float subsampling, int octave, SiftPointD *pts, int max_pts)
+{
+  LaunchScope ls(ctx, "descr");
+  hipLaunchKernelGGL(descr_kernel, dim3(points_grid_x(ctx, nframes), nframes), dim3(256), 0, ctx->stream, base,
+                     base_frame_stride, w, h, pitch, subsampling, octave, ctx->d_counters, pts, max_pts,
+                     ctx->opt.texfrac_bits == 8 ? 1 : 0);
+  return ls.finish();
+}
+
+int launch_rescale(misift_ctx *ctx, SiftPointD *pts, int npts, float scale)
+{
+  if (npts <= 0) return MISIFT_OK;
+  LaunchScope ls(ctx, "rescale");
+  hipLaunchKernelGGL(rescale_kernel, dim3((npts + 255) / 256), dim3(256), 0, ctx->stream, pts, npts, scale);
+  return ls.finish();
+}

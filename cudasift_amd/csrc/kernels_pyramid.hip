@@ -1,0 +1,211 @@
+// kernels_pyramid.hip — Gaussian pyramid kernels for gfx950 (wave64).
+//
+//   lowpass_kernel    replaces LowPassBlock   (reference cudaSiftD.cu:1986-2037, host cudaSiftH.cu:406-435)
+//   scaledown_kernel  replaces ScaleDown      (reference cudaSiftD.cu:84-168,    host cudaSiftH.cu:308-338)
+//   scaleup_kernel    replaces ScaleUp        (reference cudaSiftD.cu:170-190,   host cudaSiftH.cu:340-351)
+//
+// Design (not a translation of the reference's 32-lane shuffle / 16-row ring
+// tilings): every wavefront streams down a 256-pixel-wide strip.  A lane owns a
+// quad (float4) per row, so each image row is one coalesced 1 KiB dwordx4 read
+// per wavefront; the radius-4 horizontal neighbourhood is exactly the two
+// adjacent lanes' quads, fetched with DPP wave shifts (no LDS, no re-read); the
+// vertical filter window lives in VGPRs and slides one row per step, so every
+// input row is read once per segment and every output row written once.
+// HBM-bound: algorithmic bytes are 8 B/px (lowpass) and 5 B/px of input (scaledown).
+//
+// Arithmetic is the explicit fmaf chain of oracle/sift_oracle.c (bit-identical).
+#include "common.hpp"
+
+#define WAVES_PER_BLOCK 4
+#define OUT_LANES 62
+
+struct ItemCoord { int frame, strip, seg; bool valid; };
+
+__device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
+{
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const long long item = (long long)lb * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
+  ItemCoord c;
+  c.valid = item < nitems;
+  c.seg = (int)(item % g.nsegs);
+  const long long r = item / g.nsegs;
+  c.strip = (int)(r % g.nstrips);
+  c.frame = (int)(r / g.nstrips);
+  return c;
+}
+
+__device__ __forceinline__ void store_quad(float *row, int q, int width, bool aligned, float4 v)
+{
+  const int x = 4 * q;
+  if (aligned && x + 3 < width) {
+    *reinterpret_cast<float4 *>(row + x) = v;
+  } else {
+    if (x < width) row[x] = v.x;
+    if (x + 1 < width) row[x + 1] = v.y;
+    if (x + 2 < width) row[x + 2] = v.z;
+    if (x + 3 < width) row[x + 3] = v.w;
+  }
+}
+
+// ------------------------------------------------------------------ LowPass
+// out = G9^T (vertical) applied to G9 (horizontal) applied to in, clamp-to-edge.
+__global__ __launch_bounds__(256) void lowpass_kernel(const float *__restrict__ src, StripGeom g,
+                                                      float *__restrict__ dst, int dpitch,
+                                                      long long dst_frame_stride, Taps5 t, int src_aligned,
+                                                      int dst_aligned)
+{
+  const ItemCoord it = decode_item(g);
+  if (!it.valid) return;
+  const int lane = threadIdx.x & 63;
+  const int q = it.strip * OUT_LANES + lane - 1;
+  const float *img = src + (long long)it.frame * g.frame_stride;
+  float *out = dst + (long long)it.frame * dst_frame_stride;
+  const int y0 = it.seg * g.seg_rows;
+  const int y1 = min(y0 + g.seg_rows, g.height);
+  const float k0 = t.k[0], k1 = t.k[1], k2 = t.k[2], k3 = t.k[3], k4 = t.k[4];
+  const bool sal = src_aligned != 0, dal = dst_aligned != 0;
+
+  auto hrow = [&](int y) -> float4 {
+    const int yc = clampi(y, 0, g.height - 1);
+    const float4 c = load_quad(img + (size_t)yc * g.pitch, q, g.width, sal);
+    const float4 l = quad_from_left(c);
+    const float4 r = quad_from_right(c);
+    float4 h;
+    h.x = conv9(k0, k1, k2, k3, k4, c.x, c.y + l.w, c.z + l.z, c.w + l.y, r.x + l.x);
+    h.y = conv9(k0, k1, k2, k3, k4, c.y, c.z + c.x, c.w + l.w, r.x + l.z, r.y + l.y);
+    h.z = conv9(k0, k1, k2, k3, k4, c.z, c.w + c.y, r.x + c.x, r.y + l.w, r.z + l.z);
+    h.w = conv9(k0, k1, k2, k3, k4, c.w, r.x + c.z, r.y + c.y, r.z + c.x, r.w + l.w);
+    return h;
+  };
+
+  float4 w0 = hrow(y0 - 4), w1 = hrow(y0 - 3), w2 = hrow(y0 - 2), w3 = hrow(y0 - 1), w4 = hrow(y0);
+  float4 w5 = hrow(y0 + 1), w6 = hrow(y0 + 2), w7 = hrow(y0 + 3), w8;
+  const bool writer = lane >= 1 && lane <= OUT_LANES && 4 * q < g.width;
+  for (int y = y0; y < y1; y++) {
+    w8 = hrow(y + 4);
+    float4 o;
+    o.x = conv9(k0, k1, k2, k3, k4, w4.x, w3.x + w5.x, w2.x + w6.x, w1.x + w7.x, w0.x + w8.x);
+    o.y = conv9(k0, k1, k2, k3, k4, w4.y, w3.y + w5.y, w2.y + w6.y, w1.y + w7.y, w0.y + w8.y);
+    o.z = conv9(k0, k1, k2, k3, k4, w4.z, w3.z + w5.z, w2.z + w6.z, w1.z + w7.z, w0.z + w8.z);
+    o.w = conv9(k0, k1, k2, k3, k4, w4.w, w3.w + w5.w, w2.w + w6.w, w1.w + w7.w, w0.w + w8.w);
+    if (writer) store_quad(out + (size_t)y * dpitch, q, g.width, dal, o);
+    w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
+  }
+}
+
+// ---------------------------------------------------------------- ScaleDown
+// 5-tap Gaussian (variance 0.5) + 2x decimation: horizontal then vertical.
+// Geometry `g` describes the SOURCE image; strips/segments tile the OUTPUT (w/2, h/2).
+__global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict__ src, StripGeom g,
+                                                        float *__restrict__ dst, int dpitch,
+                                                        long long dst_frame_stride, Taps5 t, int src_aligned,
+                                                        int dst_aligned)
+{
+  const ItemCoord it = decode_item(g);
+  if (!it.valid) return;
+  const int lane = threadIdx.x & 63;
+  const int q = it.strip * OUT_LANES + lane - 1;          // output quad
+  const int w2 = g.width / 2, h2 = g.height / 2;
+  const float *img = src + (long long)it.frame * g.frame_stride;
+  float *out = dst + (long long)it.frame * dst_frame_stride;
+  const int y0 = it.seg * g.seg_rows;                     // output rows
+  const int y1 = min(y0 + g.seg_rows, h2);
+  const float k0 = t.k[0], k1 = t.k[1], k2 = t.k[2];      // t.k[2] = centre tap here (reference order)
+  const bool sal = src_aligned != 0, dal = dst_aligned != 0;
+
+  auto hrow = [&](int y) -> float4 {
+    const int yc = clampi(y, 0, g.height - 1);
+    const float *row = img + (size_t)yc * g.pitch;
+    const float4 A = load_quad(row, 2 * q, g.width, sal);       // input px 8q   .. 8q+3
+    const float4 B = load_quad(row, 2 * q + 1, g.width, sal);   // input px 8q+4 .. 8q+7
+    const float lz = lane_from_left(B.z), lw = lane_from_left(B.w);   // px 8q-2, 8q-1
+    const float rx = lane_from_right(A.x);                             // px 8q+8
+    float4 h;
+    float s;
+    s = k0 * (lz + A.z);  s = __builtin_fmaf(k1, lw + A.y, s);  h.x = __builtin_fmaf(k2, A.x, s);
+    s = k0 * (A.x + B.x); s = __builtin_fmaf(k1, A.y + A.w, s); h.y = __builtin_fmaf(k2, A.z, s);
+    s = k0 * (A.z + B.z); s = __builtin_fmaf(k1, A.w + B.y, s); h.z = __builtin_fmaf(k2, B.x, s);
+    s = k0 * (B.x + rx);  s = __builtin_fmaf(k1, B.y + B.w, s); h.w = __builtin_fmaf(k2, B.z, s);
+    return h;
+  };
+  auto vcomb = [&](float a0, float a1, float a2, float a3, float a4) -> float {
+    float s = k2 * a2;
+    s = __builtin_fmaf(k0, a0 + a4, s);
+    s = __builtin_fmaf(k1, a1 + a3, s);
+    return s;
+  };
+
+  const bool writer = lane >= 1 && lane <= OUT_LANES && 4 * q < w2;
+  float4 t0 = hrow(2 * y0 - 2), t1 = hrow(2 * y0 - 1), t2 = hrow(2 * y0), t3, t4;
+  for (int y = y0; y < y1; y++) {
+    t3 = hrow(2 * y + 1);
+    t4 = hrow(2 * y + 2);
+    float4 o;
+    o.x = vcomb(t0.x, t1.x, t2.x, t3.x, t4.x);
+    o.y = vcomb(t0.y, t1.y, t2.y, t3.y, t4.y);
+    o.z = vcomb(t0.z, t1.z, t2.z, t3.z, t4.z);
+    o.w = vcomb(t0.w, t1.w, t2.w, t3.w, t4.w);
+    if (writer) store_quad(out + (size_t)y * dpitch, q, w2, dal, o);
+    t0 = t2; t1 = t3; t2 = t4;
+  }
+}
+
+// ------------------------------------------------------------------ ScaleUp
+__global__ __launch_bounds__(256) void scaleup_kernel(const float *__restrict__ src, int w, int h, int spitch,
+                                                      float *__restrict__ dst, int dpitch)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const int xr = min(x + 1, w - 1), yd = min(y + 1, h - 1);
+  const float vul = src[(size_t)y * spitch + x], vur = src[(size_t)y * spitch + xr];
+  const float vdl = src[(size_t)yd * spitch + x], vdr = src[(size_t)yd * spitch + xr];
+  float2 top = make_float2(vul, 0.50f * (vul + vur));
+  float2 bot = make_float2(0.50f * (vul + vdl), 0.25f * (vul + vur + vdl + vdr));
+  *reinterpret_cast<float2 *>(dst + (size_t)(2 * y) * dpitch + 2 * x) = top;
+  *reinterpret_cast<float2 *>(dst + (size_t)(2 * y + 1) * dpitch + 2 * x) = bot;
+}
+
+// ------------------------------------------------------------- host wrappers
+static inline bool is_aligned16(const void *p, int pitch) { return (((uintptr_t)p) & 15) == 0 && (pitch & 3) == 0; }
+
+static inline dim3 grid_for(const StripGeom &g)
+{
+  const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
+  return dim3((unsigned)((nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+}
+
+int launch_lowpass(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
+                   long long dst_frame_stride, const float k9[9])
+{
+  Taps5 t;
+  for (int j = 0; j <= 4; j++) t.k[j] = k9[4 - j];    // centre first, then outward
+  const int sal = is_aligned16(src, g.pitch) && (g.frame_stride & 3) == 0;
+  const int dal = is_aligned16(dst, dpitch) && (dst_frame_stride & 3) == 0;
+  LaunchScope ls(ctx, "lowpass");
+  hipLaunchKernelGGL(lowpass_kernel, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+                     dst_frame_stride, t, sal, dal);
+  return ls.finish();
+}
+
+int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
+                     long long dst_frame_stride, const float k5[5])
+{
+  Taps5 t;
+  for (int j = 0; j < 5; j++) t.k[j] = k5[j];
+  const int sal = is_aligned16(src, g.pitch) && (g.frame_stride & 3) == 0;
+  const int dal = is_aligned16(dst, dpitch) && (dst_frame_stride & 3) == 0;
+  LaunchScope ls(ctx, "scaledown");
+  hipLaunchKernelGGL(scaledown_kernel, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+                     dst_frame_stride, t, sal, dal);
+  return ls.finish();
+}
+
+int launch_scaleup(misift_ctx *ctx, const float *src, int w, int h, int spitch, float *dst, int dpitch)
+{
+  LaunchScope ls(ctx, "scaleup");
+  hipLaunchKernelGGL(scaleup_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, ctx->stream, src, w, h,
+                     spitch, dst, dpitch);
+  return ls.finish();
+}

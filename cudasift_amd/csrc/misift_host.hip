@@ -1,0 +1,869 @@
+// misift_host.hip — host side of libmisift.so: context, memory, launch orchestration
+// and the extern "C" entry points declared in include/misift.h.
+//
+// Orchestration follows the reference's host code (cudaSiftH.cu:72-232) in WHAT is
+// computed and in the counter protocol, not in how it is scheduled: all kernels take a
+// frame dimension so a whole batch of frames goes through each pyramid level in one
+// launch; nothing is allocated, uploaded or synchronised inside the launch sequence
+// (taps travel as kernel arguments, counters are reset with one async memset, the only
+// host<->device sync is the final count read-back).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include "common.hpp"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void misift_set_error(const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *misift_last_error(void) { return g_err; }
+
+#define ARG_CHECK(cond)                                                       \
+  do {                                                                        \
+    if (!(cond)) {                                                            \
+      misift_set_error("%s: invalid argument: %s", __func__, #cond);          \
+      return MISIFT_EINVAL;                                                   \
+    }                                                                         \
+  } while (0)
+
+// --------------------------------------------------------------- profiling
+struct PendingProf { int slot; hipEvent_t a, b; };
+struct CtxExtra {
+  std::vector<PendingProf> pending;
+  std::vector<hipEvent_t> pool;
+};
+static CtxExtra *extra(misift_ctx *ctx);
+
+LaunchScope::LaunchScope(misift_ctx *c, const char *n) : ctx(c), name(n)
+{
+  if (ctx->profile) {
+    CtxExtra *x = extra(ctx);
+    hipEvent_t a, b;
+    if (x->pool.size() >= 2) {
+      a = x->pool.back(); x->pool.pop_back();
+      b = x->pool.back(); x->pool.pop_back();
+    } else {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+    }
+    int slot = -1;
+    for (int i = 0; i < ctx->nprof; i++)
+      if (!strcmp(ctx->prof[i].name, n)) slot = i;
+    if (slot < 0 && ctx->nprof < 32) {
+      slot = ctx->nprof++;
+      strncpy(ctx->prof[slot].name, n, 31);
+      ctx->prof[slot].name[31] = 0;
+      ctx->prof[slot].total_ms = 0;
+      ctx->prof[slot].calls = 0;
+    }
+    hipEventRecord(a, ctx->stream);
+    x->pending.push_back({slot, a, b});
+  }
+}
+
+int LaunchScope::finish()
+{
+  if (ctx->profile) {
+    CtxExtra *x = extra(ctx);
+    hipEventRecord(x->pending.back().b, ctx->stream);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    misift_set_error("launch of %s failed: %s", name, hipGetErrorString(e));
+    return MISIFT_EHIP;
+  }
+  return MISIFT_OK;
+}
+
+static int resolve_profile(misift_ctx *ctx)
+{
+  CtxExtra *x = extra(ctx);
+  if (x->pending.empty()) return MISIFT_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto &p : x->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess && p.slot >= 0) {
+      ctx->prof[p.slot].total_ms += ms;
+      ctx->prof[p.slot].calls++;
+    }
+    x->pool.push_back(p.a);
+    x->pool.push_back(p.b);
+  }
+  x->pending.clear();
+  return MISIFT_OK;
+}
+
+// ----------------------------------------------------------------- context
+struct CtxFull {
+  misift_ctx c;
+  CtxExtra x;
+};
+static CtxExtra *extra(misift_ctx *ctx) { return &reinterpret_cast<CtxFull *>(ctx)->x; }
+
+extern "C" int misift_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int misift_device_info(int device, char *name, int name_len, int *mem_clock_khz, int *bus_width_bits,
+                                  size_t *total_mem_bytes, int *num_cus, int *lds_bytes_per_block)
+{
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (name && name_len > 0) {
+    strncpy(name, prop.name, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (mem_clock_khz) *mem_clock_khz = prop.memoryClockRate;
+  if (bus_width_bits) *bus_width_bits = prop.memoryBusWidth;
+  if (total_mem_bytes) *total_mem_bytes = prop.totalGlobalMem;
+  if (num_cus) *num_cus = prop.multiProcessorCount;
+  if (lds_bytes_per_block) *lds_bytes_per_block = (int)prop.sharedMemPerBlock;
+  return MISIFT_OK;
+}
+
+extern "C" void misift_default_options(misift_options *opt)
+{
+  memset(opt, 0, sizeof(*opt));
+  opt->texfrac_bits = 8;
+  opt->fix_numpts = 0;
+  opt->match_full = 0;
+  opt->match_exact_top2 = 0;
+  opt->quiet = 0;
+  opt->fused = 1;
+  const char *e;
+  if ((e = getenv("MISIFT_TEXFRAC_BITS"))) opt->texfrac_bits = atoi(e);
+  if ((e = getenv("MISIFT_FIX_NUMPTS"))) opt->fix_numpts = atoi(e);
+  if ((e = getenv("MISIFT_MATCH_FULL"))) opt->match_full = atoi(e);
+  if ((e = getenv("MISIFT_MATCH_EXACT_TOP2"))) opt->match_exact_top2 = atoi(e);
+  if ((e = getenv("MISIFT_QUIET"))) opt->quiet = atoi(e);
+  if ((e = getenv("MISIFT_FUSED"))) opt->fused = atoi(e);
+}
+
+extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
+{
+  ARG_CHECK(out != nullptr);
+  int n = misift_device_count();
+  if (n <= 0) {
+    misift_set_error("no HIP device visible");
+    return MISIFT_ENODEV;
+  }
+  if (device < 0 || device >= n) device = n - 1;      // like InitCuda: clamp (cudaSiftH.cu:27)
+  HIP_TRY(hipSetDevice(device));
+  CtxFull *f = new CtxFull();
+  misift_ctx *ctx = &f->c;
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->device = device;
+  ctx->stream = (hipStream_t)stream;
+  misift_default_options(&ctx->opt);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_TRY(hipEventCreate(&ctx->ev0));
+  HIP_TRY(hipEventCreate(&ctx->ev1));
+  int rc = misift_ensure_frames(ctx, 1, 65536);
+  if (rc) return rc;
+  rc = launch_selftest(ctx);
+  if (rc) return rc;
+  *out = ctx;
+  return MISIFT_OK;
+}
+
+extern "C" void misift_ctx_destroy(misift_ctx *ctx)
+{
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  CtxExtra *x = extra(ctx);
+  for (auto &p : x->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto e : x->pool) hipEventDestroy(e);
+  if (ctx->d_counters) hipFree(ctx->d_counters);
+  if (ctx->h_counters) hipHostFree(ctx->h_counters);
+  if (ctx->d_cand) hipFree(ctx->d_cand);
+  if (ctx->d_own_scratch) hipFree(ctx->d_own_scratch);
+  if (ctx->d_match_tmp) hipFree(ctx->d_match_tmp);
+  hipEventDestroy(ctx->ev0);
+  hipEventDestroy(ctx->ev1);
+  delete reinterpret_cast<CtxFull *>(ctx);
+}
+
+extern "C" int misift_ctx_set_stream(misift_ctx *ctx, void *stream)
+{
+  ARG_CHECK(ctx != nullptr);
+  ctx->stream = (hipStream_t)stream;
+  return MISIFT_OK;
+}
+
+extern "C" int misift_ctx_sync(misift_ctx *ctx)
+{
+  ARG_CHECK(ctx != nullptr);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_set_options(misift_ctx *ctx, const misift_options *opt)
+{
+  ARG_CHECK(ctx && opt);
+  ARG_CHECK(opt->texfrac_bits == 8 || opt->texfrac_bits == 23 || opt->texfrac_bits == 0);
+  ctx->opt = *opt;
+  return MISIFT_OK;
+}
+
+extern "C" int misift_get_options(misift_ctx *ctx, misift_options *opt)
+{
+  ARG_CHECK(ctx && opt);
+  *opt = ctx->opt;
+  return MISIFT_OK;
+}
+
+int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
+{
+  if (nframes > ctx->cap_frames) {
+    if (ctx->d_counters) HIP_TRY(hipFree(ctx->d_counters));
+    if (ctx->h_counters) HIP_TRY(hipHostFree(ctx->h_counters));
+    ctx->d_counters = nullptr; ctx->h_counters = nullptr;
+    HIP_TRY(hipMalloc((void **)&ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, hipHostMallocDefault));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, ctx->stream));
+    memset(ctx->h_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes);
+  }
+  if (nframes > ctx->cap_frames || cand_cap > ctx->cand_cap) {
+    const int nf = nframes > ctx->cap_frames ? nframes : ctx->cap_frames;
+    const size_t cc = cand_cap > ctx->cand_cap ? cand_cap : ctx->cand_cap;
+    if (ctx->d_cand) HIP_TRY(hipFree(ctx->d_cand));
+    ctx->d_cand = nullptr;
+    HIP_TRY(hipMalloc((void **)&ctx->d_cand, sizeof(unsigned) * cc * nf));
+    ctx->cand_cap = cc;
+    ctx->cap_frames = nf;
+  }
+  return MISIFT_OK;
+}
+
+// ------------------------------------------------------------------ memory
+extern "C" int misift_malloc(size_t bytes, void **out)
+{
+  ARG_CHECK(out != nullptr);
+  *out = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {
+    misift_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return MISIFT_ENOMEM;
+  }
+  return MISIFT_OK;
+}
+
+extern "C" int misift_free(void *ptr)
+{
+  if (ptr) HIP_TRY(hipFree(ptr));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_memset(misift_ctx *ctx, void *ptr, int value, size_t bytes)
+{
+  ARG_CHECK(ctx && ptr);
+  HIP_TRY(hipMemsetAsync(ptr, value, bytes, ctx->stream));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_copy_h2d(misift_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+  ARG_CHECK(ctx && dst && src);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_copy_d2h(misift_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+  ARG_CHECK(ctx && dst && src);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
+static inline int ialign_up(int a, int b) { return (a % b != 0) ? (a - a % b + b) : a; }
+
+extern "C" int misift_image_alloc(int width, int height, float **d_out, int *pitch_floats)
+{
+  ARG_CHECK(width > 0 && height > 0 && d_out && pitch_floats);
+  const int p = ialign_up(width, 128);
+  void *ptr = nullptr;
+  int rc = misift_malloc(sizeof(float) * (size_t)p * height, &ptr);
+  if (rc) return rc;
+  *d_out = (float *)ptr;
+  *pitch_floats = p;
+  return MISIFT_OK;
+}
+
+extern "C" int misift_upload_2d(misift_ctx *ctx, float *d_dst, int dpitch, const float *h_src, int hpitch, int width,
+                                int height)
+{
+  ARG_CHECK(ctx && d_dst && h_src && width > 0 && height > 0);
+  HIP_TRY(hipMemcpy2DAsync(d_dst, sizeof(float) * (size_t)dpitch, h_src, sizeof(float) * (size_t)hpitch,
+                           sizeof(float) * (size_t)width, height, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_download_2d(misift_ctx *ctx, float *h_dst, int hpitch, const float *d_src, int dpitch, int width,
+                                  int height)
+{
+  ARG_CHECK(ctx && h_dst && d_src && width > 0 && height > 0);
+  HIP_TRY(hipMemcpy2DAsync(h_dst, sizeof(float) * (size_t)hpitch, d_src, sizeof(float) * (size_t)dpitch,
+                           sizeof(float) * (size_t)width, height, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_download_fields(misift_ctx *ctx, void *h_pts, const void *d_pts, int npts, int offset, int nfields)
+{
+  ARG_CHECK(ctx && h_pts && d_pts && npts >= 0 && offset >= 0 && nfields > 0 &&
+            offset + 4 * nfields <= MISIFT_POINT_BYTES);
+  if (npts == 0) return MISIFT_OK;
+  HIP_TRY(hipMemcpy2DAsync((char *)h_pts + offset, MISIFT_POINT_BYTES, (const char *)d_pts + offset,
+                           MISIFT_POINT_BYTES, 4 * (size_t)nfields, npts, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
+// Reference sizing (cudaSiftH.cu:39-57): sums numOctaves+1 levels, kept for compatibility.
+static void scratch_sizes(int width, int height, int num_octaves, int scale_up, size_t *size_img, size_t *size_tmp)
+{
+  const int nd = NUM_SCALES + 3;
+  int w = width * (scale_up ? 2 : 1), h = height * (scale_up ? 2 : 1);
+  int p = ialign_up(w, 128);
+  size_t size = (size_t)h * p, sizeTmp = (size_t)nd * h * p;
+  for (int i = 0; i < num_octaves; i++) {
+    w /= 2;
+    h /= 2;
+    const int p2 = ialign_up(w, 128);
+    size += (size_t)h * p2;
+    sizeTmp += (size_t)nd * h * p2;
+  }
+  *size_img = size;
+  *size_tmp = sizeTmp;
+}
+
+extern "C" size_t misift_scratch_floats(int width, int height, int num_octaves, int scale_up)
+{
+  size_t a, b;
+  scratch_sizes(width, height, num_octaves, scale_up, &a, &b);
+  size_t total = a + b;
+  return (total + 4095) / 4096 * 4096;     // the reference rounds the arena to 4096-float rows (:58)
+}
+
+// -------------------------------------------------------------- host taps
+// cudaSiftH.cu:408-418
+static void lowpass_taps(float scale, float k[9])
+{
+  float kernelSum = 0.0f;
+  const float ivar2 = 1.0f / (2.0f * scale * scale);
+  for (int j = -4; j <= 4; j++) {
+    k[j + 4] = (float)expf((float)(-(double)j * j * ivar2));
+    kernelSum += k[j + 4];
+  }
+  for (int j = -4; j <= 4; j++) k[j + 4] /= kernelSum;
+}
+
+// cudaSiftH.cu:316-323
+static void scaledown_taps(float variance, float k[5])
+{
+  float kernelSum = 0.0f;
+  for (int j = 0; j < 5; j++) {
+    k[j] = (float)expf((float)(-(double)(j - 2) * (j - 2) / 2.0 / variance));
+    kernelSum += k[j];
+  }
+  for (int j = 0; j < 5; j++) k[j] /= kernelSum;
+}
+
+// cudaSiftH.cu:439-458
+static void laplace_taps_rec(int numOctaves, float initBlur, float *kernel)
+{
+  if (numOctaves > 1) {
+    const float totInitBlur = sqrtf(initBlur * initBlur + 0.5f * 0.5f) / 2.0f;
+    laplace_taps_rec(numOctaves - 1, totInitBlur, kernel);
+  }
+  float scale = powf(2.0f, -1.0f / NUM_SCALES);
+  const float diffScale = powf(2.0f, 1.0f / NUM_SCALES);
+  for (int i = 0; i < NUM_SCALES + 3; i++) {
+    float kernelSum = 0.0f;
+    const float var = scale * scale - initBlur * initBlur;
+    for (int j = 0; j <= 4; j++) {
+      kernel[numOctaves * 12 * 16 + 16 * i + j] = (float)expf((float)(-(double)j * j / 2.0 / var));
+      kernelSum += (j == 0 ? 1 : 2) * kernel[numOctaves * 12 * 16 + 16 * i + j];
+    }
+    for (int j = 0; j <= 4; j++) kernel[numOctaves * 12 * 16 + 16 * i + j] /= kernelSum;
+    scale *= diffScale;
+  }
+}
+
+extern "C" int misift_laplace_taps(int num_octaves, float *taps)
+{
+  ARG_CHECK(taps && num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);
+  memset(taps, 0, sizeof(float) * 8 * 12 * 16);
+  laplace_taps_rec(num_octaves, 0.0f, taps);
+  return MISIFT_OK;
+}
+
+static LaplaceTaps octave_taps(const float *table, int octave)
+{
+  LaplaceTaps t;
+  for (int s = 0; s < NUM_BLURS; s++)
+    for (int j = 0; j < 5; j++) t.k[s][j] = table[octave * 12 * 16 + 16 * s + j];
+  return t;
+}
+
+// ---------------------------------------------------------------- geometry
+static StripGeom make_geom(misift_ctx *ctx, int w, int h, int pitch, int nframes, long long frame_stride,
+                           int out_w, int out_rows, int out_lanes)
+{
+  StripGeom g;
+  g.width = w; g.height = h; g.pitch = pitch;
+  g.nframes = nframes; g.frame_stride = frame_stride;
+  const int nquads = (out_w + 3) / 4;
+  g.nstrips = (nquads + out_lanes - 1) / out_lanes;
+  if (g.nstrips < 1) g.nstrips = 1;
+  // aim for ~16 wavefronts per CU across the launch; segments between 8 and 128 rows
+  const long long target = (long long)ctx->num_cus * 16;
+  long long want = (target + (long long)nframes * g.nstrips - 1) / ((long long)nframes * g.nstrips);
+  if (want < 1) want = 1;
+  int seg = (int)((out_rows + want - 1) / want);
+  seg = (seg + 7) / 8 * 8;
+  if (seg < 8) seg = 8;
+  if (seg > 128) seg = 128;
+  g.seg_rows = seg;
+  g.nsegs = (out_rows + seg - 1) / seg;
+  if (g.nsegs < 1) g.nsegs = 1;
+  return g;
+}
+
+// --------------------------------------------------------------- selftest
+__global__ void selftest_kernel(float *out)
+{
+  const int lane = threadIdx.x;
+  const float v = (float)(lane + 1);
+  out[lane] = lane_from_left(v);          // expect lane      (0 for lane 0)
+  out[64 + lane] = lane_from_right(v);    // expect lane + 2  (0 for lane 63)
+}
+
+int launch_selftest(misift_ctx *ctx)
+{
+  float *d = nullptr;
+  float h[128];
+  HIP_TRY(hipMalloc((void **)&d, sizeof(h)));
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipFree(d));
+  for (int l = 1; l < 64; l++)
+    if (h[l] != (float)l) {
+      misift_set_error("selftest: DPP wave_shr:1 lane %d got %g, expected %d", l, h[l], l);
+      return MISIFT_EHIP;
+    }
+  for (int l = 0; l < 63; l++)
+    if (h[64 + l] != (float)(l + 2)) {
+      misift_set_error("selftest: DPP wave_shl:1 lane %d got %g, expected %d", l, h[64 + l], l + 2);
+      return MISIFT_EHIP;
+    }
+  return MISIFT_OK;
+}
+
+// -------------------------------------------------------------- extraction
+struct Level { int w, h, p; float *img; };   // img = frame-0 pointer of that pyramid level
+
+static int extract_impl(misift_ctx *ctx, const float *d_imgs, int nframes, long long frame_stride, int width,
+                        int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
+                        int scale_up, float *d_scratch, SiftPointD *pts, int max_pts)
+{
+  ARG_CHECK(ctx && d_imgs && pts);
+  ARG_CHECK(nframes >= 1 && width >= 16 && height >= 16 && pitch >= width);
+  ARG_CHECK((width >> (num_octaves - 1)) >= 8 && (height >> (num_octaves - 1)) >= 8);
+  ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);
+  ARG_CHECK(max_pts >= 1);
+  ARG_CHECK(width * (scale_up ? 2 : 1) < 16384 && height * (scale_up ? 2 : 1) < 16384);
+  ARG_CHECK(!scale_up || nframes == 1);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = misift_ensure_frames(ctx, nframes, 2 * (size_t)max_pts);
+  if (rc) return rc;
+  const size_t S = misift_scratch_floats(width, height, num_octaves, scale_up);
+  if (!d_scratch) {
+    if (ctx->own_scratch_floats < S * nframes) {
+      if (ctx->d_own_scratch) HIP_TRY(hipFree(ctx->d_own_scratch));
+      ctx->d_own_scratch = nullptr; ctx->own_scratch_floats = 0;
+      HIP_TRY(hipMalloc((void **)&ctx->d_own_scratch, sizeof(float) * S * nframes));
+      ctx->own_scratch_floats = S * nframes;
+    }
+    d_scratch = ctx->d_own_scratch;
+  }
+  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, ctx->stream));
+
+  float table[8 * 12 * 16];
+  misift_laplace_taps(num_octaves, table);          // cudaSiftH.cu:109-111
+  float k9[9], k5[5];
+  lowpass_taps(init_blur > 0.001f ? init_blur : 0.001f, k9);
+  scaledown_taps(0.5f, k5);
+
+  // arena layout of cudaSiftH.cu:104-107, :151-159, :179-184 (per frame, frame stride S)
+  size_t size_img, size_tmp;
+  scratch_sizes(width, height, num_octaves, scale_up, &size_img, &size_tmp);
+  const int W = width * (scale_up ? 2 : 1), H = height * (scale_up ? 2 : 1);
+  float *memoryTmp = d_scratch;
+  float *memorySub = d_scratch + size_tmp;
+  std::vector<Level> lv(num_octaves + 1);
+  {
+    int w = W, h = H;
+    float *ptr = memorySub;
+    for (int o = num_octaves; o >= 1; o--) {
+      lv[o].w = w; lv[o].h = h; lv[o].p = ialign_up(w, 128); lv[o].img = ptr;
+      ptr += (size_t)h * lv[o].p;
+      w /= 2; h /= 2;
+    }
+  }
+  const long long SS = (long long)S;
+  // --- prefilter (cudaSiftH.cu:112 / :119-123)
+  {
+    const Level &L = lv[num_octaves];
+    if (!scale_up) {
+      StripGeom g = make_geom(ctx, width, height, pitch, nframes, frame_stride, width, height, 62);
+      rc = launch_lowpass(ctx, d_imgs, g, L.img, L.p, SS, k9);
+      if (rc) return rc;
+    } else {
+      float *upImg = memoryTmp;
+      rc = launch_scaleup(ctx, d_imgs, width, height, pitch, upImg, L.p);
+      if (rc) return rc;
+      StripGeom g = make_geom(ctx, W, H, L.p, 1, SS, W, H, 62);
+      rc = launch_lowpass(ctx, upImg, g, L.img, L.p, SS, k9);
+      if (rc) return rc;
+      lowest_scale *= 2.0f;
+    }
+  }
+  // --- pyramid (ScaleDown chain of cudaSiftH.cu:153-160), finest to coarsest
+  for (int o = num_octaves; o >= 2; o--) {
+    const Level &src = lv[o], &dst = lv[o - 1];
+    StripGeom g = make_geom(ctx, src.w, src.h, src.p, nframes, SS, dst.w, dst.h, 62);
+    rc = launch_scaledown(ctx, src.img, g, dst.img, dst.p, SS, k5);
+    if (rc) return rc;
+  }
+  // --- octaves, coarsest first (cudaSiftH.cu:161 after the recursion)
+  for (int o = 1; o <= num_octaves; o++) {
+    const Level &L = lv[o];
+    const float subsampling = (float)(1 << (num_octaves - o));
+    const LaplaceTaps taps = octave_taps(table, o);
+    if (ctx->opt.fused) {
+      StripGeom g = make_geom(ctx, L.w, L.h, L.p, nframes, SS, L.w, L.h, 60);
+      rc = launch_dog_detect(ctx, L.img, g, taps, thresh, o);
+      if (rc) return rc;
+      rc = launch_refine(ctx, nullptr, 0, L.img, SS, &taps, L.w, L.h, L.p, nframes, 10.0f, 1.0f / NUM_SCALES,
+                         lowest_scale / subsampling, subsampling, o, pts, max_pts);
+      if (rc) return rc;
+    } else {
+      StripGeom g = make_geom(ctx, L.w, L.h, L.p, nframes, SS, L.w, L.h, 62);
+      rc = launch_laplace(ctx, L.img, g, memoryTmp, SS, taps);
+      if (rc) return rc;
+      rc = launch_detect(ctx, memoryTmp, g, SS, thresh, o);
+      if (rc) return rc;
+      rc = launch_refine(ctx, memoryTmp, SS, nullptr, 0, nullptr, L.w, L.h, L.p, nframes, 10.0f,
+                         1.0f / NUM_SCALES, lowest_scale / subsampling, subsampling, o, pts, max_pts);
+      if (rc) return rc;
+    }
+    rc = launch_orient(ctx, L.img, SS, L.w, L.h, L.p, nframes, o, pts, max_pts);
+    if (rc) return rc;
+    rc = launch_descr(ctx, L.img, SS, L.w, L.h, L.p, nframes, subsampling, o, pts, max_pts);
+    if (rc) return rc;
+  }
+  return MISIFT_OK;
+}
+
+static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *num_pts_out)
+{
+  HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes,
+                         hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
+  for (int f = 0; f < nframes; f++) {
+    const unsigned c = ctx->h_counters[(size_t)f * CNT_STRIDE + slot];
+    num_pts_out[f] = (int)(c < (unsigned)max_pts ? c : (unsigned)max_pts);     // cudaSiftH.cu:116
+  }
+  return MISIFT_OK;
+}
+
+extern "C" int misift_extract(misift_ctx *ctx, const float *d_img, int width, int height, int pitch, int num_octaves,
+                              float init_blur, float thresh, float lowest_scale, int scale_up, float *d_scratch,
+                              void *d_pts, int max_pts, int *num_pts_out)
+{
+  ARG_CHECK(num_pts_out != nullptr);
+  int rc = extract_impl(ctx, d_img, 1, 0, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
+                        scale_up, d_scratch, (SiftPointD *)d_pts, max_pts);
+  if (rc) return rc;
+  rc = read_counts(ctx, 1, num_octaves, max_pts, num_pts_out);
+  if (rc) return rc;
+  if (scale_up) {                                    // cudaSiftH.cu:130
+    rc = launch_rescale(ctx, (SiftPointD *)d_pts, *num_pts_out, 0.5f);
+    if (rc) return rc;
+  }
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_extract_batch(misift_ctx *ctx, const float *d_imgs, int nframes, size_t frame_stride, int width,
+                                    int height, int pitch, int num_octaves, float init_blur, float thresh,
+                                    float lowest_scale, float *d_scratch, void *d_pts, int max_pts,
+                                    int *num_pts_out)
+{
+  ARG_CHECK(num_pts_out != nullptr);
+  int rc = extract_impl(ctx, d_imgs, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
+                        init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts);
+  if (rc) return rc;
+  rc = read_counts(ctx, nframes, num_octaves, max_pts, num_pts_out);
+  if (rc) return rc;
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, int nframes, size_t frame_stride,
+                                          int width, int height, int pitch, int num_octaves, float init_blur,
+                                          float thresh, float lowest_scale, float *d_scratch, void *d_pts,
+                                          int max_pts, int *d_counts_out)
+{
+  int rc = extract_impl(ctx, d_imgs, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
+                        init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts);
+  if (rc) return rc;
+  if (d_counts_out) {
+    const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
+    HIP_TRY(hipMemcpy2DAsync(d_counts_out, sizeof(int), ctx->d_counters + slot, sizeof(unsigned) * CNT_STRIDE,
+                             sizeof(int), nframes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return MISIFT_OK;
+}
+
+extern "C" int misift_get_counters(misift_ctx *ctx, int frame, unsigned int *counters17)
+{
+  ARG_CHECK(ctx && counters17 && frame >= 0 && frame < ctx->cap_frames);
+  unsigned tmp[CNT_STRIDE];
+  HIP_TRY(hipMemcpyAsync(tmp, ctx->d_counters + (size_t)frame * CNT_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  memcpy(counters17, tmp, sizeof(unsigned) * 17);
+  return MISIFT_OK;
+}
+
+extern "C" int misift_set_counters(misift_ctx *ctx, int frame, const unsigned int *counters17)
+{
+  ARG_CHECK(ctx && counters17 && frame >= 0 && frame < ctx->cap_frames);
+  unsigned tmp[CNT_STRIDE];
+  memset(tmp, 0, sizeof(tmp));
+  memcpy(tmp, counters17, sizeof(unsigned) * 17);
+  HIP_TRY(hipMemcpyAsync(ctx->d_counters + (size_t)frame * CNT_STRIDE, tmp, sizeof(tmp), hipMemcpyHostToDevice,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
+// ------------------------------------------------------- stage entry points
+extern "C" int misift_lowpass(misift_ctx *ctx, const float *d_src, int width, int height, int spitch, float *d_dst,
+                              int dpitch, float sigma)
+{
+  ARG_CHECK(ctx && d_src && d_dst && width > 0 && height > 0 && spitch >= width && dpitch >= width);
+  float k9[9];
+  lowpass_taps(sigma, k9);
+  StripGeom g = make_geom(ctx, width, height, spitch, 1, 0, width, height, 62);
+  int rc = launch_lowpass(ctx, d_src, g, d_dst, dpitch, 0, k9);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_scaledown(misift_ctx *ctx, const float *d_src, int width, int height, int spitch, float *d_dst,
+                                int dpitch)
+{
+  ARG_CHECK(ctx && d_src && d_dst && width > 1 && height > 1 && spitch >= width && dpitch >= width / 2);
+  float k5[5];
+  scaledown_taps(0.5f, k5);
+  StripGeom g = make_geom(ctx, width, height, spitch, 1, 0, width / 2, height / 2, 62);
+  int rc = launch_scaledown(ctx, d_src, g, d_dst, dpitch, 0, k5);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_scaleup(misift_ctx *ctx, const float *d_src, int width, int height, int spitch, float *d_dst,
+                              int dpitch)
+{
+  ARG_CHECK(ctx && d_src && d_dst && width > 0 && height > 0 && spitch >= width && dpitch >= 2 * width &&
+            (dpitch & 1) == 0);
+  int rc = launch_scaleup(ctx, d_src, width, height, spitch, d_dst, dpitch);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_laplace(misift_ctx *ctx, const float *d_base, int width, int height, int pitch, int num_octaves,
+                              int octave, float *d_dog)
+{
+  ARG_CHECK(ctx && d_base && d_dog && width > 0 && height > 0 && pitch >= width);
+  ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES && octave >= 1 && octave <= num_octaves);
+  float table[8 * 12 * 16];
+  misift_laplace_taps(num_octaves, table);
+  StripGeom g = make_geom(ctx, width, height, pitch, 1, 0, width, height, 62);
+  int rc = launch_laplace(ctx, d_base, g, d_dog, 0, octave_taps(table, octave));
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_reset_counters(misift_ctx *ctx, int max_pts)
+{
+  ARG_CHECK(ctx && max_pts >= 1);
+  int rc = misift_ensure_frames(ctx, 1, 2 * (size_t)max_pts);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * CNT_STRIDE, ctx->stream));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_findpoints(misift_ctx *ctx, const float *d_dog, int width, int height, int pitch, float thresh,
+                                 float edge_limit, float lowest_scale, float subsampling, int octave, void *d_pts,
+                                 int max_pts)
+{
+  ARG_CHECK(ctx && d_dog && d_pts && width >= 16 && height >= 16 && pitch >= width && width < 16384 && height < 16384);
+  ARG_CHECK(octave >= 1 && octave <= MISIFT_MAX_OCTAVES && max_pts >= 1);
+  int rc = misift_ensure_frames(ctx, 1, 2 * (size_t)max_pts);
+  if (rc) return rc;
+  StripGeom g = make_geom(ctx, width, height, pitch, 1, 0, width, height, 62);
+  rc = launch_detect(ctx, d_dog, g, 0, thresh, octave);
+  if (rc) return rc;
+  rc = launch_refine(ctx, d_dog, 0, nullptr, 0, nullptr, width, height, pitch, 1, edge_limit, 1.0f / NUM_SCALES,
+                     lowest_scale, subsampling, octave, (SiftPointD *)d_pts, max_pts);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_dog_findpoints(misift_ctx *ctx, const float *d_base, int width, int height, int pitch,
+                                     int num_octaves, int octave, float thresh, float edge_limit, float lowest_scale,
+                                     float subsampling, void *d_pts, int max_pts)
+{
+  ARG_CHECK(ctx && d_base && d_pts && width >= 16 && height >= 16 && pitch >= width && width < 16384 && height < 16384);
+  ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES && octave >= 1 && octave <= num_octaves);
+  int rc = misift_ensure_frames(ctx, 1, 2 * (size_t)max_pts);
+  if (rc) return rc;
+  float table[8 * 12 * 16];
+  misift_laplace_taps(num_octaves, table);
+  const LaplaceTaps taps = octave_taps(table, octave);
+  StripGeom g = make_geom(ctx, width, height, pitch, 1, 0, width, height, 60);
+  rc = launch_dog_detect(ctx, d_base, g, taps, thresh, octave);
+  if (rc) return rc;
+  rc = launch_refine(ctx, nullptr, 0, d_base, 0, &taps, width, height, pitch, 1, edge_limit, 1.0f / NUM_SCALES,
+                     lowest_scale, subsampling, octave, (SiftPointD *)d_pts, max_pts);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_orientations(misift_ctx *ctx, const float *d_base, int width, int height, int pitch, int octave,
+                                   void *d_pts, int max_pts)
+{
+  ARG_CHECK(ctx && d_base && d_pts && width > 0 && height > 0 && pitch >= width && octave >= 1 &&
+            octave <= MISIFT_MAX_OCTAVES);
+  int rc = launch_orient(ctx, d_base, 0, width, height, pitch, 1, octave, (SiftPointD *)d_pts, max_pts);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_descriptors(misift_ctx *ctx, const float *d_base, int width, int height, int pitch,
+                                  float subsampling, int octave, void *d_pts, int max_pts)
+{
+  ARG_CHECK(ctx && d_base && d_pts && width > 0 && height > 0 && pitch >= width && octave >= 1 &&
+            octave <= MISIFT_MAX_OCTAVES);
+  int rc = launch_descr(ctx, d_base, 0, width, height, pitch, 1, subsampling, octave, (SiftPointD *)d_pts, max_pts);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_rescale_positions(misift_ctx *ctx, void *d_pts, int npts, float scale)
+{
+  ARG_CHECK(ctx && d_pts && npts >= 0);
+  int rc = launch_rescale(ctx, (SiftPointD *)d_pts, npts, scale);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
+// ----------------------------------------------------------------- matching
+extern "C" int misift_match_rows(misift_ctx *ctx, void *d_pts1, int row_begin, int row_count, const void *d_pts2, int n2)
+{
+  ARG_CHECK(ctx && row_begin >= 0 && row_count >= 0 && n2 >= 0);
+  if (row_count == 0 || n2 == 0) return MISIFT_OK;       // matching.cu:1095-1096
+  ARG_CHECK(d_pts1 && d_pts2);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = launch_match(ctx, (SiftPointD *)d_pts1, row_begin, row_count, (const SiftPointD *)d_pts2, n2);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));              // matching.cu:1191
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_match(misift_ctx *ctx, void *d_pts1, int n1, const void *d_pts2, int n2)
+{
+  return misift_match_rows(ctx, d_pts1, 0, n1, d_pts2, n2);
+}
+
+// ------------------------------------------------------------------- timing
+extern "C" int misift_timer_start(misift_ctx *ctx)
+{
+  ARG_CHECK(ctx != nullptr);
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_timer_stop_ms(misift_ctx *ctx, float *ms_out)
+{
+  ARG_CHECK(ctx && ms_out);
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+  return MISIFT_OK;
+}
+
+extern "C" int misift_profile_enable(misift_ctx *ctx, int on)
+{
+  ARG_CHECK(ctx != nullptr);
+  int rc = resolve_profile(ctx);
+  ctx->profile = on != 0;
+  return rc;
+}
+
+extern "C" int misift_profile_reset(misift_ctx *ctx)
+{
+  ARG_CHECK(ctx != nullptr);
+  int rc = resolve_profile(ctx);
+  ctx->nprof = 0;
+  return rc;
+}
+
+extern "C" int misift_profile_read(misift_ctx *ctx, int cap, char (*names)[32], float *total_ms, int *calls, int *n_out)
+{
+  ARG_CHECK(ctx && names && total_ms && calls && n_out);
+  int rc = resolve_profile(ctx);
+  if (rc) return rc;
+  int n = ctx->nprof < cap ? ctx->nprof : cap;
+  for (int i = 0; i < n; i++) {
+    memcpy(names[i], ctx->prof[i].name, 32);
+    total_ms[i] = ctx->prof[i].total_ms;
+    calls[i] = ctx->prof[i].calls;
+  }
+  *n_out = n;
+  return MISIFT_OK;
+}

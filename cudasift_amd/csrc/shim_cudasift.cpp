@@ -1,0 +1,285 @@
+// shim_cudasift.cpp — the C++ drop-in layer: cudaSift.h / cudaImage.h on top of the C-ABI.
+//
+// Plain C++ (built by g++, no HIP headers): every function below is a thin adapter from
+// the reference's C++-linkage API (cudaSift.h:35-43, cudaImage.h:8-32) to the extern "C"
+// entry points of include/misift.h, so the reference's own mainSift.cpp / geomFuncs.cpp
+// link against libcudasift.so + libmisift.so unchanged.
+//
+// Behaviour kept from the reference: one process-global device context chosen by
+// InitCuda (cudaSiftH.cu:19-37); runtime failures print to stderr and exit(-1)
+// (cudautils.h:15-39); ExtractSift prints "SIFT extraction time" and "Incl prefiltering
+// & memcpy" (cudaSiftH.cu:117, :143) and MatchSiftData prints "MatchSiftData time"
+// (matching.cu:1203) unless MISIFT_QUIET=1.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "cudaImage.h"
+#include "cudaSift.h"
+#include "misift.h"
+
+static misift_ctx *g_ctx = nullptr;
+
+static void die(const char *what)
+{
+  fprintf(stderr, "misift error in %s: %s\n", what, misift_last_error());
+  exit(-1);
+}
+#define SAFE(call)                       \
+  do {                                   \
+    if ((call) != MISIFT_OK) die(#call); \
+  } while (0)
+
+static misift_ctx *ctx()
+{
+  if (!g_ctx) SAFE(misift_ctx_create(0, nullptr, &g_ctx));
+  return g_ctx;
+}
+
+static bool quiet()
+{
+  misift_options o;
+  misift_get_options(ctx(), &o);
+  return o.quiet != 0;
+}
+
+// ------------------------------------------------------------- cudaImage.h
+int iDivUp(int a, int b) { return (a % b != 0) ? (a / b + 1) : (a / b); }
+int iDivDown(int a, int b) { return a / b; }
+int iAlignUp(int a, int b) { return (a % b != 0) ? (a - a % b + b) : a; }
+int iAlignDown(int a, int b) { return a - a % b; }
+
+static std::chrono::steady_clock::time_point g_timers[16];
+void StartTimer(unsigned int *hTimer)
+{
+  static unsigned next = 0;
+  *hTimer = next++ % 16;
+  g_timers[*hTimer] = std::chrono::steady_clock::now();
+}
+double StopTimer(unsigned int hTimer)
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_timers[hTimer % 16]).count();
+}
+
+CudaImage::CudaImage()
+    : width(0), height(0), pitch(0), h_data(NULL), d_data(NULL), t_data(NULL), d_internalAlloc(false),
+      h_internalAlloc(false)
+{
+}
+
+CudaImage::~CudaImage()
+{
+  if (d_internalAlloc && d_data != NULL) misift_free(d_data);
+  d_data = NULL;
+  if (h_internalAlloc && h_data != NULL) free(h_data);
+  h_data = NULL;
+  if (t_data != NULL) misift_free(t_data);
+  t_data = NULL;
+}
+
+void CudaImage::Allocate(int w, int h, int p, bool host, float *devmem, float *hostmem)
+{
+  width = w;
+  height = h;
+  pitch = p;
+  d_data = devmem;
+  h_data = hostmem;
+  t_data = NULL;
+  d_internalAlloc = false;
+  h_internalAlloc = false;
+  if (devmem == NULL) {
+    ctx();
+    SAFE(misift_image_alloc(width, height, &d_data, &pitch));   // pitch overwritten, in floats (cudaImage.cu:24-25)
+    if (d_data == NULL) printf("Failed to allocate device data\n");
+    d_internalAlloc = true;
+  }
+  if (host && hostmem == NULL) {
+    h_data = (float *)malloc(sizeof(float) * pitch * height);
+    h_internalAlloc = true;
+  }
+}
+
+double CudaImage::Download()
+{
+  auto t0 = std::chrono::steady_clock::now();
+  if (d_data != NULL && h_data != NULL) SAFE(misift_upload_2d(ctx(), d_data, pitch, h_data, width, width, height));
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+double CudaImage::Readback()
+{
+  auto t0 = std::chrono::steady_clock::now();
+  SAFE(misift_download_2d(ctx(), h_data, width, d_data, pitch, width, height));
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Legacy cudaArray path (cudaImage.cu:80-115): no pipeline user; kept working as a plain
+// device buffer of pitch x height floats.
+double CudaImage::InitTexture()
+{
+  void *p = nullptr;
+  SAFE(misift_malloc(sizeof(float) * (size_t)pitch * height, &p));
+  t_data = (float *)p;
+  if (t_data == NULL) printf("Failed to allocated texture data\n");
+  return 0.0;
+}
+
+double CudaImage::CopyToTexture(CudaImage &dst, bool host)
+{
+  if (dst.t_data == NULL) {
+    printf("Error CopyToTexture: No texture data\n");
+    return 0.0;
+  }
+  if ((!host || h_data == NULL) && (host || d_data == NULL)) {
+    printf("Error CopyToTexture: No source data\n");
+    return 0.0;
+  }
+  const size_t bytes = sizeof(float) * (size_t)pitch * dst.height;
+  if (host) {
+    SAFE(misift_copy_h2d(ctx(), dst.t_data, h_data, bytes));
+  } else {
+    float *tmp = (float *)malloc(bytes);
+    SAFE(misift_copy_d2h(ctx(), tmp, d_data, bytes));
+    SAFE(misift_copy_h2d(ctx(), dst.t_data, tmp, bytes));
+    free(tmp);
+  }
+  return 0.0;
+}
+
+// -------------------------------------------------------------- cudaSift.h
+void InitCuda(int devNum)
+{
+  int nDevices = misift_device_count();
+  if (!nDevices) {
+    std::cerr << "No HIP devices available" << std::endl;
+    return;
+  }
+  devNum = std::min(nDevices - 1, devNum);
+  if (g_ctx) {
+    misift_ctx_destroy(g_ctx);
+    g_ctx = nullptr;
+  }
+  SAFE(misift_ctx_create(devNum, nullptr, &g_ctx));
+  char name[256];
+  int memClockKHz = 0, busWidth = 0, cus = 0, lds = 0;
+  size_t mem = 0;
+  SAFE(misift_device_info(devNum, name, sizeof(name), &memClockKHz, &busWidth, &mem, &cus, &lds));
+  printf("Device Number: %d\n", devNum);
+  printf("  Device name: %s\n", name);
+  printf("  Memory Clock Rate (MHz): %d\n", memClockKHz / 1000);
+  printf("  Memory Bus Width (bits): %d\n", busWidth);
+  printf("  Peak Memory Bandwidth (GB/s): %.1f\n\n", 2.0 * memClockKHz * (busWidth / 8) / 1.0e6);
+}
+
+float *AllocSiftTempMemory(int width, int height, int numOctaves, bool scaleUp)
+{
+  ctx();
+  void *p = nullptr;
+  SAFE(misift_malloc(sizeof(float) * misift_scratch_floats(width, height, numOctaves, scaleUp ? 1 : 0), &p));
+  return (float *)p;
+}
+
+void FreeSiftTempMemory(float *memoryTmp)
+{
+  if (memoryTmp) SAFE(misift_free(memoryTmp));
+}
+
+void ExtractSift(SiftData &siftData, CudaImage &img, int numOctaves, double initBlur, float thresh, float lowestScale,
+                 bool scaleUp, float *tempMemory)
+{
+  auto t0 = std::chrono::steady_clock::now();
+  int numPts = 0;
+  SAFE(misift_extract(ctx(), img.d_data, img.width, img.height, img.pitch, numOctaves, (float)initBlur, thresh,
+                      lowestScale, scaleUp ? 1 : 0, tempMemory, siftData.d_data, siftData.maxPts, &numPts));
+  siftData.numPts = numPts;
+  const double t1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  const bool q = quiet();
+  if (!q) printf("SIFT extraction time =        %.2f ms %d\n", t1, siftData.numPts);
+  if (siftData.h_data && siftData.numPts > 0)
+    SAFE(misift_copy_d2h(ctx(), siftData.h_data, siftData.d_data, sizeof(SiftPoint) * (size_t)siftData.numPts));
+  const double t2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!q) printf("Incl prefiltering & memcpy =  %.2f ms %d\n\n", t2, siftData.numPts);
+}
+
+void InitSiftData(SiftData &data, int num, bool host, bool dev)
+{
+  data.numPts = 0;
+  data.maxPts = num;
+  const size_t sz = sizeof(SiftPoint) * (size_t)num;        // size_t: no int overflow (Appendix B #17)
+  data.h_data = NULL;
+  if (host) data.h_data = (SiftPoint *)malloc(sz);
+  data.d_data = NULL;
+  if (dev) {
+    ctx();
+    void *p = nullptr;
+    SAFE(misift_malloc(sz, &p));
+    data.d_data = (SiftPoint *)p;
+  }
+}
+
+void FreeSiftData(SiftData &data)
+{
+  if (data.d_data != NULL) SAFE(misift_free(data.d_data));
+  data.d_data = NULL;
+  if (data.h_data != NULL) free(data.h_data);
+  data.h_data = NULL;
+  data.numPts = 0;
+  data.maxPts = 0;
+}
+
+void PrintSiftData(SiftData &data)
+{
+  SiftPoint *h_data = data.h_data;
+  if (data.h_data == NULL) {
+    h_data = (SiftPoint *)malloc(sizeof(SiftPoint) * (size_t)data.maxPts);
+    if (data.numPts > 0) SAFE(misift_copy_d2h(ctx(), h_data, data.d_data, sizeof(SiftPoint) * (size_t)data.numPts));
+    data.h_data = h_data;
+  }
+  for (int i = 0; i < data.numPts; i++) {
+    printf("xpos         = %.2f\n", h_data[i].xpos);
+    printf("ypos         = %.2f\n", h_data[i].ypos);
+    printf("scale        = %.2f\n", h_data[i].scale);
+    printf("sharpness    = %.2f\n", h_data[i].sharpness);
+    printf("edgeness     = %.2f\n", h_data[i].edgeness);
+    printf("orientation  = %.2f\n", h_data[i].orientation);
+    printf("score        = %.2f\n", h_data[i].score);
+    const float *desc = h_data[i].data;
+    for (int j = 0; j < 8; j++) {
+      printf(j == 0 ? "data = " : "       ");
+      for (int k = 0; k < 16; k++) {
+        if (desc[j + 8 * k] < 0.05)
+          printf(" .   ");
+        else
+          printf("%.2f ", desc[j + 8 * k]);
+      }
+      printf("\n");
+    }
+  }
+  printf("Number of available points: %d\n", data.numPts);
+  printf("Number of allocated points: %d\n", data.maxPts);
+}
+
+double MatchSiftData(SiftData &data1, SiftData &data2)
+{
+  auto t0 = std::chrono::steady_clock::now();
+  if (!data1.numPts || !data2.numPts) return 0.0;
+  if (data1.d_data == NULL || data2.d_data == NULL) return 0.0;
+  SAFE(misift_match(ctx(), data1.d_data, data1.numPts, data2.d_data, data2.numPts));
+  if (data1.h_data != NULL)      // score, ambiguity, match, match_xpos, match_ypos (matching.cu:1195-1199)
+    SAFE(misift_download_fields(ctx(), data1.h_data, data1.d_data, data1.numPts, offsetof(SiftPoint, score), 5));
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!quiet()) printf("MatchSiftData time =          %.2f ms\n", ms);
+  return ms;
+}
+
+double FindHomography(SiftData &data, float *homography, int *numMatches, int numLoops, float minScore,
+                      float maxAmbiguity, float thresh)
+{
+  auto t0 = std::chrono::steady_clock::now();
+  SAFE(misift_find_homography(ctx(), data.d_data, data.numPts, homography, numMatches, numLoops, minScore,
+                              maxAmbiguity, thresh));
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}

@@ -1,0 +1,219 @@
+/* misift.h — the thin C-ABI between host code (C++ shim, ctypes, cgo, JNI …)
+ * and the gfx950 HIP kernels of libmisift.so.
+ *
+ * Plain pointers and sizes only: no C++ types, no torch types, no HIP types
+ * (a hipStream_t crosses as void*).  Every function returns 0 on success or a
+ * negative MISIFT_E* code; misift_last_error() gives the message for the
+ * calling thread.  Device pointers are ordinary HBM pointers (hipMalloc,
+ * torch tensors' data_ptr(), …).
+ *
+ * Each entry point names the reference interface it replaces (file:line in
+ * Celebrandil/CudaSift).  The C++ drop-in layer (include/cudaSift.h,
+ * include/cudaImage.h, cudasift_amd/csrc/shim_cudasift.cpp) is written
+ * purely on top of this file.
+ */
+#ifndef MISIFT_H
+#define MISIFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISIFT_OK          0
+#define MISIFT_EINVAL     -1   /* bad argument                                  */
+#define MISIFT_EHIP       -2   /* HIP runtime / kernel launch failure           */
+#define MISIFT_ENOMEM     -3   /* allocation failure                            */
+#define MISIFT_ENODEV     -4   /* no gfx950 device visible                      */
+
+#define MISIFT_NUM_SCALES      5   /* DoG scales searched per octave (cudaSiftD.h:8) */
+#define MISIFT_MAX_OCTAVES     7   /* counter protocol has 17 slots = 2*8+1          */
+#define MISIFT_POINT_BYTES   576   /* sizeof(SiftPoint) (cudaSift.h:6-22)            */
+
+/* Same 576-byte record as SiftPoint in include/cudaSift.h (reference
+ * cudaSift.h:6-22); declared here so C callers need no C++ header. */
+typedef struct misift_point {
+  float xpos, ypos, scale, sharpness, edgeness, orientation, score, ambiguity;
+  int32_t match;
+  float match_xpos, match_ypos, match_error, subsampling;
+  float empty[3];
+  float data[128];
+} misift_point;
+
+typedef struct misift_ctx misift_ctx;   /* opaque: one per device (+stream)  */
+
+/* Behaviour switches.  Defaults reproduce the reference. */
+typedef struct misift_options {
+  int texfrac_bits;      /* 8 = emulate CUDA's 9-bit texture filter weights
+                            (cudaSiftH.cu:196-205); 23 = full fp32 bilinear   */
+  int fix_numpts;        /* 0 = numPts excludes finest-octave duplicates
+                            (cudaSiftH.cu:115); 1 = include them              */
+  int match_full;        /* 0 = ignore the last n2%32 columns
+                            (matching.cu:325); 1 = use every column           */
+  int match_exact_top2;  /* 0 = 8-class lossy runner-up merge
+                            (matching.cu:378-390); 1 = true second best       */
+  int quiet;             /* 1 = C++ shim prints nothing per call              */
+  int fused;             /* 1 = fused DoG+extrema kernel (no DoG planes in
+                            HBM); 0 = separate laplace / findpoints kernels   */
+} misift_options;
+
+/* ------------------------------------------------------------------ runtime */
+
+/* cudaSiftH.cu:19-37 (InitCuda): device count / properties. */
+int misift_device_count(void);
+int misift_device_info(int device, char *name, int name_len, int *mem_clock_khz,
+                       int *bus_width_bits, size_t *total_mem_bytes,
+                       int *num_cus, int *lds_bytes_per_block);
+
+/* One context per device; `stream` is a hipStream_t (NULL = the null stream).
+ * The context owns the per-frame point counters (cudaSiftD.cu:13-14), a
+ * pinned read-back buffer and the filter tap tables (cudaSiftD.cu:15-17). */
+int misift_ctx_create(int device, void *stream, misift_ctx **out);
+void misift_ctx_destroy(misift_ctx *ctx);
+int misift_ctx_set_stream(misift_ctx *ctx, void *stream);
+int misift_ctx_sync(misift_ctx *ctx);
+const char *misift_last_error(void);
+
+void misift_default_options(misift_options *opt);
+int misift_set_options(misift_ctx *ctx, const misift_options *opt);
+int misift_get_options(misift_ctx *ctx, misift_options *opt);
+
+/* ------------------------------------------------------------------- memory */
+
+/* cudaMalloc / cudaFree / cudaMemcpy as used by cudaSiftH.cu:234-264 and
+ * cudaImage.cu:15-78. */
+int misift_malloc(size_t bytes, void **out);
+int misift_free(void *ptr);
+int misift_memset(misift_ctx *ctx, void *ptr, int value, size_t bytes);
+int misift_copy_h2d(misift_ctx *ctx, void *dst, const void *src, size_t bytes);
+int misift_copy_d2h(misift_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* cudaMallocPitch: rows padded to a multiple of 128 floats (cudaImage.cu:24). */
+int misift_image_alloc(int width, int height, float **d_out, int *pitch_floats);
+/* cudaMemcpy2D, all strides in floats (cudaImage.cu:55-78). */
+int misift_upload_2d(misift_ctx *ctx, float *d_dst, int dpitch, const float *h_src,
+                     int hpitch, int width, int height);
+int misift_download_2d(misift_ctx *ctx, float *h_dst, int hpitch, const float *d_src,
+                       int dpitch, int width, int height);
+/* Strided gather of `nfields` consecutive 32-bit fields starting at byte
+ * `offset` of every 576-byte record (matching.cu:1195-1199). */
+int misift_download_fields(misift_ctx *ctx, void *h_pts, const void *d_pts, int npts,
+                           int offset, int nfields);
+
+/* Scratch arena: cudaSiftH.cu:39-64 (AllocSiftTempMemory). Size in floats. */
+size_t misift_scratch_floats(int width, int height, int num_octaves, int scale_up);
+
+/* --------------------------------------------------------------- extraction */
+
+/* cudaSiftH.cu:72-144 (ExtractSift) for one device-resident frame.
+ * d_img: width x height floats, row stride `pitch` floats.
+ * d_scratch: misift_scratch_floats() floats, or NULL to allocate per call.
+ * d_pts: max_pts records.  *num_pts_out follows the reference's rule
+ * numPts = min(counter[2*num_octaves], max_pts) (cudaSiftH.cu:115-116).
+ * One host<->device sync (the count read-back), like the reference. */
+int misift_extract(misift_ctx *ctx, const float *d_img, int width, int height, int pitch,
+                   int num_octaves, float init_blur, float thresh, float lowest_scale,
+                   int scale_up, float *d_scratch, void *d_pts, int max_pts,
+                   int *num_pts_out);
+
+/* Same pipeline over a batch of independent frames in one launch sequence
+ * (BASELINE config 4: frames shard across GPUs, one batch per device).
+ * d_imgs: nframes images, frame stride `frame_stride` floats.
+ * d_scratch: nframes * misift_scratch_floats() floats (or NULL).
+ * d_pts: nframes * max_pts records, frame f at d_pts + f*max_pts.
+ * num_pts_out: host array of nframes ints. */
+int misift_extract_batch(misift_ctx *ctx, const float *d_imgs, int nframes,
+                         size_t frame_stride, int width, int height, int pitch,
+                         int num_octaves, float init_blur, float thresh,
+                         float lowest_scale, float *d_scratch, void *d_pts,
+                         int max_pts, int *num_pts_out);
+/* As above but does not synchronise: counts stay on the device
+ * (d_counts_out: nframes ints, may be NULL) so a caller can queue batches. */
+int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, int nframes,
+                               size_t frame_stride, int width, int height, int pitch,
+                               int num_octaves, float init_blur, float thresh,
+                               float lowest_scale, float *d_scratch, void *d_pts,
+                               int max_pts, int *d_counts_out);
+
+/* Per-frame point counters of the last extraction, 17 per frame, in the
+ * reference's layout (cudaSiftD.cu:14, protocol cudaSiftD.cu:1297-1300). */
+int misift_get_counters(misift_ctx *ctx, int frame, unsigned int *counters17);
+int misift_set_counters(misift_ctx *ctx, int frame, const unsigned int *counters17);
+
+/* ------------------------------------------------- stage-level entry points
+ * The individual launch wrappers of cudaSiftH.cu:308-514, exposed so each
+ * kernel can be checked against the oracle in isolation. */
+
+/* LowPass (cudaSiftH.cu:406-435, LowPassBlock cudaSiftD.cu:1986-2037). */
+int misift_lowpass(misift_ctx *ctx, const float *d_src, int width, int height, int spitch,
+                   float *d_dst, int dpitch, float sigma);
+/* ScaleDown (cudaSiftH.cu:308-338, cudaSiftD.cu:84-168): dst is (w/2,h/2). */
+int misift_scaledown(misift_ctx *ctx, const float *d_src, int width, int height,
+                     int spitch, float *d_dst, int dpitch);
+/* ScaleUp (cudaSiftH.cu:340-351, cudaSiftD.cu:170-190): dst is (2w,2h). */
+int misift_scaleup(misift_ctx *ctx, const float *d_src, int width, int height, int spitch,
+                   float *d_dst, int dpitch);
+/* PrepareLaplaceKernels (cudaSiftH.cu:439-458): fills 8*12*16 floats. */
+int misift_laplace_taps(int num_octaves, float *taps_8x12x16);
+/* LaplaceMulti (cudaSiftH.cu:460-487, LaplaceMultiMem cudaSiftD.cu:1753-1793):
+ * 7 DoG planes, plane stride height*pitch.  `octave` = reference octave index
+ * (num_octaves = finest … 1 = coarsest) selecting the tap table. */
+int misift_laplace(misift_ctx *ctx, const float *d_base, int width, int height, int pitch,
+                   int num_octaves, int octave, float *d_dog);
+/* FindPointsMulti (cudaSiftH.cu:489-514, FindPointsMultiNew cudaSiftD.cu:1292-1431).
+ * Appends to d_pts using the context counters of frame 0 (reset them with
+ * misift_reset_counters first). */
+int misift_reset_counters(misift_ctx *ctx, int max_pts);
+int misift_findpoints(misift_ctx *ctx, const float *d_dog, int width, int height, int pitch,
+                      float thresh, float edge_limit, float lowest_scale,
+                      float subsampling, int octave, void *d_pts, int max_pts);
+/* Fused LaplaceMulti + FindPointsMulti: same result, no DoG planes in HBM. */
+int misift_dog_findpoints(misift_ctx *ctx, const float *d_base, int width, int height,
+                          int pitch, int num_octaves, int octave, float thresh,
+                          float edge_limit, float lowest_scale, float subsampling,
+                          void *d_pts, int max_pts);
+/* ComputeOrientations (cudaSiftH.cu:353-369, cudaSiftD.cu:972-1057). */
+int misift_orientations(misift_ctx *ctx, const float *d_base, int width, int height,
+                        int pitch, int octave, void *d_pts, int max_pts);
+/* ExtractSiftDescriptors (cudaSiftH.cu:371-382, cudaSiftD.cu:308-417). */
+int misift_descriptors(misift_ctx *ctx, const float *d_base, int width, int height,
+                       int pitch, float subsampling, int octave, void *d_pts, int max_pts);
+/* RescalePositions (cudaSiftH.cu:397-404, cudaSiftD.cu:753-761). */
+int misift_rescale_positions(misift_ctx *ctx, void *d_pts, int npts, float scale);
+
+/* ----------------------------------------------------------------- matching */
+
+/* MatchSiftData (matching.cu:1090-1206; CleanMatches :289, FindMaxCorr10
+ * :301-397) on device-resident records: fills score, ambiguity, match,
+ * match_xpos, match_ypos of d_pts1[0..n1).  fp32 MFMA, k-ordered so every
+ * score is bit-identical to the reference's sequential FMA chain. */
+int misift_match(misift_ctx *ctx, void *d_pts1, int n1, const void *d_pts2, int n2);
+/* Row-block form for BASELINE config 5: rows [row_begin,row_begin+row_count)
+ * of set 1 against all of set 2 (each GPU takes one row block). */
+int misift_match_rows(misift_ctx *ctx, void *d_pts1, int row_begin, int row_count,
+                      const void *d_pts2, int n2);
+
+/* FindHomography (matching.cu:1000-1087): RANSAC over stored matches. */
+int misift_find_homography(misift_ctx *ctx, const void *d_pts, int npts, float *homography9,
+                           int *num_matches, int num_loops, float min_score,
+                           float max_ambiguity, float thresh);
+
+/* ------------------------------------------------------------------- timing */
+
+/* TimerGPU (cudautils.h:61-81): event pair on the context stream. */
+int misift_timer_start(misift_ctx *ctx);
+int misift_timer_stop_ms(misift_ctx *ctx, float *ms_out);
+
+/* Per-kernel accumulated HIP-event timings of the context's launches
+ * (enabled with misift_profile_enable; used by bench.py for the roofline).
+ * names/ms/calls: arrays of `cap` entries; *n_out = entries filled. */
+int misift_profile_enable(misift_ctx *ctx, int on);
+int misift_profile_reset(misift_ctx *ctx);
+int misift_profile_read(misift_ctx *ctx, int cap, char (*names)[32], float *total_ms,
+                        int *calls, int *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISIFT_H */

@@ -1,0 +1,234 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and the cpu_baseline leg of
+bench.py (the checker, never the thing measured or shipped).  The product
+package `cudasift_amd` never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# numpy view of the 576-byte SiftPoint record (reference cudaSift.h:6-22)
+POINT_DTYPE = np.dtype([
+    ("xpos", "<f4"), ("ypos", "<f4"), ("scale", "<f4"), ("sharpness", "<f4"),
+    ("edgeness", "<f4"), ("orientation", "<f4"), ("score", "<f4"), ("ambiguity", "<f4"),
+    ("match", "<i4"), ("match_xpos", "<f4"), ("match_ypos", "<f4"), ("match_error", "<f4"),
+    ("subsampling", "<f4"), ("empty", "<f4", (3,)), ("data", "<f4", (128,)),
+])
+assert POINT_DTYPE.itemsize == 576
+
+
+class OrcStats(C.Structure):
+    _fields_ = [("tile_overflows", C.c_long), ("nan_guards", C.c_long), ("empty_hists", C.c_long),
+                ("oob_votes", C.c_long), ("capacity_drops", C.c_long)]
+
+
+_lib = None
+
+
+def build():
+    """(Re)build liboracle.so and, when /root/reference exists, oracle/_ref."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        fp = C.POINTER(C.c_float)
+        vp = C.c_void_p
+        L.orc_lowpass_taps.argtypes = [C.c_float, fp]
+        L.orc_scaledown_taps.argtypes = [C.c_float, fp]
+        L.orc_laplace_taps.argtypes = [C.c_int, fp]
+        L.orc_lowpass.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_float]
+        L.orc_scaledown.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orc_scaleup.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orc_laplace.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
+        L.orc_findpoints.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, vp, C.c_int, C.c_int]
+        L.orc_findpoints.restype = C.c_int
+        L.orc_tex2d.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.orc_tex2d.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_orientations.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
+                                       C.POINTER(C.c_uint), C.c_int, C.c_int]
+        L.orc_descriptors.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int]
+        L.orc_scratch_floats.argtypes = [C.c_int] * 4
+        L.orc_scratch_floats.restype = C.c_size_t
+        L.orc_extract.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                  C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint)]
+        L.orc_extract.restype = C.c_int
+        L.orc_dot128.argtypes = [vp, vp]
+        L.orc_dot128.restype = C.c_float
+        L.orc_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+        L.orc_match_rows.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+        L.orc_match_argmax.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+        L.orc_stats_get.argtypes = [C.POINTER(OrcStats)]
+        L.orc_sizeof_point.restype = C.c_int
+        assert L.orc_sizeof_point() == 576
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- taps
+def lowpass_taps(sigma):
+    k = np.zeros(9, np.float32)
+    lib().orc_lowpass_taps(sigma, k.ctypes.data_as(C.POINTER(C.c_float)))
+    return k
+
+
+def scaledown_taps(variance=0.5):
+    k = np.zeros(5, np.float32)
+    lib().orc_scaledown_taps(variance, k.ctypes.data_as(C.POINTER(C.c_float)))
+    return k
+
+
+def laplace_taps(num_octaves):
+    k = np.zeros(8 * 12 * 16, np.float32)
+    lib().orc_laplace_taps(num_octaves, k.ctypes.data_as(C.POINTER(C.c_float)))
+    return k
+
+
+# ---------------------------------------------------------------- stages (2-D arrays, pitch == width)
+def lowpass(img, sigma):
+    img = _f32(img)
+    h, w = img.shape
+    out = np.empty_like(img)
+    lib().orc_lowpass(_p(img), w, h, w, _p(out), w, sigma)
+    return out
+
+
+def scaledown(img):
+    img = _f32(img)
+    h, w = img.shape
+    out = np.empty((h // 2, w // 2), np.float32)
+    lib().orc_scaledown(_p(img), w, h, w, _p(out), w // 2)
+    return out
+
+
+def scaleup(img):
+    img = _f32(img)
+    h, w = img.shape
+    out = np.empty((2 * h, 2 * w), np.float32)
+    lib().orc_scaleup(_p(img), w, h, w, _p(out), 2 * w)
+    return out
+
+
+def laplace(base, num_octaves, octave):
+    """7 DoG planes [7,h,w] of one octave base image."""
+    base = _f32(base)
+    h, w = base.shape
+    taps = laplace_taps(num_octaves)
+    dog = np.empty((7, h, w), np.float32)
+    lib().orc_laplace(_p(base), w, h, w, _p(taps), octave, _p(dog))
+    return dog
+
+
+def findpoints(dog, thresh, subsampling=1.0, lowest_scale=0.0, max_pts=32768, edge_limit=10.0):
+    dog = _f32(dog)
+    _, h, w = dog.shape
+    pts = np.zeros(max_pts, POINT_DTYPE)
+    n = lib().orc_findpoints(_p(dog), w, h, w, thresh, edge_limit, 1.0 / 5, lowest_scale, subsampling,
+                             _p(pts), 0, max_pts)
+    return pts, n
+
+
+def orientations(base, pts, first, last, max_pts, fracbits=8):
+    base = _f32(base)
+    h, w = base.shape
+    dup = C.c_uint(last)
+    lib().orc_orientations(_p(base), w, h, w, _p(pts), first, last, C.byref(dup), max_pts, fracbits)
+    return int(dup.value)
+
+
+def descriptors(base, pts, first, last, subsampling=1.0, fracbits=8):
+    base = _f32(base)
+    h, w = base.shape
+    lib().orc_descriptors(_p(base), w, h, w, _p(pts), first, last, subsampling, fracbits)
+
+
+def tex2d(img, x, y, fracbits=8):
+    img = _f32(img)
+    h, w = img.shape
+    return float(lib().orc_tex2d(_p(img), w, h, w, x, y, fracbits))
+
+
+# ---------------------------------------------------------------- whole path
+def extract(img, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, scale_up=False,
+            max_pts=32768, fracbits=8, fix_numpts=False):
+    """orc_extract on a host image.  Returns (points[max_pts] structured array, numPts, counters[17])."""
+    img = _f32(img)
+    h, w = img.shape
+    pts = np.zeros(max_pts, POINT_DTYPE)
+    cnt = (C.c_uint * 17)()
+    n = lib().orc_extract(_p(img), w, h, w, num_octaves, init_blur, thresh, lowest_scale, int(scale_up),
+                          _p(pts), max_pts, fracbits, int(fix_numpts), cnt)
+    return pts, n, np.array(list(cnt), dtype=np.uint32)
+
+
+def match(pts1, n1, pts2, n2, full=False, exact=False):
+    """In-place MatchSiftData on structured arrays."""
+    flags = (1 if full else 0) | (2 if exact else 0)
+    lib().orc_match(_p(pts1), n1, _p(pts2), n2, flags)
+
+
+def match_rows(pts1, row0, nrows, pts2, n2, full=False, exact=False):
+    flags = (1 if full else 0) | (2 if exact else 0)
+    lib().orc_match_rows(_p(pts1), row0, nrows, _p(pts2), n2, flags)
+
+
+def match_argmax(a, b):
+    a = _f32(a); b = _f32(b)
+    score = np.zeros(a.shape[0], np.float32)
+    index = np.zeros(a.shape[0], np.int32)
+    lib().orc_match_argmax(_p(a), a.shape[0], _p(b), b.shape[0], _p(score), _p(index))
+    return score, index
+
+
+def stats():
+    s = OrcStats()
+    lib().orc_stats_get(C.byref(s))
+    return {k: getattr(s, k) for k, _ in OrcStats._fields_}
+
+
+def stats_reset():
+    lib().orc_stats_reset()
+
+
+# ---------------------------------------------------------------- oracle/_ref (reference's own CPU matcher)
+def ref_lib(npts):
+    path = os.path.join(HERE, "_ref", "libmatchref_%d.so" % npts)
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.ref_generate.argtypes = [vp, vp, C.c_uint]
+    L.ref_match_c1.argtypes = [vp, vp, vp, vp]
+    L.ref_match_c3.argtypes = [vp, vp, vp, vp]
+    L.ref_npts.restype = C.c_int
+    assert L.ref_npts() == npts
+    return L
+
+
+def aligned_f32(n, align=32):
+    """float32 array whose data pointer is `align`-byte aligned (MatchC3 uses _mm256_load_ps)."""
+    raw = np.zeros(n + align, np.float32)
+    off = (-raw.ctypes.data % align) // 4
+    return raw[off:off + n]

@@ -1,0 +1,783 @@
+/* sift_oracle.c — CPU restatement of the CudaSift hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Nothing under oracle/ is part of the product: only tests/, the smoke check
+ * in __graft_entry__.py and the `cpu_baseline` leg of bench.py may load this
+ * library, and only as the checker / the timed CPU baseline.  The shipped path
+ * (libmisift.so) never links, loads or falls back to it.
+ *
+ * What it restates (all citations are file:line in Celebrandil/CudaSift @ v1):
+ *   taps            cudaSiftH.cu:316-323 (ScaleDown), :408-418 (LowPass), :439-458 (Laplace)
+ *   LowPass         cudaSiftD.cu:1986-2037 (LowPassBlock; plainest form :1928-1950)
+ *   ScaleDown       cudaSiftD.cu:84-168
+ *   ScaleUp         cudaSiftD.cu:170-190
+ *   LaplaceMulti    cudaSiftD.cu:1753-1793 (LaplaceMultiMem)
+ *   FindPointsMulti cudaSiftD.cu:1292-1431 (FindPointsMultiNew)
+ *   Orientations    cudaSiftD.cu:972-1057  (ComputeOrientationsCONST)
+ *   Descriptors     cudaSiftD.cu:295-417   (FastAtan2 + ExtractSiftDescriptorsCONSTNew)
+ *   ExtractSift     cudaSiftH.cu:72-232    (octave recursion, counter protocol, numPts rule)
+ *   MatchSiftData   matching.cu:289-397, :1090-1206 (CleanMatches + FindMaxCorr10)
+ *
+ * PARITY PINNING.  The reference ships no golden vectors, known-answer tests or
+ * fixtures for extraction and cannot be built here (CUDA), so
+ * the EXTRACTION part of this oracle is "parity unpinned": it is checked only
+ * against closed forms, the tap table of SURVEY Appendix C and cross
+ * implementations (tests/test_oracle_*.py).  The MATCHER part is pinned against
+ * the reference's own CPU routines MatchC1/MatchC3 (match.cu:57-130), compiled
+ * from the reference tree into oracle/_ref/ by oracle/build_ref.sh.
+ *
+ * Arithmetic conventions (shared with the HIP kernels so the DoG pyramid and
+ * every discrete decision agree bit for bit): IEEE fp32, compiled with
+ * -ffp-contract=off; the separable filters use the explicit fmaf chains written
+ * below (centre tap first, then outward — the order of the reference
+ * expressions with nvcc's default multiply-add contraction); everything else is
+ * plain, uncontracted arithmetic.  libm calls (expf, atan2f, sinf, cosf, sqrtf,
+ * powf, exp2f) differ from the device versions in the last bits; tests use the
+ * tolerances of SURVEY §7.5 for anything downstream of them.
+ *
+ * Deliberate deviations from the reference: #4 no 32
+ * candidates-per-tile cap (overflows are counted in orc_stats), #7 FastAtan2(0,0)
+ * -> 0 instead of NaN, #8 empty orientation histogram -> orientation 0,
+ * #9/#10 selectable, #11 never writes past n1, #13 ScaleDown guarded, descriptor
+ * votes landing at index >= 128 (angi==8 in the last cell) are dropped.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NUM_SCALES 5
+#define LAPLACE_S  (NUM_SCALES + 3)
+
+typedef struct {
+  float xpos, ypos, scale, sharpness, edgeness, orientation, score, ambiguity;
+  int32_t match;
+  float match_xpos, match_ypos, match_error, subsampling;
+  float empty[3];
+  float data[128];
+} SiftPoint;
+
+typedef struct {
+  long tile_overflows;   /* 30x8xscale tiles that held > 32 candidates (App. B #4) */
+  long nan_guards;       /* descriptor samples with dx==dy==0 (App. B #7)          */
+  long empty_hists;      /* orientation histograms without a peak (App. B #8)      */
+  long oob_votes;        /* descriptor votes dropped at index >= 128                */
+  long capacity_drops;   /* points dropped because maxPts was reached               */
+} orc_stats_t;
+
+static orc_stats_t g_stats;
+void orc_stats_reset(void) { memset(&g_stats, 0, sizeof(g_stats)); }
+void orc_stats_get(orc_stats_t *out) { *out = g_stats; }
+int orc_sizeof_point(void) { return (int)sizeof(SiftPoint); }
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ------------------------------------------------------------------ taps */
+
+/* cudaSiftH.cu:408-418.  k[4] is the centre tap. */
+void orc_lowpass_taps(float scale, float k[9])
+{
+  float kernelSum = 0.0f;
+  float ivar2 = 1.0f / (2.0f * scale * scale);
+  for (int j = -4; j <= 4; j++) {
+    k[j + 4] = (float)expf((float)(-(double)j * j * ivar2));
+    kernelSum += k[j + 4];
+  }
+  for (int j = -4; j <= 4; j++) k[j + 4] /= kernelSum;
+}
+
+/* cudaSiftH.cu:316-323.  k[2] is the centre tap. */
+void orc_scaledown_taps(float variance, float k[5])
+{
+  float kernelSum = 0.0f;
+  for (int j = 0; j < 5; j++) {
+    k[j] = (float)expf((float)(-(double)(j - 2) * (j - 2) / 2.0 / variance));
+    kernelSum += k[j];
+  }
+  for (int j = 0; j < 5; j++) k[j] /= kernelSum;
+}
+
+/* cudaSiftH.cu:439-458, recursive; table index [octave*12*16 + 16*scale + j],
+ * j=0 is the centre tap.  `kernel` must hold 8*12*16 floats. */
+void orc_laplace_taps_rec(int numOctaves, float initBlur, float *kernel)
+{
+  if (numOctaves > 1) {
+    float totInitBlur = sqrtf(initBlur * initBlur + 0.5f * 0.5f) / 2.0f;
+    orc_laplace_taps_rec(numOctaves - 1, totInitBlur, kernel);
+  }
+  float scale = powf(2.0f, -1.0f / NUM_SCALES);
+  float diffScale = powf(2.0f, 1.0f / NUM_SCALES);
+  for (int i = 0; i < NUM_SCALES + 3; i++) {
+    float kernelSum = 0.0f;
+    float var = scale * scale - initBlur * initBlur;
+    for (int j = 0; j <= 4; j++) {
+      kernel[numOctaves * 12 * 16 + 16 * i + j] = (float)expf((float)(-(double)j * j / 2.0 / var));
+      kernelSum += (j == 0 ? 1 : 2) * kernel[numOctaves * 12 * 16 + 16 * i + j];
+    }
+    for (int j = 0; j <= 4; j++) kernel[numOctaves * 12 * 16 + 16 * i + j] /= kernelSum;
+    scale *= diffScale;
+  }
+}
+
+void orc_laplace_taps(int numOctaves, float *kernel)
+{
+  memset(kernel, 0, sizeof(float) * 8 * 12 * 16);
+  orc_laplace_taps_rec(numOctaves, 0.0f, kernel);   /* cudaSiftH.cu:110 */
+}
+
+/* ---------------------------------------------------- separable filtering */
+
+/* Symmetric 9-tap dot product, kc[0] = centre tap, p_j = (value at -j) + (value at +j).
+ * This exact fmaf chain is the shared arithmetic contract with the HIP kernels. */
+static inline float conv9(const float kc[5], float c, float p1, float p2, float p3, float p4)
+{
+  float s = kc[0] * c;
+  s = fmaf(kc[1], p1, s);
+  s = fmaf(kc[2], p2, s);
+  s = fmaf(kc[3], p3, s);
+  s = fmaf(kc[4], p4, s);
+  return s;
+}
+
+/* LowPass: horizontal pass first, then vertical; clamp-to-edge.
+ * cudaSiftD.cu:1999-2005 (horizontal), :2022-2026 (vertical). */
+void orc_lowpass(const float *src, int w, int h, int spitch, float *dst, int dpitch, float sigma)
+{
+  float k9[9], kc[5];
+  orc_lowpass_taps(sigma, k9);
+  for (int j = 0; j <= 4; j++) kc[j] = k9[4 - j];   /* kc[0]=k[4] centre … kc[4]=k[0] */
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)w * h);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++) {
+    const float *r = src + (size_t)y * spitch;
+    for (int x = 0; x < w; x++) {
+#define R(d) r[clampi(x + (d), 0, w - 1)]
+      tmp[(size_t)y * w + x] = conv9(kc, R(0), R(1) + R(-1), R(2) + R(-2), R(3) + R(-3), R(4) + R(-4));
+#undef R
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+#define T(d) tmp[(size_t)clampi(y + (d), 0, h - 1) * w + x]
+      dst[(size_t)y * dpitch + x] = conv9(kc, T(0), T(-1) + T(1), T(-2) + T(2), T(-3) + T(3), T(-4) + T(4));
+#undef T
+    }
+  }
+  free(tmp);
+}
+
+/* ScaleDown: 5-tap Gaussian (variance 0.5) + 2x decimation, horizontal then vertical.
+ * cudaSiftD.cu:123 (row filter) and :125 (column filter).  dst is (w/2, h/2). */
+void orc_scaledown(const float *src, int w, int h, int spitch, float *dst, int dpitch)
+{
+  float k[5];
+  orc_scaledown_taps(0.5f, k);
+  const float k0 = k[0], k1 = k[1], k2 = k[2];
+  int w2 = w / 2, h2 = h / 2;
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)(w2 > 0 ? w2 : 1) * h);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++) {
+    const float *r = src + (size_t)y * spitch;
+    for (int x = 0; x < w2; x++) {
+#define R(m) r[clampi(2 * x + (m) - 2, 0, w - 1)]
+      float s = k0 * (R(0) + R(4));
+      s = fmaf(k1, R(1) + R(3), s);
+      s = fmaf(k2, R(2), s);
+      tmp[(size_t)y * w2 + x] = s;
+#undef R
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h2; y++) {
+    for (int x = 0; x < w2; x++) {
+#define T(m) tmp[(size_t)clampi(2 * y + (m) - 2, 0, h - 1) * w2 + x]
+      float s = k2 * T(2);
+      s = fmaf(k0, T(0) + T(4), s);
+      s = fmaf(k1, T(1) + T(3), s);
+      dst[(size_t)y * dpitch + x] = s;
+#undef T
+    }
+  }
+  free(tmp);
+}
+
+/* ScaleUp: cudaSiftD.cu:170-190.  dst is (2w, 2h). */
+void orc_scaleup(const float *src, int w, int h, int spitch, float *dst, int dpitch)
+{
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int xr = x + 1 < w ? x + 1 : w - 1, yd = y + 1 < h ? y + 1 : h - 1;
+      float vul = src[(size_t)y * spitch + x], vur = src[(size_t)y * spitch + xr];
+      float vdl = src[(size_t)yd * spitch + x], vdr = src[(size_t)yd * spitch + xr];
+      dst[(size_t)(2 * y) * dpitch + 2 * x] = vul;
+      dst[(size_t)(2 * y) * dpitch + 2 * x + 1] = 0.50f * (vul + vur);
+      dst[(size_t)(2 * y + 1) * dpitch + 2 * x] = 0.50f * (vul + vdl);
+      dst[(size_t)(2 * y + 1) * dpitch + 2 * x + 1] = 0.25f * (vul + vur + vdl + vdr);
+    }
+}
+
+/* LaplaceMulti: 8 blurs of the same base (vertical pass first, then horizontal),
+ * 7 differences.  cudaSiftD.cu:1762-1774 (vertical), :1777-1791 (horizontal + DoG).
+ * taps: the 8*12*16 table; octave: reference octave index.  dog: 7 planes, plane
+ * stride h*pitch, row stride pitch. */
+void orc_laplace(const float *base, int w, int h, int pitch, const float *taps, int octave, float *dog)
+{
+  const float *kt = taps + octave * 12 * 16;
+  float *vbuf = (float *)malloc(sizeof(float) * (size_t)LAPLACE_S * w * h);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+#define B(d) base[(size_t)clampi(y + (d), 0, h - 1) * pitch + x]
+      float c = B(0), p1 = B(-1) + B(1), p2 = B(-2) + B(2), p3 = B(-3) + B(3), p4 = B(-4) + B(4);
+#undef B
+      for (int s = 0; s < LAPLACE_S; s++)
+        vbuf[((size_t)s * h + y) * w + x] = conv9(kt + 16 * s, c, p1, p2, p3, p4);
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+      float old = 0.0f;
+      for (int s = 0; s < LAPLACE_S; s++) {
+        const float *v = vbuf + ((size_t)s * h + y) * w;
+#define V(d) v[clampi(x + (d), 0, w - 1)]
+        float res = conv9(kt + 16 * s, V(0), V(-1) + V(1), V(-2) + V(2), V(-3) + V(3), V(-4) + V(4));
+#undef V
+        if (s > 0) dog[((size_t)(s - 1) * h + y) * pitch + x] = res - old;
+        old = res;
+      }
+    }
+  }
+  free(vbuf);
+}
+
+/* ------------------------------------------------------------ FindPoints */
+
+/* FindPointsMultiNew, cudaSiftD.cu:1292-1431.  Appends records starting at
+ * index *count (counter protocol handled by the caller); returns the number of
+ * detections (before the capacity clamp).  Scan order: scale, row, column. */
+int orc_findpoints(const float *dog, int w, int h, int pitch, float thresh, float edgeLimit,
+                   float factor, float lowestScale, float subsampling, SiftPoint *pts,
+                   int start, int maxPts)
+{
+  const size_t size = (size_t)pitch * h;
+  int n = 0;
+  /* overflow statistics for the reference's 30x8 tiles (Appendix B #4) */
+  int tilesx = (w + 29) / 30, tilesy = (h + 7) / 8;
+  int *tilecnt = (int *)calloc((size_t)tilesx * tilesy * NUM_SCALES, sizeof(int));
+  for (int s = 0; s < NUM_SCALES; s++) {
+    const float *d0 = dog + size * s, *d1 = dog + size * (s + 1), *d2 = dog + size * (s + 2);
+    for (int y = 0; y < h; y++) {
+      int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
+      for (int x = 0; x < w; x++) {
+        float v = d1[(size_t)y * pitch + x];
+        if (!(fabsf(v) > thresh)) continue;
+        int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
+        const int xs[3] = {xm, x, xp}, ys[3] = {ym, y, yp};
+        const float *pl[3] = {d0, d1, d2};
+        float minv = INFINITY, maxv = -INFINITY;
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++)
+            for (int c = 0; c < 3; c++) {
+              if (a == 1 && b == 1 && c == 1) continue;    /* the 26 neighbours, clamped coords */
+              float t = pl[a][(size_t)ys[b] * pitch + xs[c]];
+              minv = fminf(minv, t);
+              maxv = fmaxf(maxv, t);
+            }
+        if (!((v < fminf(-thresh, minv)) || (v > fmaxf(thresh, maxv)))) continue;
+        tilecnt[((size_t)s * tilesy + y / 8) * tilesx + x / 30]++;
+        /* refinement, cudaSiftD.cu:1383-1417: unclamped neighbour reads (x,y interior here) */
+        const float *data1 = d1 + (size_t)y * pitch + x;
+        float val = data1[0];
+        float dxx = 2.0f * val - data1[-1] - data1[1];
+        float dyy = 2.0f * val - data1[-pitch] - data1[pitch];
+        float dxy = 0.25f * (data1[+pitch + 1] + data1[-pitch - 1] - data1[-pitch + 1] - data1[+pitch - 1]);
+        float tra = dxx + dyy;
+        float det = dxx * dyy - dxy * dxy;
+        if (!(tra * tra < edgeLimit * det)) continue;
+        float edge = (tra * tra) / det;
+        float dx = 0.5f * (data1[1] - data1[-1]);
+        float dy = 0.5f * (data1[pitch] - data1[-pitch]);
+        const float *data0 = d0 + (size_t)y * pitch + x;
+        const float *data2 = d2 + (size_t)y * pitch + x;
+        float ds = 0.5f * (data0[0] - data2[0]);
+        float dss = 2.0f * val - data2[0] - data0[0];
+        float dxs = 0.25f * (data2[1] + data0[-1] - data0[1] - data2[-1]);
+        float dys = 0.25f * (data2[pitch] + data0[-pitch] - data2[-pitch] - data0[pitch]);
+        float idxx = dyy * dss - dys * dys;
+        float idxy = dys * dxs - dxy * dss;
+        float idxs = dxy * dys - dyy * dxs;
+        float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
+        float idyy = dxx * dss - dxs * dxs;
+        float idys = dxy * dxs - dxx * dys;
+        float idss = dxx * dyy - dxy * dxy;
+        float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
+        float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
+        float pds = idet * (idxs * dx + idys * dy + idss * ds);
+        if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
+          pdx = dx / dxx;
+          pdy = dy / dyy;
+          pds = ds / dss;
+        }
+        float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
+        float sc = powf(2.0f, (float)s / NUM_SCALES) * exp2f(pds * factor);
+        if (!(sc >= lowestScale)) continue;
+        int idx = start + n;
+        n++;
+        if (idx >= maxPts) { g_stats.capacity_drops++; continue; }
+        SiftPoint *p = &pts[idx];
+        p->xpos = x + pdx;
+        p->ypos = y + pdy;
+        p->scale = sc;
+        p->sharpness = val + dval;
+        p->edgeness = edge;
+        p->subsampling = subsampling;
+      }
+    }
+  }
+  for (size_t i = 0; i < (size_t)tilesx * tilesy * NUM_SCALES; i++)
+    if (tilecnt[i] > 32) g_stats.tile_overflows++;
+  free(tilecnt);
+  return n;
+}
+
+/* ------------------------------------------------ texture-fetch emulation */
+
+/* tex2D<float>(x, y) of a pitch2D texture: unnormalised coordinates, clamp
+ * addressing, linear filtering (cudaSiftH.cu:196-205).  fracbits==8 rounds the
+ * interpolation weights to 8 fractional bits like the CUDA texture unit;
+ * anything else keeps full fp32 weights.  Shared arithmetic contract with HIP. */
+static inline float tex2d(const float *img, int w, int h, int pitch, float x, float y, int fracbits)
+{
+  float xb = x - 0.5f, yb = y - 0.5f;
+  float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (fracbits == 8) {
+    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+  }
+  /* clamp in float first so far-away coordinates cannot overflow the int cast */
+  fx = fminf(fmaxf(fx, -2.0f), (float)w);
+  fy = fminf(fmaxf(fy, -2.0f), (float)h);
+  int ix = (int)fx, iy = (int)fy;
+  int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
+  int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+  float t00 = img[(size_t)y0 * pitch + x0], t10 = img[(size_t)y0 * pitch + x1];
+  float t01 = img[(size_t)y1 * pitch + x0], t11 = img[(size_t)y1 * pitch + x1];
+  float ia = 1.0f - a, ib = 1.0f - b;
+  float v = (ia * ib) * t00;
+  v = fmaf(a * ib, t10, v);
+  v = fmaf(ia * b, t01, v);
+  v = fmaf(a * b, t11, v);
+  return v;
+}
+
+float orc_tex2d(const float *img, int w, int h, int pitch, float x, float y, int fracbits)
+{
+  return tex2d(img, w, h, pitch, x, y, fracbits);
+}
+
+/* ----------------------------------------------------------- orientation */
+
+/* ComputeOrientationsCONST, cudaSiftD.cu:972-1057, for points [first,last).
+ * Duplicates are appended at *dupCount (incremented; dropped when >= maxPts).
+ * Returns nothing; orientation written in place. */
+void orc_orientations(const float *img, int w, int h, int pitch, SiftPoint *pts, int first,
+                      int last, unsigned int *dupCount, int maxPts, int fracbits)
+{
+  for (int bx = first; bx < last; bx++) {
+    SiftPoint *p = &pts[bx];
+    float hist[64];
+    float gauss[11];
+    float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * p->scale * p->scale);
+    for (int t = 0; t < 11; t++) gauss[t] = expf(i2sigma2 * (t - 5) * (t - 5));
+    for (int t = 0; t < 64; t++) hist[t] = 0.0f;
+    float xp = p->xpos - 4.5f;
+    float yp = p->ypos - 4.5f;
+    for (int tx = 0; tx < 121; tx++) {
+      int yd = tx / 11;
+      int xd = tx - yd * 11;
+      float xf = xp + xd;
+      float yf = yp + yd;
+      float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, fracbits) - tex2d(img, w, h, pitch, xf - 1.0f, yf, fracbits);
+      float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, fracbits) - tex2d(img, w, h, pitch, xf, yf - 1.0f, fracbits);
+      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+      if (bin > 31) bin = 0;
+      float grad = sqrtf(dx * dx + dy * dy);
+      hist[bin] += grad * gauss[xd] * gauss[yd];
+    }
+    for (int tx = 0; tx < 32; tx++) {
+      int x1m = (tx >= 1 ? tx - 1 : tx + 31), x1p = (tx <= 30 ? tx + 1 : tx - 31);
+      int x2m = (tx >= 2 ? tx - 2 : tx + 30), x2p = (tx <= 29 ? tx + 2 : tx - 30);
+      hist[tx + 32] = 6.0f * hist[tx] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
+    }
+    for (int tx = 0; tx < 32; tx++) {
+      int x1m = (tx >= 1 ? tx - 1 : tx + 31), x1p = (tx <= 30 ? tx + 1 : tx - 31);
+      float v = hist[32 + tx];
+      hist[tx] = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
+    }
+    float maxval1 = 0.0f, maxval2 = 0.0f;
+    int i1 = -1, i2 = -1;
+    for (int i = 0; i < 32; i++) {
+      float v = hist[i];
+      if (v > maxval1) {
+        maxval2 = maxval1; maxval1 = v; i2 = i1; i1 = i;
+      } else if (v > maxval2) {
+        maxval2 = v; i2 = i;
+      }
+    }
+    if (i1 < 0) {                       /* Appendix B #8 */
+      g_stats.empty_hists++;
+      p->orientation = 0.0f;
+      continue;
+    }
+    {
+      float val1 = hist[32 + ((i1 + 1) & 31)];
+      float val2 = hist[32 + ((i1 + 31) & 31)];
+      float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
+      p->orientation = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+    }
+    if (maxval2 > 0.8f * maxval1) {
+      float val1 = hist[32 + ((i2 + 1) & 31)];
+      float val2 = hist[32 + ((i2 + 31) & 31)];
+      float peak = i2 + 0.5f * (val1 - val2) / (2.0f * maxval2 - val1 - val2);
+      unsigned int idx = (*dupCount)++;
+      if (idx < (unsigned int)maxPts) {
+        SiftPoint *q = &pts[idx];
+        q->xpos = p->xpos; q->ypos = p->ypos; q->scale = p->scale;
+        q->sharpness = p->sharpness; q->edgeness = p->edgeness;
+        q->orientation = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+        q->subsampling = p->subsampling;
+      } else {
+        g_stats.capacity_drops++;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------ descriptors */
+
+/* FastAtan2, cudaSiftD.cu:295-306, with the (0,0) guard of Appendix B #7. */
+static inline float fast_atan2(float y, float x)
+{
+  float absx = fabsf(x), absy = fabsf(y);
+  float mx = fmaxf(absx, absy), mn = fminf(absx, absy);
+  if (mx == 0.0f) return 0.0f;
+  float a = mn / mx;
+  float s = a * a;
+  float r = ((-0.0464964749f * s + 0.15931422f) * s - 0.327622764f) * s * a + a;
+  r = (absy > absx ? 1.57079637f - r : r);
+  r = (x < 0 ? 3.14159274f - r : r);
+  r = (y < 0 ? -r : r);
+  return r;
+}
+float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+
+/* ExtractSiftDescriptorsCONSTNew, cudaSiftD.cu:308-417, for points [first,last). */
+void orc_descriptors(const float *img, int w, int h, int pitch, SiftPoint *pts, int first, int last,
+                     float subsampling, int fracbits)
+{
+  float gauss[16];
+  for (int t = 0; t < 16; t++) gauss[t] = expf(-(t - 7.5f) * (t - 7.5f) / 128.0f);
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int bx = first; bx < last; bx++) {
+    SiftPoint *p = &pts[bx];
+    float buffer[128];
+    long guards = 0, oob = 0;
+    for (int i = 0; i < 128; i++) buffer[i] = 0.0f;
+    float theta = 2.0f * 3.1415f / 360.0f * p->orientation;
+    float sina = sinf(theta);
+    float cosa = cosf(theta);
+    float scale = 12.0f / 16.0f * p->scale;
+    float ssina = scale * sina;
+    float scosa = scale * cosa;
+    for (int y = 0; y < 16; y++) {
+      for (int tx = 0; tx < 16; tx++) {
+        float xpos = p->xpos + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
+        float ypos = p->ypos + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+        float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, fracbits) -
+                   tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, fracbits);
+        float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, fracbits) -
+                   tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, fracbits);
+        float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+        if (dx == 0.0f && dy == 0.0f) guards++;
+        float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+
+        int hori = (tx + 2) / 4 - 1;
+        float horf = (tx - 1.5f) / 4.0f - hori;
+        float ihorf = 1.0f - horf;
+        int veri = (y + 2) / 4 - 1;
+        float verf = (y - 1.5f) / 4.0f - veri;
+        float iverf = 1.0f - verf;
+        int angi = (int)angf;
+        int angp = (angi < 7 ? angi + 1 : 0);
+        angf -= angi;
+        float iangf = 1.0f - angf;
+
+        int hist = 8 * (4 * veri + hori);
+        int p1 = angi + hist;
+        int p2 = angp + hist;
+#define VOTE(idx, val) do { int i_ = (idx); if (i_ >= 0 && i_ < 128) buffer[i_] += (val); else oob++; } while (0)
+        if (tx >= 2) {
+          float grad1 = ihorf * grad;
+          if (y >= 2) {
+            float grad2 = iverf * grad1;
+            VOTE(p1, iangf * grad2);
+            VOTE(p2, angf * grad2);
+          }
+          if (y <= 13) {
+            float grad2 = verf * grad1;
+            VOTE(p1 + 32, iangf * grad2);
+            VOTE(p2 + 32, angf * grad2);
+          }
+        }
+        if (tx <= 13) {
+          float grad1 = horf * grad;
+          if (y >= 2) {
+            float grad2 = iverf * grad1;
+            VOTE(p1 + 8, iangf * grad2);
+            VOTE(p2 + 8, angf * grad2);
+          }
+          if (y <= 13) {
+            float grad2 = verf * grad1;
+            VOTE(p1 + 40, iangf * grad2);
+            VOTE(p2 + 40, angf * grad2);
+          }
+        }
+#undef VOTE
+      }
+    }
+    /* normalise, clamp at 0.2, normalise again (cudaSiftD.cu:390-409) */
+    float sum = 0.0f;
+    for (int i = 0; i < 128; i++) sum += buffer[i] * buffer[i];
+    float rs = 1.0f / sqrtf(sum);
+    float sum2 = 0.0f;
+    for (int i = 0; i < 128; i++) {
+      buffer[i] = fminf(buffer[i] * rs, 0.2f);
+      sum2 += buffer[i] * buffer[i];
+    }
+    float rs2 = 1.0f / sqrtf(sum2);
+    for (int i = 0; i < 128; i++) p->data[i] = buffer[i] * rs2;
+    p->xpos *= subsampling;
+    p->ypos *= subsampling;
+    p->scale *= subsampling;
+    if (guards || oob) {
+#pragma omp critical
+      { g_stats.nan_guards += guards; g_stats.oob_votes += oob; }
+    }
+  }
+}
+
+/* ----------------------------------------------------------- ExtractSift */
+
+static int ialign_up(int a, int b) { return (a % b != 0) ? (a - a % b + b) : a; }
+
+/* Scratch layout and sizes of cudaSiftH.cu:39-64 / :80-95 (in floats). */
+size_t orc_scratch_floats(int width, int height, int numOctaves, int scaleUp)
+{
+  const int nd = NUM_SCALES + 3;
+  int w = width * (scaleUp ? 2 : 1), h = height * (scaleUp ? 2 : 1);
+  int p = ialign_up(w, 128);
+  size_t size = (size_t)h * p, sizeTmp = (size_t)nd * h * p;
+  for (int i = 0; i < numOctaves; i++) {
+    w /= 2; h /= 2;
+    int p2 = ialign_up(w, 128);
+    size += (size_t)h * p2;
+    sizeTmp += (size_t)nd * h * p2;
+  }
+  return size + sizeTmp;
+}
+
+typedef struct {
+  const float *taps;
+  float thresh, lowestScale;
+  int maxPts, fracbits;
+  SiftPoint *pts;
+  unsigned int cnt[17];
+} orc_job_t;
+
+/* ExtractSiftOctave, cudaSiftH.cu:169-232. */
+static void extract_octave(orc_job_t *job, const float *img, int w, int h, int pitch, int octave,
+                           float subsampling, float *memoryTmp)
+{
+  unsigned int *cnt = job->cnt;
+  orc_laplace(img, w, h, pitch, job->taps, octave, memoryTmp);
+  /* counter protocol, cudaSiftD.cu:1297-1300, :1419-1420 */
+  unsigned int start = cnt[2 * octave - 1];
+  if (cnt[2 * octave] < start) cnt[2 * octave] = start;
+  if (cnt[2 * octave + 1] < start) cnt[2 * octave + 1] = start;
+  int ndet = orc_findpoints(memoryTmp, w, h, pitch, job->thresh, 10.0f, 1.0f / NUM_SCALES,
+                            job->lowestScale / subsampling, subsampling, job->pts, (int)cnt[2 * octave],
+                            job->maxPts);
+  cnt[2 * octave] += (unsigned int)ndet;
+  /* orientation, cudaSiftD.cu:978-979, :1038-1040 */
+  int fst = (int)(start < (unsigned int)job->maxPts ? start : (unsigned int)job->maxPts);
+  int tot = (int)(cnt[2 * octave] < (unsigned int)job->maxPts ? cnt[2 * octave] : (unsigned int)job->maxPts);
+  if (cnt[2 * octave + 1] < cnt[2 * octave]) cnt[2 * octave + 1] = cnt[2 * octave];
+  orc_orientations(img, w, h, pitch, job->pts, fst, tot, &cnt[2 * octave + 1], job->maxPts, job->fracbits);
+  /* descriptors, cudaSiftD.cu:320-322 */
+  int tot2 = (int)(cnt[2 * octave + 1] < (unsigned int)job->maxPts ? cnt[2 * octave + 1] : (unsigned int)job->maxPts);
+  orc_descriptors(img, w, h, pitch, job->pts, fst, tot2, subsampling, job->fracbits);
+}
+
+/* ExtractSiftLoop, cudaSiftH.cu:146-167: coarsest octave is processed first. */
+static void extract_loop(orc_job_t *job, const float *img, int w, int h, int pitch, int numOctaves,
+                         float subsampling, float *memoryTmp, float *memorySub)
+{
+  if (numOctaves > 1) {
+    int p = ialign_up(w / 2, 128);
+    orc_scaledown(img, w, h, pitch, memorySub, p);
+    extract_loop(job, memorySub, w / 2, h / 2, p, numOctaves - 1, subsampling * 2.0f, memoryTmp,
+                 memorySub + (size_t)(h / 2) * p);
+  }
+  extract_octave(job, img, w, h, pitch, numOctaves, subsampling, memoryTmp);
+}
+
+/* ExtractSift, cudaSiftH.cu:72-144.  Host-memory image (row stride `pitch`
+ * floats).  Returns numPts = min(cnt[2*numOctaves], maxPts) — or
+ * min(cnt[2*numOctaves+1], maxPts) when fixNumPts is set (Appendix B #1).
+ * counters17 (optional) receives the 17 counters. */
+int orc_extract(const float *img, int width, int height, int pitch, int numOctaves, float initBlur,
+                float thresh, float lowestScale, int scaleUp, SiftPoint *pts, int maxPts, int fracbits,
+                int fixNumPts, unsigned int *counters17)
+{
+  float taps[8 * 12 * 16];
+  orc_laplace_taps(numOctaves, taps);
+  const int nd = NUM_SCALES + 3;
+  int w = width * (scaleUp ? 2 : 1), h = height * (scaleUp ? 2 : 1);
+  int p = ialign_up(w, 128);
+  size_t total = orc_scratch_floats(width, height, numOctaves, scaleUp);
+  size_t sizeTmp = (size_t)nd * h * p;
+  {
+    int ww = w, hh = h;
+    for (int i = 0; i < numOctaves; i++) {
+      ww /= 2; hh /= 2;
+      sizeTmp += (size_t)nd * hh * ialign_up(ww, 128);
+    }
+  }
+  float *memoryTmp = (float *)malloc(sizeof(float) * total);
+  float *memorySub = memoryTmp + sizeTmp;
+  float *lowImg = memorySub;
+  orc_job_t job;
+  memset(&job, 0, sizeof(job));
+  job.taps = taps; job.thresh = thresh; job.maxPts = maxPts; job.fracbits = fracbits; job.pts = pts;
+  float blur = initBlur > 0.001f ? initBlur : 0.001f;
+  if (!scaleUp) {
+    job.lowestScale = lowestScale;
+    orc_lowpass(img, w, h, pitch, lowImg, p, blur);
+  } else {
+    float *upImg = memoryTmp;      /* cudaSiftH.cu:119-123: the up-sampled image borrows the DoG region */
+    orc_scaleup(img, width, height, pitch, upImg, p);
+    orc_lowpass(upImg, w, h, p, lowImg, p, blur);
+    job.lowestScale = lowestScale * 2.0f;
+  }
+  extract_loop(&job, lowImg, w, h, p, numOctaves, 1.0f, memoryTmp, memorySub + (size_t)h * p);
+  unsigned int c = job.cnt[2 * numOctaves + (fixNumPts ? 1 : 0)];
+  int numPts = (int)(c < (unsigned int)maxPts ? c : (unsigned int)maxPts);
+  if (scaleUp) {                                   /* RescalePositions, cudaSiftD.cu:753-761 */
+    for (int i = 0; i < numPts; i++) {
+      pts[i].xpos *= 0.5f; pts[i].ypos *= 0.5f; pts[i].scale *= 0.5f;
+    }
+  }
+  if (counters17) memcpy(counters17, job.cnt, sizeof(job.cnt));
+  free(memoryTmp);
+  return numPts;
+}
+
+/* ---------------------------------------------------------------- matcher */
+
+/* One correlation, the sequential fp32 FMA chain of matching.cu:343-346
+ * (k = 0..127 in order, accumulator starts at 0). */
+static inline float dot128(const float *a, const float *b)
+{
+  float s = 0.0f;
+  for (int k = 0; k < 128; k++) s = fmaf(a[k], b[k], s);
+  return s;
+}
+float orc_dot128(const float *a, const float *b) { return dot128(a, b); }
+
+/* MatchSiftData: CleanMatches (matching.cu:289) + FindMaxCorr10 (:301-397).
+ * flags bit0: use all n2 columns instead of 32*floor(n2/32) (Appendix B #9);
+ * flags bit1: exact second best instead of the 8-class merge (Appendix B #10).
+ * Rows [row0, row0+nrows) of set 1 are processed (row-block form). */
+void orc_match_rows(SiftPoint *s1, int row0, int nrows, const SiftPoint *s2, int n2, int flags)
+{
+  const int full = flags & 1, exact = flags & 2;
+  const int ncols = full ? n2 : 32 * (n2 / 32);
+  /* transposed copy of set 2 so the k-ordered chains of 32 columns vectorise */
+  float *bt = (float *)malloc(sizeof(float) * 128 * (size_t)(ncols > 0 ? ncols : 1));
+  for (int j = 0; j < ncols; j++)
+    for (int k = 0; k < 128; k++) bt[(size_t)k * ncols + j] = s2[j].data[k];
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int r = row0; r < row0 + nrows; r++) {
+    const float *a = s1[r].data;
+    float cmax[8], csec[8];
+    int cidx[8];
+    for (int c = 0; c < 8; c++) { cmax[c] = 0.0f; csec[c] = 0.0f; cidx[c] = -1; }
+    float emax = 0.0f, esec = 0.0f;   /* exact top-2 */
+    int eidx = -1;
+    for (int bp2 = 0; bp2 < ncols; bp2 += 32) {
+      int nb = ncols - bp2 < 32 ? ncols - bp2 : 32;
+      float acc[32];
+      for (int j = 0; j < 32; j++) acc[j] = 0.0f;
+      for (int k = 0; k < 128; k++) {
+        const float ak = a[k];
+        const float *brow = bt + (size_t)k * ncols + bp2;
+        for (int j = 0; j < nb; j++) acc[j] = fmaf(ak, brow[j], acc[j]);
+      }
+      for (int j = 0; j < nb; j++) {                 /* ascending p2 within every class */
+        int c = j >> 2;
+        float sc = acc[j];
+        if (sc > cmax[c]) { csec[c] = cmax[c]; cmax[c] = sc; cidx[c] = bp2 + j; }
+        else if (sc > csec[c]) csec[c] = sc;
+        if (sc > emax) { esec = emax; emax = sc; eidx = bp2 + j; }
+        else if (sc > esec) esec = sc;
+      }
+    }
+    float max_score, sec_score;
+    int index;
+    if (exact) {
+      max_score = emax; sec_score = esec; index = eidx;
+    } else {                                         /* matching.cu:375-390 */
+      max_score = cmax[0]; sec_score = csec[0]; index = cidx[0];
+      for (int y = 0; y < 8; y++)
+        if (index != cidx[y]) {
+          if (cmax[y] > max_score) {
+            sec_score = fmaxf(max_score, sec_score);
+            max_score = cmax[y];
+            index = cidx[y];
+          } else if (cmax[y] > sec_score)
+            sec_score = cmax[y];
+        }
+    }
+    s1[r].score = max_score;
+    s1[r].match = index;
+    s1[r].match_xpos = index >= 0 ? s2[index].xpos : 0.0f;   /* never reads sift2[-1] */
+    s1[r].match_ypos = index >= 0 ? s2[index].ypos : 0.0f;
+    s1[r].ambiguity = sec_score / (max_score + 1e-6f);
+  }
+  free(bt);
+}
+
+void orc_match(SiftPoint *s1, int n1, const SiftPoint *s2, int n2, int flags)
+{
+  if (n1 <= 0 || n2 <= 0) return;                    /* matching.cu:1095-1096 */
+  orc_match_rows(s1, 0, n1, s2, n2, flags);
+}
+
+/* Plain argmax matcher over packed [n][128] arrays (the problem statement of
+ * match.cu:57-72, MatchC1) — used to cross-check against oracle/_ref. */
+void orc_match_argmax(const float *pts1, int n1, const float *pts2, int n2, float *score, int *index)
+{
+#pragma omp parallel for schedule(static)
+  for (int p1 = 0; p1 < n1; p1++) {
+    float best = 0.0f;
+    int bi = -1;
+    for (int p2 = 0; p2 < n2; p2++) {
+      float s = dot128(pts1 + (size_t)p1 * 128, pts2 + (size_t)p2 * 128);
+      if (s > best) { best = s; bi = p2; }
+    }
+    score[p1] = best;
+    index[p1] = bi;
+  }
+}

@@ -1,0 +1,48 @@
+"""Synthetic inputs for tests and bench: textured frames and match.cu-style descriptors."""
+import numpy as np
+
+
+SYNTH_AMP = 26.0      # tuned once so the oracle finds ~2000 keypoints per 1920x1080 frame (thresh 3.0), then frozen
+SYNTH_BANDS = 6
+
+
+def synth_frame(f, width=1920, height=1080, amp=SYNTH_AMP):
+    """Band-limited noise frame, fp32 in [0,255], fully textured (no flat patches).
+
+    frame f = clamp(128 + amp * S / std(S), 0, 255), S = sum_{j=0..5} (G_{sigma=2^j} * W_{f,j}) / std_j
+    (equal energy per octave band, like natural 1/f images), W iid N(0,1) from PCG64 seeded
+    0x51F7 + f.  The Gaussian blurs are applied in the Fourier domain (periodic boundary)."""
+    rng = np.random.Generator(np.random.PCG64(0x51F7 + int(f)))
+    fy = np.fft.fftfreq(height)[:, None]
+    fx = np.fft.rfftfreq(width)[None, :]
+    r2 = fx * fx + fy * fy
+    acc = np.zeros((height, width), np.float64)
+    for j in range(SYNTH_BANDS):
+        w = rng.standard_normal((height, width))
+        sigma = 2.0 ** j
+        g = np.exp(-2.0 * (np.pi ** 2) * (sigma ** 2) * r2)
+        b = np.fft.irfft2(np.fft.rfft2(w) * g, s=(height, width))
+        acc += b / b.std()
+    img = 128.0 + amp * acc / acc.std()
+    return np.clip(img, 0.0, 255.0).astype(np.float32)
+
+
+def synth_descriptors(n, seed=12345, l2=False):
+    """match.cu:945-957 recipe: uniform [0,1) vectors scaled by sqrt(128)/sum (or L2-normalised)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    d = rng.random((n, 128), dtype=np.float32)
+    if l2:
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+    else:
+        d *= (np.float32(np.sqrt(128.0)) / d.sum(axis=1, keepdims=True, dtype=np.float32))
+    return d.astype(np.float32)
+
+
+def descriptors_to_points(d, dtype):
+    """Embed [n,128] descriptors into SiftPoint records (AoS, 576-byte stride)."""
+    pts = np.zeros(d.shape[0], dtype)
+    pts["data"] = d
+    pts["xpos"] = np.arange(d.shape[0], dtype=np.float32) % 1920
+    pts["ypos"] = np.arange(d.shape[0], dtype=np.float32) // 1920
+    pts["match"] = -2
+    return pts

@@ -1,0 +1,360 @@
+"""GPU parity tests: every HIP kernel (through the C-ABI) against the CPU oracle.
+
+Bar (north_star): keypoints (x, y, scale, orientation) and descriptors within 1e-4 relative;
+match indices/scores identical modulo ties.  The separable filters, DoG pyramid, extremum
+decisions, refinement and the matcher's scores are held to BIT equality (explicit-FMA
+arithmetic contract); orientation/descriptor go through libm/ocml and use SURVEY §7.5 tolerances.
+"""
+import numpy as np
+import pytest
+
+from conftest import record
+from synth import descriptors_to_points, synth_descriptors, synth_frame
+from util import ATOL, RTOL, associate, compare_points
+
+pytestmark = pytest.mark.gpu
+
+
+def orc():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def rand_img(h, w, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.random((h, w), dtype=np.float32) * 255.0
+    # add structure so blurred values are not ~constant
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    return (0.5 * base + 60.0 * np.sin(xx * 0.11) * np.cos(yy * 0.07) + 64.0).astype(np.float32)
+
+
+SIZES = [(37, 1281), (70, 130), (64, 1920), (135, 240), (67, 120), (200, 250), (33, 17)]
+
+
+# ------------------------------------------------------------------ pyramid
+@pytest.mark.parametrize("h,w", SIZES)
+def test_lowpass_bitexact(ctx, h, w):
+    img = rand_img(h, w, 1)
+    for sigma in (1.0, 0.5, 1.7):
+        ref = orc().lowpass(img, sigma)
+        got = ctx.lowpass(img, sigma)
+        diff = np.abs(ref - got).max()
+        record("lowpass_%dx%d_s%.1f" % (w, h, sigma), maxabs=diff, bitexact=bool(np.array_equal(ref, got)))
+        assert diff <= ATOL
+        assert np.array_equal(ref, got), "lowpass not bit-exact, max diff %g" % diff
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_scaledown_bitexact(ctx, h, w):
+    img = rand_img(h, w, 2)
+    ref = orc().scaledown(img)
+    got = ctx.scaledown(img)
+    assert ref.shape == got.shape == (h // 2, w // 2)
+    diff = np.abs(ref - got).max() if ref.size else 0.0
+    record("scaledown_%dx%d" % (w, h), maxabs=diff, bitexact=bool(np.array_equal(ref, got)))
+    assert diff <= ATOL
+    assert np.array_equal(ref, got)
+
+
+def test_scaleup_bitexact(ctx):
+    img = rand_img(45, 77, 3)
+    assert np.array_equal(orc().scaleup(img), ctx.scaleup(img))
+
+
+def test_laplace_taps_equal():
+    from cudasift_amd import capi
+    for no in (1, 3, 5, 6):
+        assert np.array_equal(orc().laplace_taps(no), capi.laplace_taps(no))
+
+
+@pytest.mark.parametrize("h,w", SIZES[:6])
+def test_laplace_bitexact(ctx, h, w):
+    img = orc().lowpass(rand_img(h, w, 4), 1.0)
+    for octave in (5, 3):
+        ref = orc().laplace(img, 5, octave)
+        got = ctx.laplace(img, 5, octave)
+        diff = np.abs(ref - got).max()
+        record("laplace_%dx%d_o%d" % (w, h, octave), maxabs=diff, bitexact=bool(np.array_equal(ref, got)))
+        assert diff <= ATOL
+        assert np.array_equal(ref, got)
+
+
+# -------------------------------------------------------------- find points
+def _dog_of(img, octave=5):
+    base = orc().lowpass(img, 1.0)
+    return base, orc().laplace(base, 5, octave)
+
+
+def _cmp_detections(a, na, b, nb, name):
+    """Detections carry xpos, ypos, scale, sharpness, edgeness, subsampling only."""
+    A, B = a[:na].copy(), b[:nb].copy()
+    A["orientation"] = 0
+    B["orientation"] = 0
+    ia, ib, oa, ob = associate(A, B)
+    st = {"n_oracle": na, "n_hip": nb, "paired": len(ia), "paired_exact": associate.last_exact,
+          "only_oracle": len(oa), "only_hip": len(ob)}
+    if len(ia):
+        for f in ("xpos", "ypos", "scale", "sharpness", "edgeness"):
+            x, y = A[f][ia].astype(np.float64), B[f][ib].astype(np.float64)
+            st[f + "_relerr"] = float((np.abs(x - y) / np.maximum(np.abs(x), 1.0)).max())
+    record(name, **st)
+    assert na == nb and not oa and not ob, st
+    assert st["paired_exact"] == na, st
+    for f in ("xpos", "ypos", "scale", "sharpness", "edgeness"):
+        assert st.get(f + "_relerr", 0.0) <= RTOL, st
+    return st
+
+
+def test_findpoints_unfused_vs_oracle(ctx, stereo):
+    img = stereo[0][200:680, 300:940]          # 640x480 real-image crop
+    base, dog = _dog_of(img)
+    ref, nref = orc().findpoints(dog, 2.0)
+    got, ngot = ctx.findpoints(dog, 2.0, octave=5)
+    assert nref > 200
+    _cmp_detections(ref, nref, got, ngot, "findpoints_unfused_640x480")
+
+
+@pytest.mark.parametrize("h,w", [(480, 640), (135, 240), (67, 121), (270, 483)])
+def test_findpoints_fused_vs_oracle(ctx, stereo, h, w):
+    img = stereo[1][100:100 + h, 200:200 + w]
+    base, dog = _dog_of(img)
+    ref, nref = orc().findpoints(dog, 1.5)
+    got, ngot = ctx.dog_findpoints(base, 5, 5, 1.5)
+    _cmp_detections(ref, nref, got, ngot, "findpoints_fused_%dx%d" % (w, h))
+
+
+def test_findpoints_fused_equals_unfused_synthetic(ctx):
+    img = synth_frame(3, 1920, 270)            # full-width strip decomposition
+    base, dog = _dog_of(img, 4)
+    a, na = ctx.findpoints(dog, 3.0, octave=4, subsampling=2.0)
+    b, nb = ctx.dog_findpoints(base, 5, 4, 3.0, subsampling=2.0)
+    ref, nref = orc().findpoints(dog, 3.0, subsampling=2.0)
+    _cmp_detections(ref, nref, a, na, "findpoints_unfused_1920x270")
+    _cmp_detections(ref, nref, b, nb, "findpoints_fused_1920x270")
+
+
+# ------------------------------------------------- orientation + descriptor
+@pytest.mark.parametrize("fracbits", [8, 23])
+def test_orient_descr_vs_oracle(ctx, stereo, fracbits):
+    img = stereo[0][100:580, 500:1140]
+    base, dog = _dog_of(img)
+    pts, n = orc().findpoints(dog, 2.5, max_pts=4096)
+    assert n > 100
+    ref = pts.copy()
+    ndup = orc().orientations(base, ref, 0, n, 4096, fracbits)
+    orc().descriptors(base, ref, 0, ndup, 1.0, fracbits)
+    ctx.set_options(texfrac_bits=fracbits)
+    try:
+        got, cnt = ctx.orient_and_describe(base, pts, 0, n, octave=5, subsampling=1.0, max_pts=4096)
+    finally:
+        ctx.set_options(texfrac_bits=8)
+    assert int(cnt[11]) == ndup, (cnt, ndup)
+    compare_points(ref[:ndup], got[:ndup], "orient_descr_tex%d" % fracbits, record)
+
+
+# ----------------------------------------------------------- whole pipeline
+def _extract_both(ctx, img, **kw):
+    ref, nref, cref = orc().extract(img, **kw)
+    got, ngot, cgot = ctx.extract(img, **kw)
+    return ref, nref, cref, got, ngot, cgot
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_extract_stereo_left(ctx, stereo, fused):
+    ctx.set_options(fused=fused)
+    try:
+        ref, nref, cref, got, ngot, cgot = _extract_both(ctx, stereo[0], num_octaves=5, init_blur=1.0, thresh=4.5)
+    finally:
+        ctx.set_options(fused=1)
+    record("extract_left_fused%d" % fused, counters_oracle=cref[:12], counters_hip=cgot[:12])
+    assert np.array_equal(cref, cgot), (cref, cgot)
+    assert nref == ngot
+    tot = int(cref[11])                         # includes finest-octave duplicates written past numPts
+    compare_points(ref[:tot], got[:tot], "extract_left_fused%d" % fused, record)
+
+
+def test_extract_stereo_right_1280x960(ctx, stereo):
+    ref, nref, cref, got, ngot, cgot = _extract_both(ctx, stereo[1], num_octaves=5, init_blur=1.0, thresh=4.5)
+    assert np.array_equal(cref, cgot), (cref, cgot)
+    compare_points(ref[:int(cref[11])], got[:int(cref[11])], "extract_right", record)
+
+
+def test_extract_synthetic_1920x1080(ctx):
+    img = synth_frame(0)
+    ref, nref, cref, got, ngot, cgot = _extract_both(ctx, img, num_octaves=5, init_blur=1.0, thresh=3.0)
+    record("extract_synth1080", counters_oracle=cref[:12], counters_hip=cgot[:12])
+    assert np.array_equal(cref, cgot), (cref, cgot)
+    assert 1000 < nref < 4000
+    compare_points(ref[:int(cref[11])], got[:int(cref[11])], "extract_synth1080", record)
+
+
+def test_extract_options_and_edge_cases(ctx, stereo):
+    img = stereo[0][:333, :517]                 # odd sizes, 3 octaves, lowestScale, no scratch, tiny capacity
+    for kw in (dict(num_octaves=3, thresh=3.0, lowest_scale=1.5),
+               dict(num_octaves=4, thresh=2.0, max_pts=256),
+               dict(num_octaves=2, thresh=1000.0)):
+        ref, nref, cref = orc().extract(img, **kw)
+        got, ngot, cgot = ctx.extract(img, scratch=False, **kw)
+        cap = kw.get("max_pts", 32768)
+        assert nref == ngot, (kw, cref, cgot)
+        # counters are deterministic until the capacity is hit (afterwards WHICH points were kept, and
+        # hence the duplicate count, depends on the append order — also in the reference)
+        below = cref < cap
+        assert np.array_equal(cref[below], cgot[below]) and (cgot[~below] >= cap).all(), (kw, cref, cgot)
+        if cap > 1000 and nref:
+            compare_points(ref[:nref], got[:ngot], "extract_opts_%d" % kw["num_octaves"], record)
+    ctx.set_options(fix_numpts=1)
+    try:
+        ref, nref, cref = orc().extract(img, num_octaves=3, thresh=3.0, fix_numpts=True)
+        got, ngot, cgot = ctx.extract(img, num_octaves=3, thresh=3.0)
+    finally:
+        ctx.set_options(fix_numpts=0)
+    assert nref == ngot == int(cref[7])
+
+
+def test_extract_scaleup(ctx, stereo):
+    img = stereo[0][300:540, 400:720]
+    ref, nref, cref = orc().extract(img, num_octaves=4, thresh=3.0, scale_up=True)
+    got, ngot, cgot = ctx.extract(img, num_octaves=4, thresh=3.0, scale_up=True)
+    assert np.array_equal(cref, cgot), (cref, cgot)
+    compare_points(ref[:nref], got[:ngot], "extract_scaleup", record)
+
+
+def test_extract_batch_equals_single(ctx):
+    imgs = np.stack([synth_frame(10 + f, 640, 360) for f in range(5)])
+    pts, n = ctx.extract_batch(imgs, num_octaves=4, thresh=3.0, max_pts=8192)
+    for f in range(5):
+        ref, nref, cref = orc().extract(imgs[f], num_octaves=4, thresh=3.0, max_pts=8192)
+        assert nref == n[f], (f, nref, n)
+        compare_points(ref[:nref], pts[f][:n[f]], "extract_batch_f%d" % f, record)
+
+
+def test_extract_deterministic_set(ctx, stereo):
+    a, na, ca = ctx.extract(stereo[1][:480, :640], thresh=3.0)
+    b, nb, cb = ctx.extract(stereo[1][:480, :640], thresh=3.0)
+    assert na == nb and np.array_equal(ca, cb)
+    ia, ib, oa, ob = associate(a[:na], b[:nb])
+    assert not oa and not ob and associate.last_exact == na
+
+
+# ------------------------------------------------------------------ matcher
+def _match_case(ctx, n1, n2, seed, full, exact, l2=False):
+    o = orc()
+    p1 = descriptors_to_points(synth_descriptors(n1, seed, l2), o.POINT_DTYPE)
+    p2 = descriptors_to_points(synth_descriptors(n2, seed + 1, l2), o.POINT_DTYPE)
+    ref = p1.copy()
+    o.match(ref, n1, p2, n2, full=full, exact=exact)
+    ctx.set_options(match_full=int(full), match_exact_top2=int(exact))
+    try:
+        got = ctx.match(p1, n1, p2, n2)
+    finally:
+        ctx.set_options(match_full=0, match_exact_top2=0)
+    name = "match_%dx%d_f%d_e%d" % (n1, n2, full, exact)
+    st = {"idx_equal": float((ref["match"] == got["match"]).mean()),
+          "score_bitexact": bool(np.array_equal(ref["score"], got["score"])),
+          "amb_bitexact": bool(np.array_equal(ref["ambiguity"], got["ambiguity"])),
+          "score_maxabs": float(np.abs(ref["score"] - got["score"]).max()),
+          "amb_maxabs": float(np.abs(ref["ambiguity"] - got["ambiguity"]).max())}
+    record(name, **st)
+    assert np.array_equal(ref["match"], got["match"]), st
+    assert np.array_equal(ref["score"], got["score"]), st
+    assert np.array_equal(ref["ambiguity"], got["ambiguity"]), st
+    assert np.array_equal(ref["match_xpos"], got["match_xpos"]) and np.array_equal(ref["match_ypos"], got["match_ypos"])
+    return ref, got
+
+
+@pytest.mark.parametrize("n1,n2", [(1000, 1000), (2000, 2085), (37, 31), (129, 64), (1, 33), (4100, 3000)])
+def test_match_reference_mode(ctx, n1, n2):
+    _match_case(ctx, n1, n2, 7, full=False, exact=False)
+
+
+@pytest.mark.parametrize("full,exact", [(True, False), (False, True), (True, True)])
+def test_match_modes(ctx, full, exact):
+    _match_case(ctx, 777, 1003, 11, full, exact, l2=True)
+
+
+def test_match_empty_and_ties(ctx):
+    o = orc()
+    p1 = descriptors_to_points(synth_descriptors(64, 3), o.POINT_DTYPE)
+    # n2 < 32 in reference mode: no column takes part -> match -1, score 0, xpos/ypos 0
+    got = ctx.match(p1, 64, p1[:20].copy(), 20)
+    assert (got["match"] == -1).all() and (got["score"] == 0).all() and (got["match_xpos"] == 0).all()
+    # exact duplicates in set 2: the earliest index must win, ambiguity ~ 1
+    p2 = np.concatenate([p1, p1])
+    ref = p1.copy()
+    o.match(ref, 64, p2, 128)
+    got = ctx.match(p1, 64, p2, 128)
+    assert np.array_equal(ref["match"], got["match"]) and (got["match"] == np.arange(64)).all()
+    assert np.array_equal(ref["ambiguity"], got["ambiguity"])
+    # all-negative correlations never win (score initialised to 0, matching.cu:317)
+    neg = p1.copy()
+    neg["data"] *= -1.0
+    got = ctx.match(neg, 64, p1, 64)
+    assert (got["match"] == -1).all()
+
+
+def test_match_rows_split(ctx):
+    o = orc()
+    n1, n2 = 1500, 1536
+    p1 = descriptors_to_points(synth_descriptors(n1, 21), o.POINT_DTYPE)
+    p2 = descriptors_to_points(synth_descriptors(n2, 22), o.POINT_DTYPE)
+    full = ctx.match(p1, n1, p2, n2)
+    part = p1.copy()
+    for r0, rc in ((0, 700), (700, 800)):
+        tmp = ctx.match(part, n1, p2, n2, row_begin=r0, row_count=rc)
+        part[r0:r0 + rc] = tmp[r0:r0 + rc]
+    for f in ("score", "ambiguity", "match"):
+        assert np.array_equal(full[f], part[f])
+
+
+def test_match_real_descriptors(ctx, stereo):
+    a, na, _ = ctx.extract(stereo[0], thresh=4.5)
+    b, nb, _ = ctx.extract(stereo[1], thresh=4.5)
+    ref = a.copy()
+    orc().match(ref, na, b, nb)
+    got = ctx.match(a, na, b, nb)
+    for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+        assert np.array_equal(ref[f][:na], got[f][:na]), f
+    m = got[:na]
+    good = m["ambiguity"] < 0.95
+    dy = m["match_ypos"][good] - m["ypos"][good]
+    dx = m["match_xpos"][good] - m["xpos"][good]
+    # the pair is a ~(-533, +18) px shift: most confident matches must agree with it
+    frac = float(((np.abs(dx + 533) < 40) & (np.abs(dy - 18) < 40)).mean())
+    record("match_real", n1=na, n2=nb, confident=int(good.sum()), geometric_consistency=frac)
+    assert good.sum() > 200 and frac > 0.7
+
+
+def test_match_large_property(ctx):
+    """Full-size style property (no oracle): matching a set against a shuffled copy of itself
+    must return the permutation with score == self-correlation, at 20000 x 20000."""
+    o = orc()
+    n = 20000
+    d = synth_descriptors(n, 99, l2=True)
+    perm = np.random.default_rng(5).permutation(n)
+    p1 = descriptors_to_points(d, o.POINT_DTYPE)
+    p2 = descriptors_to_points(d[perm], o.POINT_DTYPE)
+    ctx.set_options(match_full=1, match_exact_top2=1)
+    try:
+        got = ctx.match(p1, n, p2, n)
+    finally:
+        ctx.set_options(match_full=0, match_exact_top2=0)
+    inv = np.empty(n, int)
+    inv[perm] = np.arange(n)
+    assert np.array_equal(got["match"], inv)
+    self_corr = np.array([o.lib().orc_dot128(d[i].ctypes.data, d[i].ctypes.data) for i in range(0, n, 997)], np.float32)
+    # orc_dot128 returns c_float; compare a sample of rows bit-exactly
+    assert np.array_equal(got["score"][::997], self_corr)
+    assert (got["ambiguity"] < 1.0).all()
+
+
+def test_homography_from_matches(ctx, stereo):
+    from cudasift_amd import capi
+    a, na, _ = ctx.extract(stereo[0], thresh=4.5)
+    b, nb, _ = ctx.extract(stereo[1], thresh=4.5)
+    m = ctx.match(a, na, b, nb)
+    d = ctx.upload(m)
+    H, nmatch = ctx.find_homography(d.ptr, na, num_loops=2000, min_score=0.0, max_ambiguity=0.95, thresh=5.0)
+    record("homography", H=H.reshape(-1), inliers=nmatch)
+    assert nmatch > 100
+    assert abs(H[0, 2] + 533) < 60 and abs(H[1, 2] - 18) < 60

@@ -1,0 +1,118 @@
+"""Comparison helpers shared by the parity tests."""
+import numpy as np
+
+# north_star tolerance: 1e-4 relative on keypoint fields and descriptors
+RTOL = 1e-4
+ATOL = 1e-4
+
+
+def point_keys(p):
+    """Identity of a keypoint: bit patterns of (subsampling, xpos, ypos, sharpness).
+
+    The DoG pyramid and the refinement arithmetic are bit-identical between oracle and HIP
+    (explicit-FMA contract), so these four fields must agree exactly; scale/orientation/
+    descriptor go through libm and are compared with tolerances."""
+    k = np.stack([p["subsampling"].view(np.uint32), p["xpos"].view(np.uint32), p["ypos"].view(np.uint32),
+                  p["sharpness"].view(np.uint32)], axis=1)
+    return [tuple(r) for r in k.tolist()]
+
+
+def associate(a, b):
+    """Pair records of a and b with equal identity keys (duplicates paired by orientation order).
+    Returns (ia, ib, only_a, only_b)."""
+    from collections import defaultdict
+    da, db = defaultdict(list), defaultdict(list)
+    for i, k in enumerate(point_keys(a)):
+        da[k].append(i)
+    for i, k in enumerate(point_keys(b)):
+        db[k].append(i)
+    ia, ib, only_a, only_b = [], [], [], []
+    for k, la in da.items():
+        lb = db.get(k, [])
+        la = sorted(la, key=lambda i: a["orientation"][i])
+        lb = sorted(lb, key=lambda i: b["orientation"][i])
+        m = min(len(la), len(lb))
+        ia += la[:m]
+        ib += lb[:m]
+        only_a += la[m:]
+        only_b += lb[m:]
+    for k, lb in db.items():
+        if k not in da:
+            only_b += lb
+    n_exact = len(ia)
+    # second chance for leftovers: nearest neighbour within 1e-3 px / 1e-3 relative scale (would only be
+    # needed if the bit-exactness contract were broken; the count is reported as "paired_fuzzy")
+    if only_a and only_b:
+        ua, ub = list(only_a), list(only_b)
+        used = set()
+        still_a = []
+        bx = np.array([b["xpos"][j] for j in ub], np.float64)
+        by = np.array([b["ypos"][j] for j in ub], np.float64)
+        bs = np.array([b["scale"][j] for j in ub], np.float64)
+        bo = np.array([b["orientation"][j] for j in ub], np.float64)
+        bsub = np.array([b["subsampling"][j] for j in ub], np.float64)
+        for i in ua:
+            sub = float(a["subsampling"][i])
+            ok = (bsub == sub) & (np.abs(bx - a["xpos"][i]) <= 1e-3 * sub) & (np.abs(by - a["ypos"][i]) <= 1e-3 * sub) \
+                & (np.abs(bs - a["scale"][i]) <= 1e-3 * np.abs(a["scale"][i]))
+            cand = [j for j in np.nonzero(ok)[0] if j not in used]
+            if cand:
+                j = min(cand, key=lambda j: circ_diff_deg(bo[j], a["orientation"][i]))
+                used.add(j)
+                ia.append(i)
+                ib.append(ub[j])
+            else:
+                still_a.append(i)
+        only_a = still_a
+        only_b = [ub[j] for j in range(len(ub)) if j not in used]
+    associate.last_exact = n_exact
+    return np.array(ia, int), np.array(ib, int), only_a, only_b
+
+
+def rel_err(x, y):
+    x = np.asarray(x, np.float64)
+    y = np.asarray(y, np.float64)
+    return np.abs(x - y) / np.maximum(np.maximum(np.abs(x), np.abs(y)), 1.0)
+
+
+def circ_diff_deg(a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)) % 360.0
+    return np.minimum(d, 360.0 - d)
+
+
+def compare_points(a, b, name, record=None, outlier_budget=0.005):
+    """a = oracle points, b = HIP points (already cut to their valid lengths).
+    Asserts set equality and the SURVEY §7.5 tolerances; orientation/descriptor outliers (histogram-bin
+    flips caused by last-bit libm differences) are allowed up to `outlier_budget` of the points."""
+    ia, ib, only_a, only_b = associate(a, b)
+    n = max(len(a), len(b), 1)
+    stats = {"n_oracle": len(a), "n_hip": len(b), "paired": len(ia), "paired_exact": associate.last_exact,
+             "only_oracle": len(only_a), "only_hip": len(only_b)}
+    A, B = a[ia], b[ib]
+    stats["pos_relerr_max"] = float(max(rel_err(A["xpos"], B["xpos"]).max(), rel_err(A["ypos"], B["ypos"]).max())) \
+        if len(ia) else 0.0
+    stats["sharp_relerr_max"] = float(rel_err(A["sharpness"], B["sharpness"]).max()) if len(ia) else 0.0
+    stats["scale_relerr_max"] = float(rel_err(A["scale"], B["scale"]).max()) if len(ia) else 0.0
+    stats["edge_relerr_max"] = float(rel_err(A["edgeness"], B["edgeness"]).max()) if len(ia) else 0.0
+    od = circ_diff_deg(A["orientation"], B["orientation"]) if len(ia) else np.zeros(0)
+    dd = np.abs(A["data"].astype(np.float64) - B["data"]).max(axis=1) if len(ia) else np.zeros(0)
+    cos = (A["data"].astype(np.float64) * B["data"]).sum(axis=1) if len(ia) else np.ones(0)
+    bad_o = od > 0.036
+    bad_d = dd > ATOL
+    stats["orient_maxdiff_deg_inliers"] = float(od[~bad_o].max()) if (~bad_o).any() else 0.0
+    stats["orient_outliers"] = int(bad_o.sum())
+    stats["desc_maxabs_inliers"] = float(dd[~bad_d].max()) if (~bad_d).any() else 0.0
+    stats["desc_outliers"] = int(bad_d.sum())
+    stats["desc_outliers_not_orient"] = int((bad_d & ~bad_o).sum())
+    stats["desc_min_cos"] = float(cos.min()) if len(cos) else 1.0
+    stats["nan_desc_hip"] = int(np.isnan(b["data"]).any(axis=1).sum())
+    if record:
+        record(name, **stats)
+    assert len(only_a) == 0 and len(only_b) == 0, "keypoint sets differ: %s" % stats
+    assert stats["pos_relerr_max"] <= RTOL and stats["sharp_relerr_max"] <= RTOL, stats
+    assert stats["scale_relerr_max"] <= RTOL, stats
+    assert stats["edge_relerr_max"] <= RTOL, stats
+    assert stats["nan_desc_hip"] == 0, stats
+    assert stats["orient_outliers"] <= max(2, outlier_budget * n), stats
+    assert stats["desc_outliers"] <= max(2, 2 * outlier_budget * n), stats
+    return stats
