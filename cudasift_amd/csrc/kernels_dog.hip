@@ -124,6 +124,26 @@ __device__ __forceinline__ Row6 make_row6(float4 c)
   o.r = lane_from_right(c.x);
   return o;
 }
+// Fused path: the DoG quad was COMPUTED (not loaded), so the clamp-to-edge addressing of the
+// reference's neighbour reads (cudaSiftD.cu:1308, xpos clamped) must be applied in DoG space:
+// pixels right of the image take DoG(width-1), the pixel left of column 0 takes DoG(0).
+__device__ __forceinline__ Row6 make_row6_edge(float4 c, int q, int width)
+{
+  const int x = 4 * q;
+  if (x < width && x + 3 >= width) {           // this quad holds the last image column
+    const int last = width - 1 - x;            // 0..3
+    const float e = last == 0 ? c.x : (last == 1 ? c.y : (last == 2 ? c.z : c.w));
+    if (last < 1) c.y = e;
+    if (last < 2) c.z = e;
+    if (last < 3) c.w = e;
+  }
+  Row6 o;
+  o.x = c.x; o.y = c.y; o.z = c.z; o.w = c.w;
+  const float fl = lane_from_left(c.w), fr = lane_from_right(c.x);   // all lanes execute the DPP
+  o.l = (x - 1 < 0) ? c.x : fl;
+  o.r = (x + 4 >= width) ? c.w : fr;
+  return o;
+}
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(256) void dog_detect_kernel(const float *__restrict
 #pragma unroll
     for (int s = 1; s < NUM_BLURS; s++) {
       const float4 res = blur_quad(taps.k[s], r4, p1, p2, p3, p4);
-      dst[s - 1] = make_row6(sub4(res, old));
+      dst[s - 1] = make_row6_edge(sub4(res, old), q, g.width);
       old = res;
     }
   };
