@@ -12,7 +12,7 @@ HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_
             $(CSRC)/kernels_match.hip $(CSRC)/misift_host.hip $(CSRC)/homography.hip
 HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
-all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle
+all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle dropin
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
 	@mkdir -p $(BUILD)
@@ -32,3 +32,15 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean
+
+# Drop-in demonstration: the reference's OWN mainSift.cpp + geomFuncs.cpp, compiled unchanged from
+# $(REF) against include/cudaSift.h + libcudasift.so (mini-OpenCV stand-in because OpenCV is absent).
+# Output under oracle/_ref/ (git-ignored, travels to the GPU box).  Skipped where $(REF) is absent.
+REF ?= /root/reference
+dropin: cudasift_amd/libcudasift.so
+	@if [ -f $(REF)/mainSift.cpp ]; then mkdir -p oracle/_ref && \
+	  $(CXX) -O2 -std=c++17 -Iinclude -Icudasift_amd/compat -o oracle/_ref/cudasift_dropin \
+	    $(REF)/mainSift.cpp $(REF)/geomFuncs.cpp -Lcudasift_amd -lcudasift -lmisift \
+	    -Wl,-rpath,'$$ORIGIN/../../cudasift_amd' && echo "built oracle/_ref/cudasift_dropin"; \
+	else echo "dropin: $(REF) absent, keeping prebuilt binary"; fi
+.PHONY: dropin

@@ -1,0 +1,110 @@
+"""CPU tests of the boundary (no GPU, no compute calls): the C-ABI library loads and exports every symbol
+include/misift.h declares; the C++ shim exports the reference's mangled C++ API; struct layouts match."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+def declared_functions():
+    src = open(os.path.join(INC, "misift.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(misift_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from cudasift_amd import capi
+    L = capi.lib()                       # raises if libmisift.so is missing: there is no fallback
+    names = declared_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), "libmisift.so does not export %s" % n
+    # the ctypes table covers the whole header (so tests/bench bind by the declared signatures)
+    assert set(names) == set(capi.SIGNATURES.keys()), set(names) ^ set(capi.SIGNATURES.keys())
+
+
+def test_cabi_no_device_paths_fail_cleanly():
+    """On a box without a GPU nothing falls back to the CPU: context creation reports MISIFT_ENODEV."""
+    from cudasift_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(capi.MisiftError):
+        capi.Context(0)
+    assert b"no HIP device" in capi.lib().misift_last_error()
+
+
+def test_host_only_entry_points():
+    from cudasift_amd import capi
+    # scratch sizing follows cudaSiftH.cu:39-57 (numOctaves+1 levels), rounded to 4096 floats
+    w, h, p = 1920, 1080, 1920
+    size, tmp = h * p, 8 * h * p
+    ww, hh = w, h
+    for _ in range(5):
+        ww //= 2
+        hh //= 2
+        pp = (ww + 127) // 128 * 128
+        size += hh * pp
+        tmp += 8 * hh * pp
+    assert capi.scratch_floats(1920, 1080, 5) == (size + tmp + 4095) // 4096 * 4096
+    from oracle import pyoracle as orc
+    assert np.array_equal(capi.laplace_taps(5), orc.laplace_taps(5))     # same host formula, same libm
+    o = capi.Options()
+    capi.lib().misift_default_options(C.byref(o))
+    assert (o.texfrac_bits, o.fix_numpts, o.match_full, o.match_exact_top2) == (8, 0, 0, 0)
+
+
+def test_point_record_layout():
+    from cudasift_amd import capi
+    d = capi.POINT_DTYPE
+    assert d.itemsize == 576
+    assert d.fields["score"][1] == 24 and d.fields["match"][1] == 32 and d.fields["match_xpos"][1] == 36
+    assert d.fields["subsampling"][1] == 48 and d.fields["data"][1] == 64
+
+
+def test_cpp_shim_exports_reference_api():
+    lib = os.path.join(ROOT, "cudasift_amd", "libcudasift.so")
+    assert os.path.exists(lib), "run `make`"
+    syms = subprocess.check_output("nm -D --defined-only %s | c++filt" % lib, shell=True, text=True)
+    for want in ["InitCuda(int)", "AllocSiftTempMemory(int, int, int, bool)", "FreeSiftTempMemory(float*)",
+                 "ExtractSift(SiftData&, CudaImage&, int, double, float, float, bool, float*)",
+                 "InitSiftData(SiftData&, int, bool, bool)", "FreeSiftData(SiftData&)", "PrintSiftData(SiftData&)",
+                 "MatchSiftData(SiftData&, SiftData&)",
+                 "FindHomography(SiftData&, float*, int*, int, float, float, float)",
+                 "CudaImage::CudaImage()", "CudaImage::~CudaImage()",
+                 "CudaImage::Allocate(int, int, int, bool, float*, float*)", "CudaImage::Download()",
+                 "CudaImage::Readback()", "CudaImage::InitTexture()", "CudaImage::CopyToTexture(CudaImage&, bool)",
+                 "iDivUp(int, int)", "iDivDown(int, int)", "iAlignUp(int, int)", "iAlignDown(int, int)"]:
+        assert want in syms, want
+
+
+def test_headers_are_plain_cpp_and_layout_matches(tmp_path):
+    src = tmp_path / "layout.cpp"
+    src.write_text('#include <cstdio>\n#include <cstddef>\n#include "cudaSift.h"\n'
+                   'int main(){ CudaImage img; SiftData d; (void)d;\n'
+                   ' printf("%zu %zu %zu %zu %zu %zu %d\\n", sizeof(SiftPoint), offsetof(SiftPoint,score),'
+                   ' offsetof(SiftPoint,match), offsetof(SiftPoint,subsampling), offsetof(SiftPoint,data),'
+                   ' sizeof(SiftData), img.pitch); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["g++", "-std=c++17", "-I", INC, str(src), "-o", str(exe), "-L",
+                           os.path.join(ROOT, "cudasift_amd"), "-lcudasift", "-lmisift",
+                           "-Wl,-rpath," + os.path.join(ROOT, "cudasift_amd")])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    assert out == ["576", "24", "32", "48", "64", "24", "0"]
+
+
+def test_reference_main_compiles_unchanged(tmp_path):
+    ref = os.environ.get("REF", "/root/reference")
+    if not os.path.exists(os.path.join(ref, "mainSift.cpp")):
+        pytest.skip("reference tree absent")
+    exe = tmp_path / "dropin"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", INC, "-I", os.path.join(ROOT, "cudasift_amd", "compat"),
+                           os.path.join(ref, "mainSift.cpp"), os.path.join(ref, "geomFuncs.cpp"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "cudasift_amd"), "-lcudasift", "-lmisift",
+                           "-Wl,-rpath," + os.path.join(ROOT, "cudasift_amd")])
+    assert os.path.exists(exe)

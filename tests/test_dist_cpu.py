@@ -1,0 +1,91 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the multi-GPU plumbing in cudasift_amd/dist.py:
+the frame sharding, the variable-length gather of SiftPoint records to rank 0 and the row-block matcher
+split with all-gather of set 2 — the same code path bench.py drives with backend "nccl" (RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from cudasift_amd.dist import RECORD_BYTES, gather_sift_records, shard_range, unpack_records
+    from oracle import pyoracle as orc
+    from synth import descriptors_to_points, synth_descriptors
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    # ---- frames shard: every rank owns B frames with different valid counts
+    B, max_pts = 3, 16
+    rng = np.random.default_rng(100 + rank)
+    counts = rng.integers(0, max_pts + 1, size=B).astype(np.int32)
+    counts[rank % B] = 0                                   # an empty frame
+    pts = torch.from_numpy(rng.integers(0, 255, size=(B, max_pts * RECORD_BYTES), dtype=np.uint8))
+    all_counts, bufs = gather_sift_records(dist, torch, pts, counts, rank, world, dev)
+    ok = True
+    if rank == 0:
+        assert bufs is not None and len(bufs) == world
+        for r in range(world):
+            rr = np.random.default_rng(100 + r)
+            c = rr.integers(0, max_pts + 1, size=B).astype(np.int32)
+            c[r % B] = 0
+            ref = rr.integers(0, 255, size=(B, max_pts * RECORD_BYTES), dtype=np.uint8)
+            ok &= bool(np.array_equal(all_counts[r], c))
+            frames = unpack_records(bufs[r], all_counts[r])
+            for f in range(B):
+                ok &= bool(np.array_equal(frames[f].numpy().reshape(-1), ref[f, : c[f] * RECORD_BYTES]))
+    else:
+        assert bufs is None
+    # ---- matcher: row blocks of set 1, set 2 sharded then all-gathered (BASELINE config 5)
+    n1, n2 = 96, 64
+    p1 = descriptors_to_points(synth_descriptors(n1, 1), orc.POINT_DTYPE)
+    p2 = descriptors_to_points(synth_descriptors(n2, 2), orc.POINT_DTYPE)
+    b2, e2 = shard_range(n2, rank, world)
+    shard = torch.from_numpy(p2[b2:e2].view(np.uint8).reshape(e2 - b2, RECORD_BYTES).copy())
+    parts = [torch.empty((shard_range(n2, r, world)[1] - shard_range(n2, r, world)[0], RECORD_BYTES), dtype=torch.uint8)
+             for r in range(world)]
+    dist.all_gather(parts, shard)
+    full2 = torch.cat(parts).numpy().view(orc.POINT_DTYPE).reshape(-1)
+    ok &= bool(np.array_equal(full2["data"], p2["data"]))
+    b1, e1 = shard_range(n1, rank, world)
+    mine = p1.copy()
+    orc.match_rows(mine, b1, e1 - b1, full2, n2)           # the CPU oracle stands in for misift_match_rows
+    res = torch.from_numpy(np.stack([mine["score"][b1:e1], mine["ambiguity"][b1:e1],
+                                     mine["match"][b1:e1].astype(np.float32)], axis=1).copy())
+    outs = [torch.empty((shard_range(n1, r, world)[1] - shard_range(n1, r, world)[0], 3)) for r in range(world)]
+    dist.all_gather(outs, res)
+    ref = p1.copy()
+    orc.match(ref, n1, p2, n2)
+    got = torch.cat(outs).numpy()
+    ok &= bool(np.array_equal(got[:, 0], ref["score"]) and np.array_equal(got[:, 2], ref["match"].astype(np.float32)))
+    open(os.path.join(out_dir, "ok%d" % rank), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from cudasift_amd.dist import shard_range
+    for total in (0, 1, 7, 512, 100000):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [e - b for b, e in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_and_row_block_match_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "ok0").read() == "1" and open(tmp_path / "ok1").read() == "1"

@@ -1,0 +1,47 @@
+"""Drop-in check: the reference's OWN mainSift.cpp + geomFuncs.cpp (compiled unchanged from the reference
+tree by `make dropin` into oracle/_ref/cudasift_dropin, linked against libcudasift.so + libmisift.so) runs
+on the GPU and prints what the reference prints (mainSift.cpp:80-81), with the feature counts of the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "cudasift_dropin")
+
+
+def write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, np.uint8).tobytes())
+
+
+def test_reference_main_runs_unchanged(tmp_path):
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/cudasift_dropin not built (needs /root/reference at build time)")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_pair_u8.npz"))
+    os.makedirs(tmp_path / "data")
+    write_pgm(tmp_path / "data" / "left.pgm", z["left"])
+    write_pgm(tmp_path / "data" / "righ.pgm", z["right"])
+    env = dict(os.environ, MISIFT_QUIET="1")
+    r = subprocess.run([BIN, "0", "1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    outdir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(outdir):
+        with open(os.path.join(outdir, "dropin_stdout.txt"), "w") as f:
+            f.write(out[-6000:])
+    assert "Image size = (1280,960)" in out
+    m = re.search(r"Number of original features: (\d+) (\d+)", out)
+    assert m, out[-2000:]
+    from oracle import pyoracle as orc
+    _, n1, _ = orc.extract(z["left"].astype(np.float32), 5, 1.0, 4.5)
+    _, n2, _ = orc.extract(z["right"].astype(np.float32), 5, 1.0, 4.5)
+    assert (int(m.group(1)), int(m.group(2))) == (n1, n2)
+    m2 = re.search(r"Number of matching features: (\d+) (\d+) ([\d.]+)% 1 4.5", out)
+    assert m2, out[-2000:]
+    assert int(m2.group(2)) > 100                       # RANSAC inliers of the best hypothesis
+    assert os.path.exists(tmp_path / "data" / "limg_pts.pgm")

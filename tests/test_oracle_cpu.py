@@ -1,0 +1,262 @@
+"""CPU tests of the oracle (no GPU): closed forms, SURVEY Appendix C tap tables, golden regression,
+and the matcher pinned against the reference's own CPU routines built into oracle/_ref."""
+import os
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from oracle import pyoracle as orc
+from synth import descriptors_to_points, synth_descriptors
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---------------------------------------------------------------------- taps
+def test_tap_tables_match_survey_appendix_c():
+    """SURVEY.md Appendix C lists the fp32 taps computed from cudaSiftH.cu:439-458 / :316-323 / :408-418."""
+    t = orc.laplace_taps(5).reshape(8, 12, 16)
+    exp5 = {0: [.45826, .23691, .03273, .00121, .00001], 1: [.39894, .24197, .05399, .00443, .00013],
+            2: [.34732, .23777, .07629, .01147, .00081], 3: [.30249, .22698, .09590, .02282, .00306],
+            4: [.26386, .21226, .11049, .03721, .00811], 5: [.23116, .19601, .11951, .05239, .01651],
+            6: [.20416, .18017, .12383, .06628, .02763], 7: [.18247, .16598, .12492, .07779, .04008]}
+    for i, e in exp5.items():
+        assert np.allclose(t[5, i, :5], e, atol=6e-6), (i, t[5, i, :5])
+    assert np.allclose(t[4, 1, :5], [.41203, .24171, .04880, .00339, .00008], atol=6e-6)
+    assert np.allclose(t[1, 1, :5], [.41661, .24150, .04704, .00308, .00007], atol=6e-6)
+    # every table is normalised: k0 + 2*sum(k1..k4) == 1
+    for o in range(1, 6):
+        for i in range(8):
+            k = t[o, i, :5].astype(np.float64)
+            assert abs(k[0] + 2 * k[1:].sum() - 1.0) < 1e-6
+    assert np.allclose(orc.scaledown_taps(0.5), [.010334, .207561, .564210, .207561, .010334], atol=1e-6)
+    assert np.allclose(orc.lowpass_taps(1.0)[4:], [.398943, .241971, .053991, .004432, .000134], atol=1e-6)
+
+
+def test_octave_blur_recursion():
+    """b5=0, b4=.25, b3=.279509, b2=.286411, b1=.288111: sigma_1 tap tables get narrower."""
+    t = orc.laplace_taps(5).reshape(8, 12, 16)
+    centre = [t[o, 1, 0] for o in (5, 4, 3, 2, 1)]
+    assert centre == sorted(centre)          # less pre-blur to add => narrower kernel => larger centre tap
+
+
+# ------------------------------------------------------------------- filters
+def test_lowpass_constant_and_impulse():
+    c = np.full((40, 50), 7.25, np.float32)
+    assert np.allclose(orc.lowpass(c, 1.0), 7.25, atol=1e-5)
+    imp = np.zeros((41, 41), np.float32)
+    imp[20, 20] = 1.0
+    k = orc.lowpass_taps(1.3)
+    out = orc.lowpass(imp, 1.3)
+    assert np.allclose(out[16:25, 16:25], np.outer(k, k), atol=1e-7)
+
+
+def test_lowpass_vs_scipy_nearest():
+    rng = np.random.default_rng(0)
+    img = (rng.random((97, 133), dtype=np.float32) * 255).astype(np.float32)
+    k = orc.lowpass_taps(1.0).astype(np.float64)
+    ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="nearest"), k, axis=0,
+                              mode="nearest")
+    assert np.abs(orc.lowpass(img, 1.0) - ref).max() < 1e-3
+
+
+def test_scaledown_vs_scipy():
+    rng = np.random.default_rng(1)
+    img = (rng.random((75, 101), dtype=np.float32) * 255).astype(np.float32)
+    k = orc.scaledown_taps().astype(np.float64)
+    full = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="nearest"), k, axis=0,
+                               mode="nearest")
+    out = orc.scaledown(img)
+    assert out.shape == (37, 50)
+    assert np.abs(out - full[0:74:2, 0:100:2]).max() < 1e-3
+
+
+def test_scaleup_shape_and_values():
+    img = np.arange(12, dtype=np.float32).reshape(3, 4)
+    up = orc.scaleup(img)
+    assert up.shape == (6, 8)
+    assert up[0, 0] == 0 and up[0, 1] == 0.5 and up[1, 0] == 2.0 and up[1, 1] == 2.5
+    assert up[5, 7] == 11.0          # clamp at the border
+
+
+def test_laplace_dog_properties():
+    c = np.full((32, 48), 100.0, np.float32)
+    assert np.abs(orc.laplace(c, 5, 5)).max() < 1e-4        # DoG of a constant is zero
+    rng = np.random.default_rng(2)
+    img = orc.lowpass((rng.random((64, 80), dtype=np.float32) * 255).astype(np.float32), 1.0)
+    dog = orc.laplace(img, 5, 4)
+    t = orc.laplace_taps(5).reshape(8, 12, 16)[4]
+
+    def blur(i):
+        k = np.concatenate([t[i, 4:0:-1], t[i, :5]]).astype(np.float64)
+        return ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=0, mode="nearest"), k, axis=1,
+                                   mode="nearest")
+    for s in range(7):
+        assert np.abs(dog[s] - (blur(s + 1) - blur(s))).max() < 1e-3
+
+
+# -------------------------------------------------------- texture emulation
+def test_tex2d_emulation():
+    img = np.arange(20, dtype=np.float32).reshape(4, 5) * 3.0
+    assert orc.tex2d(img, 2.5, 1.5, 8) == img[1, 2]                 # texel centres
+    assert orc.tex2d(img, -3.0, -3.0, 8) == img[0, 0]               # clamp
+    assert orc.tex2d(img, 99.0, 99.0, 23) == img[3, 4]
+    assert abs(orc.tex2d(img, 3.0, 1.5, 23) - 0.5 * (img[1, 2] + img[1, 3])) < 1e-6
+    # 8 fractional bits: weights are multiples of 1/256
+    a = orc.tex2d(img, 2.5 + 1.0 / 512 + 1e-4, 1.5, 8)
+    assert abs(a - (img[1, 2] + (img[1, 3] - img[1, 2]) / 256.0)) < 1e-5
+    assert orc.tex2d(img, 2.5 + 1.0 / 1024, 1.5, 8) == img[1, 2]
+
+
+def test_fast_atan2_close_to_atan2():
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal((2000, 2)).astype(np.float32)
+    err = [abs(orc.lib().orc_fast_atan2(float(y), float(x)) - np.arctan2(y, x)) for y, x in v]
+    assert max(err) < 2e-3
+    assert orc.lib().orc_fast_atan2(0.0, 0.0) == 0.0                # Appendix B #7 guard
+
+
+# ---------------------------------------------------------------- keypoints
+def _blob(h, w, cx, cy, sigma, amp=120.0):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    return (40.0 + amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sigma * sigma))).astype(np.float32)
+
+
+def test_blob_detected_with_position_and_scale():
+    img = _blob(128, 160, 70.3, 61.6, 3.0)
+    pts, n, cnt = orc.extract(img, num_octaves=3, init_blur=0.0, thresh=2.0)
+    assert n >= 1
+    p = pts[:n]
+    best = p[np.argmax(np.abs(p["sharpness"]))]
+    assert abs(best["xpos"] - 70.3) < 0.75 and abs(best["ypos"] - 61.6) < 0.75
+    assert 2.0 < best["scale"] < 6.0          # DoG extremum scale ~ sigma * sqrt(2)
+    assert cnt[2 * 3] == n or cnt[2 * 3] >= n
+
+
+def test_scale_covariance():
+    a = _blob(200, 200, 100.0, 100.0, 3.0)
+    b = _blob(200, 200, 100.0, 100.0, 6.0)
+    pa, na, _ = orc.extract(a, num_octaves=4, init_blur=0.0, thresh=2.0)
+    pb, nb, _ = orc.extract(b, num_octaves=4, init_blur=0.0, thresh=2.0)
+    sa = pa[:na][np.argmax(np.abs(pa[:na]["sharpness"]))]["scale"]
+    sb = pb[:nb][np.argmax(np.abs(pb[:nb]["sharpness"]))]["scale"]
+    assert 1.6 < sb / sa < 2.5
+
+
+def test_orientation_covariance_and_unit_descriptors(stereo):
+    img = stereo[0][300:540, 400:720].copy()
+    rot = np.ascontiguousarray(np.rot90(img, 2))            # 180 degree rotation: same arithmetic up to ordering
+    pa, na, _ = orc.extract(img, num_octaves=3, thresh=3.0)
+    pb, nb, _ = orc.extract(rot, num_octaves=3, thresh=3.0)
+    assert na > 50 and abs(na - nb) <= max(3, 0.05 * na)
+    A = pa[:na]
+    assert np.allclose(np.linalg.norm(A["data"], axis=1), 1.0, atol=1e-5)
+    assert (A["data"] >= 0).all() and (A["orientation"] >= 0).all() and (A["orientation"] < 360.0001).all()
+    # finest-octave keypoints map exactly under a 180 degree rotation (symmetric filters, x -> w-1-x);
+    # their orientation must turn by 180 degrees
+    h, w = img.shape
+    fine = A[A["subsampling"] == 1.0][:80]
+    Bf = pb[:nb][pb[:nb]["subsampling"] == 1.0]
+    assert len(fine) >= 20
+    hits = 0
+    for p in fine:
+        xr, yr = w - 1 - p["xpos"], h - 1 - p["ypos"]
+        d = np.hypot(Bf["xpos"] - xr, Bf["ypos"] - yr)
+        if d.min() < 0.05:
+            diffs = np.abs(((Bf["orientation"][d < 0.05] - p["orientation"]) % 360.0) - 180.0)
+            hits += int(diffs.min() < 1.0)
+    assert hits >= 0.8 * len(fine), (hits, len(fine))
+
+
+def test_counter_protocol_and_numpts_rule(stereo):
+    img = stereo[1][:480, :640]
+    pts, n, cnt = orc.extract(img, num_octaves=5, thresh=3.0)
+    assert (np.diff(cnt[1:12].astype(np.int64)) >= 0).all()        # running totals, coarse to fine
+    assert n == cnt[10]                                             # excludes finest-octave duplicates (B#1)
+    pts2, n2, cnt2 = orc.extract(img, num_octaves=5, thresh=3.0, fix_numpts=True)
+    assert n2 == cnt2[11] and np.array_equal(cnt, cnt2)
+    # coarse octaves come first: subsampling is non-increasing along the array
+    sub = pts[:n]["subsampling"]
+    assert (np.diff(sub) <= 0).all() and sub[0] == 16.0 and sub[-1] == 1.0
+    # capacity clamp
+    pts3, n3, _ = orc.extract(img, num_octaves=5, thresh=3.0, max_pts=100)
+    assert n3 == 100
+
+
+def test_oracle_golden_regression():
+    """The committed fixture pins the oracle against silent drift (generated by tests/golden/make_fixtures.py)."""
+    z = np.load(os.path.join(GOLDEN, "oracle_small.npz"))
+    left = np.load(os.path.join(GOLDEN, "stereo_pair_u8.npz"))["left"]
+    crop = left[300:540, 400:720].astype(np.float32)
+    pts, n, cnt = orc.extract(crop, num_octaves=4, init_blur=1.0, thresh=3.5)
+    assert n == int(z["n"]) and np.array_equal(cnt, z["counters"])
+    p = pts[:n]
+    order = np.lexsort((p["orientation"], p["scale"], p["xpos"], p["ypos"]))
+    p = p[order]
+    for f in ("xpos", "ypos", "scale", "orientation", "sharpness", "edgeness"):
+        assert np.allclose(p[f], z[f], rtol=1e-5, atol=1e-5), f
+    assert np.abs(p["data"] - z["desc"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------- matcher
+def test_matcher_modes_against_numpy():
+    n1, n2 = 300, 277
+    p1 = descriptors_to_points(synth_descriptors(n1, 1, l2=True), orc.POINT_DTYPE)
+    p2 = descriptors_to_points(synth_descriptors(n2, 2, l2=True), orc.POINT_DTYPE)
+    S = p1["data"].astype(np.float64) @ p2["data"].astype(np.float64).T
+    # exact, all columns == numpy top-2
+    a = p1.copy()
+    orc.match(a, n1, p2, n2, full=True, exact=True)
+    assert np.array_equal(a["match"], S.argmax(1))
+    top2 = np.sort(S, axis=1)[:, -2:]
+    assert np.allclose(a["score"], top2[:, 1], atol=1e-5)
+    assert np.allclose(a["ambiguity"], top2[:, 0] / (top2[:, 1] + 1e-6), atol=1e-5)
+    # reference mode ignores the last n2 % 32 columns (Appendix B #9)
+    b = p1.copy()
+    orc.match(b, n1, p2, n2)
+    assert (b["match"] < 32 * (n2 // 32)).all()
+    assert np.array_equal(b["match"], S[:, :256].argmax(1))
+    # 8-class merge can only under-estimate the runner-up (Appendix B #10)
+    c = p1.copy()
+    orc.match(c, n1, p2, n2, exact=True)
+    assert np.array_equal(b["score"], c["score"]) and (b["ambiguity"] <= c["ambiguity"] + 1e-7).all()
+    assert (b["ambiguity"] < c["ambiguity"]).sum() > 0
+    assert np.array_equal(b["match_xpos"], p2["xpos"][b["match"]])
+
+
+def test_matcher_pinned_against_reference_cpu_code():
+    """oracle/_ref is the reference's own MatchC1 / MatchC3 (match.cu:57-130) compiled from /root/reference."""
+    L = orc.ref_lib(1024)
+    if L is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    n = 1024
+    a, b = orc.aligned_f32(n * 128), orc.aligned_f32(n * 128)
+    L.ref_generate(a.ctypes.data, b.ctypes.data, 1)          # the reference's own generator, glibc seed 1
+    s1, i1 = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    s3, i3 = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    L.ref_match_c1(a.ctypes.data, b.ctypes.data, s1.ctypes.data, i1.ctypes.data)
+    L.ref_match_c3(a.ctypes.data, b.ctypes.data, s3.ctypes.data, i3.ctypes.data)
+    so, io = orc.match_argmax(a.reshape(n, 128), b.reshape(n, 128))
+    # scalar reference: same sequential FMA chain -> bit-identical scores and indices
+    assert np.array_equal(io, i1) and np.array_equal(so, s1)
+    # AVX2 reference (8 partial sums): CheckMatches semantics — indices equal
+    assert (io != i3).sum() == 0
+    assert np.abs(so - s3).max() < 1e-4
+    # and through the SiftPoint/MatchSiftData form of the oracle (all columns, n % 32 == 0)
+    p1 = descriptors_to_points(a.reshape(n, 128), orc.POINT_DTYPE)
+    p2 = descriptors_to_points(b.reshape(n, 128), orc.POINT_DTYPE)
+    orc.match(p1, n, p2, n)
+    assert np.array_equal(p1["match"], i1) and np.array_equal(p1["score"], s1)
+
+
+def test_matcher_row_blocks_equal_full():
+    n1, n2 = 130, 96
+    p1 = descriptors_to_points(synth_descriptors(n1, 5), orc.POINT_DTYPE)
+    p2 = descriptors_to_points(synth_descriptors(n2, 6), orc.POINT_DTYPE)
+    full = p1.copy()
+    orc.match(full, n1, p2, n2)
+    part = p1.copy()
+    orc.match_rows(part, 0, 50, p2, n2)
+    orc.match_rows(part, 50, 80, p2, n2)
+    for f in ("score", "ambiguity", "match"):
+        assert np.array_equal(full[f], part[f])
