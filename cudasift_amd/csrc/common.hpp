@@ -48,15 +48,15 @@ struct StripGeom {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// Lane i receives lane i-1's value (lane 0 receives 0): DPP wave_shr:1.
+// Lane i receives lane i-1's value (lane 0 receives 0: bound_ctrl): DPP wave_shr:1.
 __device__ __forceinline__ float lane_from_left(float x)
 {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
 }
 // Lane i receives lane i+1's value (lane 63 receives 0): DPP wave_shl:1.
 __device__ __forceinline__ float lane_from_right(float x)
 {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float4 quad_from_left(float4 v)
 {
@@ -189,11 +189,11 @@ int launch_laplace(misift_ctx *ctx, const float *base, const StripGeom &g, float
                    long long dog_frame_stride, const LaplaceTaps &taps);
 int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long long dog_frame_stride,
                   float thresh, int octave);
-int launch_dog_detect(misift_ctx *ctx, const float *base, const StripGeom &g, const LaplaceTaps &taps,
+int launch_dog_scan(misift_ctx *ctx, const float *base, const StripGeom &g, const LaplaceTaps &taps,
                       float thresh, int octave);
 int launch_refine(misift_ctx *ctx, const float *dog, long long dog_frame_stride, const float *base,
                   long long base_frame_stride, const LaplaceTaps *taps, int w, int h, int pitch, int nframes,
-                  float edge_limit, float factor, float lowest_scale, float subsampling, int octave,
+                  float thresh, float edge_limit, float factor, float lowest_scale, float subsampling, int octave,
                   SiftPointD *pts, int max_pts);
 int launch_orient(misift_ctx *ctx, const float *base, long long base_frame_stride, int w, int h, int pitch,
                   int nframes, int octave, SiftPointD *pts, int max_pts);

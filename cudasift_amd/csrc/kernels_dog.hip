@@ -17,6 +17,7 @@
 //
 // Compiled with -ffp-contract=off: every multiply-add below that is meant to be
 // fused is an explicit __builtin_fmaf, exactly as in oracle/sift_oracle.c.
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include "common.hpp"
@@ -258,16 +259,25 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
   }
 }
 
-// ------------------------------------------------------- fused DoG + detect
-__global__ __launch_bounds__(256) void dog_detect_kernel(const float *__restrict__ base, StripGeom g,
-                                                         LaplaceTaps taps, float thresh, int octave,
-                                                         unsigned *__restrict__ counters,
-                                                         unsigned *__restrict__ cand, unsigned cand_cap, int aligned)
+// ------------------------------------------------------- fused DoG + scan
+// dog_scan_kernel: blur -> DoG in registers (nothing but the base image is read, nothing but
+// a short candidate list is written) and a cheap NECESSARY test per pixel and scale:
+//   |v| > thresh  and  v is a strict extremum of its 8 neighbours IN THE SAME ROW
+//   (3 planes x 3 columns).
+// Survivors ("pre-candidates", typically < 0.1 % of the pixels) go to the frame's candidate
+// list; refine_kernel<true> recomputes their 3x3x3 DoG neighbourhood bit-identically and
+// applies the reference's full 26-neighbour test (cudaSiftD.cu:1337-1360) before refining.
+// Keeping only the current DoG row in registers (no 3-row window, no box minima) leaves the
+// kernel at ~1/2 the registers and ~1/3 the instructions of a full in-register 3x3x3 test.
+__global__ __launch_bounds__(256) void dog_scan_kernel(const float *__restrict__ base, StripGeom g,
+                                                       LaplaceTaps taps, float thresh, int octave,
+                                                       unsigned *__restrict__ counters,
+                                                       unsigned *__restrict__ cand, unsigned cand_cap, int aligned)
 {
   const ItemCoord it = decode_item(g);
   if (!it.valid) return;
   const int lane = threadIdx.x & 63;
-  // one extra halo quad on each side: blur halo (lanes 0,63) + DoG neighbour halo (lanes 1,62)
+  // lanes 0,63: blur halo; lanes 1,62: DoG column-neighbour halo; lanes 2..61 test their quads
   const int q = it.strip * (OUT_LANES - 2) + lane - 2;
   const float *img = base + (long long)it.frame * g.frame_stride;
   unsigned *cnt = counters + (size_t)it.frame * CNT_STRIDE;
@@ -279,56 +289,79 @@ __global__ __launch_bounds__(256) void dog_detect_kernel(const float *__restrict
   auto ld = [&](int y) -> float4 {
     return load_quad(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al);
   };
-  Row6 ra[NUM_DOG], rb[NUM_DOG], rc[NUM_DOG];
-  // DoG row yy needs raw rows yy-4 .. yy+4.  Produce DoG rows y0-1 and y0 first, then stream.
-  float4 r0, r1, r2, r3, r4, r5, r6, r7, r8;
-  auto dogrow = [&](Row6 (&dst)[NUM_DOG]) {
+  float4 r0 = ld(y0 - 4), r1 = ld(y0 - 3), r2 = ld(y0 - 2), r3 = ld(y0 - 1), r4 = ld(y0);
+  float4 r5 = ld(y0 + 1), r6 = ld(y0 + 2), r7 = ld(y0 + 3), r8 = ld(y0 + 4);
+  for (int y = y0; y < y1; y++) {
+    const float4 rnext = ld(y + 5);              // prefetch for the next row: its latency hides under this row's math
     const float4 p1 = add4(r3, r5), p2 = add4(r2, r6), p3 = add4(r1, r7), p4 = add4(r0, r8);
+    float4 d[NUM_DOG];
     float4 old = blur_quad(taps.k[0], r4, p1, p2, p3, p4);
 #pragma unroll
     for (int s = 1; s < NUM_BLURS; s++) {
       const float4 res = blur_quad(taps.k[s], r4, p1, p2, p3, p4);
-      dst[s - 1] = make_row6_edge(sub4(res, old), q, g.width);
+      d[s - 1] = sub4(res, old);
       old = res;
-    }
-  };
-  // Rows are clamped at the image border exactly like the oracle: DoG row -1 == DoG row 0
-  // because every raw row index is clamped before the vertical filter... which is NOT the
-  // same as clamping the DoG row index.  The reference clamps the DoG row index
-  // (cudaSiftD.cu:1332-1333), so rows outside the image reuse the clamped centre row.
-  const int ya = clampi(y0 - 1, 0, g.height - 1);
-  r0 = ld(ya - 4); r1 = ld(ya - 3); r2 = ld(ya - 2); r3 = ld(ya - 1); r4 = ld(ya);
-  r5 = ld(ya + 1); r6 = ld(ya + 2); r7 = ld(ya + 3); r8 = ld(ya + 4);
-  dogrow(ra);
-  if (ya != y0) {       // advance the raw window by one row
-    r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8; r8 = ld(y0 + 4);
-  }
-  dogrow(rb);
-  for (int y = y0; y < y1; y++) {
-    if (y + 1 <= g.height - 1) {
-      r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8; r8 = ld(y + 5);
-      dogrow(rc);
-    } else {
-#pragma unroll
-      for (int p = 0; p < NUM_DOG; p++) rc[p] = rb[p];   // DoG row index clamped to height-1
     }
     float amax = 0.0f;
 #pragma unroll
     for (int p = 1; p <= NUM_SCALES; p++)
-      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(rb[p].x), fabsf(rb[p].y)), fmaxf(fabsf(rb[p].z), fabsf(rb[p].w))));
-    if (__any(amax > thresh)) {
-      const unsigned mask = extrema_mask(ra, rb, rc, thresh);
-      if (tester && mask) push_candidates(mask, q, y, g.width, cnt, list, cand_cap, octave);
-    }
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(d[p].x), fabsf(d[p].y)), fmaxf(fabsf(d[p].z), fabsf(d[p].w))));
+    // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
+    if (y >= 1 && y <= g.height - 2 && __any(amax > thresh)) {
+      unsigned mask = 0;
 #pragma unroll
-    for (int p = 0; p < NUM_DOG; p++) { ra[p] = rb[p]; rb[p] = rc[p]; }
+      for (int s = 0; s < NUM_SCALES; s++) {
+        // in-row neighbourhood of centre plane s+1: planes s, s+1, s+2, columns x-1, x, x+1
+        float lo[4], hi[4];
+#pragma unroll
+        for (int dp = 0; dp < 3; dp += 2) {                    // planes below and above: full 3-column rows
+          const float4 e = d[s + dp];
+          const float v[6] = {lane_from_left(e.w), e.x, e.y, e.z, e.w, lane_from_right(e.x)};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float mn = min3f(v[i], v[i + 1], v[i + 2]), mx = max3f(v[i], v[i + 1], v[i + 2]);
+            lo[i] = dp == 0 ? mn : fminf(lo[i], mn);
+            hi[i] = dp == 0 ? mx : fmaxf(hi[i], mx);
+          }
+        }
+        const float4 c = d[s + 1];
+        const float v[6] = {lane_from_left(c.w), c.x, c.y, c.z, c.w, lane_from_right(c.x)};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float nmax = max3f(hi[i], v[i], v[i + 2]);
+          const float nmin = min3f(lo[i], v[i], v[i + 2]);
+          const float cv = v[i + 1];
+          const bool pre = (cv > thresh && cv > nmax) || (cv < -thresh && cv < nmin);
+          mask |= (pre ? 1u : 0u) << (5 * i + s);
+        }
+      }
+      // columns 0 and width-1 can never hold an extremum either
+      if (!tester) mask = 0;
+      if (4 * q == 0) mask &= ~31u;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (4 * q + i >= g.width - 1) mask &= ~(31u << (5 * i));
+      if (mask) {
+        const unsigned n = __popc(mask);
+        unsigned idx = atomicAdd(&cnt[CNT_CAND + octave], n);
+        while (mask) {
+          const int b = __ffs(mask) - 1;
+          mask &= mask - 1;
+          const unsigned code = (unsigned)(4 * q + b / 5) | ((unsigned)y << 14) | ((unsigned)(b % 5) << 28);
+          if (idx < cand_cap) list[idx] = code;
+          else atomicAdd(&cnt[CNT_CANDOVF], 1u);
+          idx++;
+        }
+      }
+    }
+    r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8; r8 = rnext;
   }
 }
 
 // ------------------------------------------------------------------- refine
 struct RefineParams {
   int width, height, pitch, nframes;
-  float edge_limit, factor, lowest_scale, subsampling;
+  float edge_limit, factor, lowest_scale, subsampling, thresh;
   float scmul[NUM_SCALES];     // powf(2, s/NUM_SCALES), computed on the host like the oracle
   int octave, max_pts;
   unsigned cand_cap;
@@ -421,8 +454,24 @@ __global__ __launch_bounds__(64) void refine_kernel(const float *__restrict__ sr
           for (int dx = 0; dx < 3; dx++)
             d[p][dy][dx] = img[(size_t)(s + p) * plane + (size_t)(y + dy - 1) * P.pitch + (x + dx - 1)];
     }
-    // cudaSiftD.cu:1383-1417, same expression order as oracle orc_findpoints()
     const float val = d[1][1][1];
+    {
+      // the reference's 26-neighbour strict-extremum test (cudaSiftD.cu:1337-1360); candidates are
+      // interior pixels, so the clamped neighbour addressing never applies here
+      float minv = INFINITY, maxv = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++)
+            if (!(p == 1 && dy == 1 && dx == 1)) {
+              minv = fminf(minv, d[p][dy][dx]);
+              maxv = fmaxf(maxv, d[p][dy][dx]);
+            }
+      if (!((val < fminf(-P.thresh, minv)) || (val > fmaxf(P.thresh, maxv)))) continue;
+    }
+    // cudaSiftD.cu:1383-1417, same expression order as oracle orc_findpoints()
     const float dxx = 2.0f * val - d[1][1][0] - d[1][1][2];
     const float dyy = 2.0f * val - d[1][0][1] - d[1][2][1];
     const float dxy = 0.25f * (d[1][2][2] + d[1][0][0] - d[1][0][2] - d[1][2][0]);
@@ -500,29 +549,30 @@ int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long lo
   return ls.finish();
 }
 
-int launch_dog_detect(misift_ctx *ctx, const float *base, const StripGeom &g, const LaplaceTaps &taps,
+int launch_dog_scan(misift_ctx *ctx, const float *base, const StripGeom &g, const LaplaceTaps &taps,
                       float thresh, int octave)
 {
   const int al = is_aligned16(base, g.pitch) && (g.frame_stride & 3) == 0;
-  LaunchScope ls(ctx, "dog_detect");
-  hipLaunchKernelGGL(dog_detect_kernel, grid_for(g), dim3(256), 0, ctx->stream, base, g, taps, thresh, octave,
+  LaunchScope ls(ctx, "dog_scan");
+  hipLaunchKernelGGL(dog_scan_kernel, grid_for(g), dim3(256), 0, ctx->stream, base, g, taps, thresh, octave,
                      ctx->d_counters, ctx->d_cand, (unsigned)ctx->cand_cap, al);
   return ls.finish();
 }
 
 int launch_refine(misift_ctx *ctx, const float *dog, long long dog_frame_stride, const float *base,
                   long long base_frame_stride, const LaplaceTaps *taps, int w, int h, int pitch, int nframes,
-                  float edge_limit, float factor, float lowest_scale, float subsampling, int octave,
+                  float thresh, float edge_limit, float factor, float lowest_scale, float subsampling, int octave,
                   SiftPointD *pts, int max_pts)
 {
   RefineParams P;
   P.width = w; P.height = h; P.pitch = pitch; P.nframes = nframes;
   P.edge_limit = edge_limit; P.factor = factor; P.lowest_scale = lowest_scale; P.subsampling = subsampling;
+  P.thresh = thresh;
   for (int s = 0; s < NUM_SCALES; s++) P.scmul[s] = powf(2.0f, (float)s / NUM_SCALES);
   P.octave = octave; P.max_pts = max_pts; P.cand_cap = (unsigned)ctx->cand_cap;
   LaplaceTaps t;
   if (taps) t = *taps; else memset(&t, 0, sizeof(t));
-  const dim3 grid(64, nframes);
+  const dim3 grid(128, nframes);
   LaunchScope ls(ctx, "refine");
   if (dog)
     hipLaunchKernelGGL(refine_kernel<false>, grid, dim3(64), 0, ctx->stream, dog, dog_frame_stride, t, P,

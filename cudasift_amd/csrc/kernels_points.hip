@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ b
 {
   __shared__ float s_hist[WAVES_PER_BLOCK][64];
   __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  __shared__ float2 s_smp[WAVES_PER_BLOCK][128];     // (bin, weight) of the 121 samples
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.y;
   const float *img = base + (long long)frame * base_frame_stride;
@@ -45,17 +46,18 @@ __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ b
   SiftPointD *sift = pts + (size_t)frame * max_pts;
   float *hist = s_hist[wave];
   float *gauss = s_gauss[wave];
+  float2 *smp = s_smp[wave];
   const bool q8 = frac8 != 0;
 
   const int fstPts = (int)min(cnt[2 * octave - 1], (unsigned)max_pts);
   const int totPts = (int)min(cnt[2 * octave + 0], (unsigned)max_pts);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&cnt[2 * octave + 1], cnt[2 * octave + 0]);
+  if (lane >= 57) smp[64 + lane] = make_float2(-1.0f, 0.0f);     // slots 121..127 never match a bin
 
   for (int bx = fstPts + blockIdx.x * WAVES_PER_BLOCK + wave; bx < totPts; bx += gridDim.x * WAVES_PER_BLOCK) {
     const float scale = sift[bx].scale;
     const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
     if (lane < 11) gauss[lane] = expf(i2sigma2 * (lane - 5) * (lane - 5));
-    hist[lane] = 0.0f;
     wave_sync();
     const float xp = sift[bx].xpos - 4.5f;
     const float yp = sift[bx].ypos - 4.5f;
@@ -72,8 +74,22 @@ __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ b
         int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
         if (bin > 31) bin = 0;
         const float grad = sqrtf(dx * dx + dy * dy);
-        atomicAdd(&hist[bin], grad * gauss[xd] * gauss[yd]);
+        smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
       }
+    }
+    wave_sync();
+    // privatized histogram (no LDS atomics): lane (b, half) sums the samples of its half that fall in bin b
+    {
+      const float fb = (float)(lane & 31);
+      const float2 *sp = smp + (lane >> 5) * 64;
+      float acc = 0.0f;
+#pragma unroll 16
+      for (int j = 0; j < 64; j++) {
+        const float2 e = sp[j];
+        acc += (e.x == fb) ? e.y : 0.0f;
+      }
+      acc += __shfl_xor(acc, 32, 64);
+      if (lane < 32) hist[lane] = acc;
     }
     wave_sync();
     const int t = lane & 31;
@@ -144,9 +160,16 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
   return r;
 }
 
-__device__ __forceinline__ void vote(float *buffer, int idx, float val)
+// Descriptor accumulation without LDS atomics.  Phase 1: every lane evaluates 4 of the 256 rotated
+// samples and stores (iangf*grad, angf*grad, angi) into a 20x20 zero-bordered table in LDS.  Phase 2
+// is output-centric: lane = (cell c = lane>>2, angle bins a and a+4); the 8x8 samples whose trilinear
+// footprint reaches cell c are read back (fully unrolled, immediate LDS offsets, border slots read
+// as zero) and accumulated in two registers.  Same votes as cudaSiftD.cu:346-386, summed in a
+// different order (the reference's shared-memory atomics have no defined order either).
+#define SMP_W 20
+__device__ __forceinline__ float spatial_w(int m)      // horf/verf for m<4, 1-horf/1-verf for m>=4
 {
-  if (idx >= 0 && idx < 128) atomicAdd(&buffer[idx], val);
+  return m < 4 ? (m + 0.5f) * 0.25f : (7.5f - m) * 0.25f;
 }
 
 __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ base, long long base_frame_stride,
@@ -154,23 +177,30 @@ __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ ba
                                                     const unsigned *__restrict__ counters,
                                                     SiftPointD *__restrict__ pts, int max_pts, int frac8)
 {
-  __shared__ float s_buf[WAVES_PER_BLOCK][128];
+  __shared__ float4 s_smp[WAVES_PER_BLOCK][SMP_W * SMP_W];
   __shared__ float s_gauss[WAVES_PER_BLOCK][16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.y;
   const float *img = base + (long long)frame * base_frame_stride;
   const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   SiftPointD *sift = pts + (size_t)frame * max_pts;
-  float *buffer = s_buf[wave];
+  float4 *smp = s_smp[wave];
   float *gauss = s_gauss[wave];
   const bool q8 = frac8 != 0;
   if (lane < 16) gauss[lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
+  for (int i = lane; i < SMP_W * SMP_W; i += 64) smp[i] = make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // border stays zero
+
+  // this lane's output bins
+  const int cell = lane >> 2, cx = cell & 3, cy = cell >> 2;
+  const float a0 = (float)(lane & 3), a1 = a0 + 4.0f;
+  const float am0 = (lane & 3) == 0 ? 7.0f : a0 - 1.0f;      // angi whose angp lands on a0 (7 and 8 both wrap to 0)
+  const float am1 = a1 - 1.0f;
+  const bool a0_is0 = (lane & 3) == 0;
+  const float4 *cellbase = smp + (4 * cy) * SMP_W + 4 * cx;   // table slot of sample (tx,y) is (y+2)*20 + tx+2
 
   const int fstPts = (int)min(cnt[2 * octave - 1], (unsigned)max_pts);
   const int totPts = (int)min(cnt[2 * octave + 1], (unsigned)max_pts);
   for (int bx = fstPts + blockIdx.x * WAVES_PER_BLOCK + wave; bx < totPts; bx += gridDim.x * WAVES_PER_BLOCK) {
-    buffer[lane] = 0.0f;
-    buffer[lane + 64] = 0.0f;
     wave_sync();
     const float px = sift[bx].xpos, py = sift[bx].ypos, pscale = sift[bx].scale;
     const float theta = 2.0f * 3.1415f / 360.0f * sift[bx].orientation;
@@ -179,6 +209,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ ba
     const float scale = 12.0f / 16.0f * pscale;
     const float ssina = scale * sina;
     const float scosa = scale * cosa;
+    bool has8 = false;
 #pragma unroll
     for (int rep = 0; rep < 4; rep++) {
       const int id = lane + 64 * rep;
@@ -191,64 +222,53 @@ __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ ba
                        tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q8);
       const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
       float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
-
-      const int hori = (tx + 2) / 4 - 1;
-      const float horf = (tx - 1.5f) / 4.0f - hori;
-      const float ihorf = 1.0f - horf;
-      const int veri = (y + 2) / 4 - 1;
-      const float verf = (y - 1.5f) / 4.0f - veri;
-      const float iverf = 1.0f - verf;
       const int angi = (int)angf;
-      const int angp = (angi < 7 ? angi + 1 : 0);
       angf -= angi;
       const float iangf = 1.0f - angf;
-
-      const int hist = 8 * (4 * veri + hori);
-      const int p1 = angi + hist;
-      const int p2 = angp + hist;
-      if (tx >= 2) {
-        const float grad1 = ihorf * grad;
-        if (y >= 2) {
-          const float grad2 = iverf * grad1;
-          vote(buffer, p1, iangf * grad2);
-          vote(buffer, p2, angf * grad2);
-        }
-        if (y <= 13) {
-          const float grad2 = verf * grad1;
-          vote(buffer, p1 + 32, iangf * grad2);
-          vote(buffer, p2 + 32, angf * grad2);
-        }
-      }
-      if (tx <= 13) {
-        const float grad1 = horf * grad;
-        if (y >= 2) {
-          const float grad2 = iverf * grad1;
-          vote(buffer, p1 + 8, iangf * grad2);
-          vote(buffer, p2 + 8, angf * grad2);
-        }
-        if (y <= 13) {
-          const float grad2 = verf * grad1;
-          vote(buffer, p1 + 40, iangf * grad2);
-          vote(buffer, p2 + 40, angf * grad2);
-        }
-      }
+      has8 |= angi >= 8;
+      smp[(y + 2) * SMP_W + tx + 2] = make_float4(iangf * grad, angf * grad, (float)angi, 0.0f);
     }
     wave_sync();
+    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 2
+    for (int my = 0; my < 8; my++) {
+      const float wy = spatial_w(my);
+#pragma unroll
+      for (int mx = 0; mx < 8; mx++) {
+        const float4 e = cellbase[my * SMP_W + mx];
+        const float wgt = wy * spatial_w(mx);
+        const float t0 = (e.z == a0) ? e.x : ((e.z == am0 || (a0_is0 && e.z == 8.0f)) ? e.y : 0.0f);
+        const float t1 = (e.z == a1) ? e.x : ((e.z == am1) ? e.y : 0.0f);
+        acc0 = __builtin_fmaf(wgt, t0, acc0);
+        acc1 = __builtin_fmaf(wgt, t1, acc1);
+      }
+    }
+    if (__any(has8)) {
+      // rare (dy == +0 and dx < 0): angi == 8 makes the iangf vote land in
+      // bin 0 of the NEXT cell of the flattened 4x4 grid; cell 16 does not exist (dropped)
+      if (a0_is0 && cell >= 1) {
+        const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
+        const float4 *pb = smp + (4 * pcy) * SMP_W + 4 * pcx;
+        for (int my = 0; my < 8; my++)
+          for (int mx = 0; mx < 8; mx++) {
+            const float4 e = pb[my * SMP_W + mx];
+            if (e.z == 8.0f) acc0 = __builtin_fmaf(spatial_w(my) * spatial_w(mx), e.x, acc0);
+          }
+      }
+    }
     // normalise, clamp at 0.2, normalise again (reference cudaSiftD.cu:390-409)
-    const float b0 = buffer[lane], b1 = buffer[lane + 64];
-    const float tsum1 = wave_sum(b0 * b0 + b1 * b1);
+    const float tsum1 = wave_sum(acc0 * acc0 + acc1 * acc1);
     const float rs1 = 1.0f / sqrtf(tsum1);
-    const float c0 = fminf(b0 * rs1, 0.2f), c1 = fminf(b1 * rs1, 0.2f);
+    const float c0 = fminf(acc0 * rs1, 0.2f), c1 = fminf(acc1 * rs1, 0.2f);
     const float tsum2 = wave_sum(c0 * c0 + c1 * c1);
     const float rs2 = 1.0f / sqrtf(tsum2);
-    sift[bx].data[lane] = c0 * rs2;
-    sift[bx].data[lane + 64] = c1 * rs2;
+    sift[bx].data[8 * cell + (lane & 3)] = c0 * rs2;
+    sift[bx].data[8 * cell + (lane & 3) + 4] = c1 * rs2;
     if (lane == 0) {
       sift[bx].xpos = px * subsampling;
       sift[bx].ypos = py * subsampling;
       sift[bx].scale = pscale * subsampling;
     }
-    wave_sync();
   }
 }
 

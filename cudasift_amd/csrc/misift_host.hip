@@ -497,7 +497,11 @@ static int extract_impl(misift_ctx *ctx, const float *d_imgs, int nframes, long 
   ARG_CHECK(width * (scale_up ? 2 : 1) < 16384 && height * (scale_up ? 2 : 1) < 16384);
   ARG_CHECK(!scale_up || nframes == 1);
   HIP_TRY(hipSetDevice(ctx->device));
-  int rc = misift_ensure_frames(ctx, nframes, 2 * (size_t)max_pts);
+  // candidate list: pre-candidates of the fused scan (or true extrema of the unfused detect) of ONE
+  // octave; sized from the image, not from max_pts (overflow is detected and handled by the callers)
+  size_t cap = (size_t)width * height * (scale_up ? 4 : 1) / 4;
+  if (cap < 65536) cap = 65536;
+  int rc = misift_ensure_frames(ctx, nframes, cap);
   if (rc) return rc;
   const size_t S = misift_scratch_floats(width, height, num_octaves, scale_up);
   if (!d_scratch) {
@@ -565,9 +569,9 @@ static int extract_impl(misift_ctx *ctx, const float *d_imgs, int nframes, long 
     const LaplaceTaps taps = octave_taps(table, o);
     if (ctx->opt.fused) {
       StripGeom g = make_geom(ctx, L.w, L.h, L.p, nframes, SS, L.w, L.h, 60);
-      rc = launch_dog_detect(ctx, L.img, g, taps, thresh, o);
+      rc = launch_dog_scan(ctx, L.img, g, taps, thresh, o);
       if (rc) return rc;
-      rc = launch_refine(ctx, nullptr, 0, L.img, SS, &taps, L.w, L.h, L.p, nframes, 10.0f, 1.0f / NUM_SCALES,
+      rc = launch_refine(ctx, nullptr, 0, L.img, SS, &taps, L.w, L.h, L.p, nframes, thresh, 10.0f, 1.0f / NUM_SCALES,
                          lowest_scale / subsampling, subsampling, o, pts, max_pts);
       if (rc) return rc;
     } else {
@@ -576,7 +580,7 @@ static int extract_impl(misift_ctx *ctx, const float *d_imgs, int nframes, long 
       if (rc) return rc;
       rc = launch_detect(ctx, memoryTmp, g, SS, thresh, o);
       if (rc) return rc;
-      rc = launch_refine(ctx, memoryTmp, SS, nullptr, 0, nullptr, L.w, L.h, L.p, nframes, 10.0f,
+      rc = launch_refine(ctx, memoryTmp, SS, nullptr, 0, nullptr, L.w, L.h, L.p, nframes, thresh, 10.0f,
                          1.0f / NUM_SCALES, lowest_scale / subsampling, subsampling, o, pts, max_pts);
       if (rc) return rc;
     }
@@ -588,7 +592,8 @@ static int extract_impl(misift_ctx *ctx, const float *d_imgs, int nframes, long 
   return MISIFT_OK;
 }
 
-static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *num_pts_out)
+static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *num_pts_out,
+                       bool *cand_overflow)
 {
   HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes,
                          hipMemcpyDeviceToHost, ctx->stream));
@@ -597,7 +602,37 @@ static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pt
   for (int f = 0; f < nframes; f++) {
     const unsigned c = ctx->h_counters[(size_t)f * CNT_STRIDE + slot];
     num_pts_out[f] = (int)(c < (unsigned)max_pts ? c : (unsigned)max_pts);     // cudaSiftH.cu:116
+    if (ctx->h_counters[(size_t)f * CNT_STRIDE + CNT_CANDOVF]) *cand_overflow = true;
   }
+  return MISIFT_OK;
+}
+
+// Run the launch sequence and read the counts back.  If a candidate list overflowed in the fused
+// path (possible only for extreme thresh/contrast), redo the batch with the dense unfused kernels,
+// whose list holds true 3x3x3 extrema only; an overflow there is reported as an error, never dropped
+// silently (the reference silently caps at 32 candidates per 30x8 tile, cudaSiftD.cu:1371).
+static int extract_sync(misift_ctx *ctx, const float *d_imgs, int nframes, long long frame_stride, int width,
+                        int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
+                        int scale_up, float *d_scratch, SiftPointD *pts, int max_pts, int *num_pts_out)
+{
+  const int fused_saved = ctx->opt.fused;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    int rc = extract_impl(ctx, d_imgs, nframes, frame_stride, width, height, pitch, num_octaves, init_blur, thresh,
+                          lowest_scale, scale_up, d_scratch, pts, max_pts);
+    bool ovf = false;
+    if (!rc) rc = read_counts(ctx, nframes, num_octaves, max_pts, num_pts_out, &ovf);
+    if (rc) { ctx->opt.fused = fused_saved; return rc; }
+    if (!ovf) break;
+    if (ctx->opt.fused && attempt == 0) {
+      ctx->opt.fused = 0;
+      continue;
+    }
+    ctx->opt.fused = fused_saved;
+    misift_set_error("candidate list overflow: more than %zu scale-space extrema in one octave of one frame "
+                     "(raise thresh)", ctx->cand_cap);
+    return MISIFT_ENOMEM;
+  }
+  ctx->opt.fused = fused_saved;
   return MISIFT_OK;
 }
 
@@ -606,10 +641,8 @@ extern "C" int misift_extract(misift_ctx *ctx, const float *d_img, int width, in
                               void *d_pts, int max_pts, int *num_pts_out)
 {
   ARG_CHECK(num_pts_out != nullptr);
-  int rc = extract_impl(ctx, d_img, 1, 0, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
-                        scale_up, d_scratch, (SiftPointD *)d_pts, max_pts);
-  if (rc) return rc;
-  rc = read_counts(ctx, 1, num_octaves, max_pts, num_pts_out);
+  int rc = extract_sync(ctx, d_img, 1, 0, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
+                        scale_up, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
   if (scale_up) {                                    // cudaSiftH.cu:130
     rc = launch_rescale(ctx, (SiftPointD *)d_pts, *num_pts_out, 0.5f);
@@ -624,10 +657,8 @@ extern "C" int misift_extract_batch(misift_ctx *ctx, const float *d_imgs, int nf
                                     int *num_pts_out)
 {
   ARG_CHECK(num_pts_out != nullptr);
-  int rc = extract_impl(ctx, d_imgs, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
-                        init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts);
-  if (rc) return rc;
-  rc = read_counts(ctx, nframes, num_octaves, max_pts, num_pts_out);
+  int rc = extract_sync(ctx, d_imgs, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
+                        init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
   return resolve_profile(ctx);
 }
@@ -738,12 +769,14 @@ extern "C" int misift_findpoints(misift_ctx *ctx, const float *d_dog, int width,
 {
   ARG_CHECK(ctx && d_dog && d_pts && width >= 16 && height >= 16 && pitch >= width && width < 16384 && height < 16384);
   ARG_CHECK(octave >= 1 && octave <= MISIFT_MAX_OCTAVES && max_pts >= 1);
-  int rc = misift_ensure_frames(ctx, 1, 2 * (size_t)max_pts);
+  size_t cap = (size_t)width * height / 4;
+  if (cap < 65536) cap = 65536;
+  int rc = misift_ensure_frames(ctx, 1, cap);
   if (rc) return rc;
   StripGeom g = make_geom(ctx, width, height, pitch, 1, 0, width, height, 62);
   rc = launch_detect(ctx, d_dog, g, 0, thresh, octave);
   if (rc) return rc;
-  rc = launch_refine(ctx, d_dog, 0, nullptr, 0, nullptr, width, height, pitch, 1, edge_limit, 1.0f / NUM_SCALES,
+  rc = launch_refine(ctx, d_dog, 0, nullptr, 0, nullptr, width, height, pitch, 1, thresh, edge_limit, 1.0f / NUM_SCALES,
                      lowest_scale, subsampling, octave, (SiftPointD *)d_pts, max_pts);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -756,15 +789,17 @@ extern "C" int misift_dog_findpoints(misift_ctx *ctx, const float *d_base, int w
 {
   ARG_CHECK(ctx && d_base && d_pts && width >= 16 && height >= 16 && pitch >= width && width < 16384 && height < 16384);
   ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES && octave >= 1 && octave <= num_octaves);
-  int rc = misift_ensure_frames(ctx, 1, 2 * (size_t)max_pts);
+  size_t cap = (size_t)width * height / 4;
+  if (cap < 65536) cap = 65536;
+  int rc = misift_ensure_frames(ctx, 1, cap);
   if (rc) return rc;
   float table[8 * 12 * 16];
   misift_laplace_taps(num_octaves, table);
   const LaplaceTaps taps = octave_taps(table, octave);
   StripGeom g = make_geom(ctx, width, height, pitch, 1, 0, width, height, 60);
-  rc = launch_dog_detect(ctx, d_base, g, taps, thresh, octave);
+  rc = launch_dog_scan(ctx, d_base, g, taps, thresh, octave);
   if (rc) return rc;
-  rc = launch_refine(ctx, nullptr, 0, d_base, 0, &taps, width, height, pitch, 1, edge_limit, 1.0f / NUM_SCALES,
+  rc = launch_refine(ctx, nullptr, 0, d_base, 0, &taps, width, height, pitch, 1, thresh, edge_limit, 1.0f / NUM_SCALES,
                      lowest_scale, subsampling, octave, (SiftPointD *)d_pts, max_pts);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
