@@ -101,6 +101,35 @@ __device__ __forceinline__ float4 load_quad(const float *row, int q, int width, 
                      row[clampi(x + 3, 0, w1)]);
 }
 
+// Fast-path column addressing for images whose width is a multiple of 4 and whose rows are 16-byte
+// aligned (every pyramid level of the standard sizes): the lane's quad index is clamped once, every
+// row is ONE unconditional dwordx4 load, and the clamp-to-edge semantics for the halo quads left /
+// right of the image are restored with selects (splat of column 0 / column width-1) — no divergent
+// branches in the streaming loops.
+struct QuadCol {
+  int off;      // float offset of the clamped quad within a row
+  int edge;     // -1: quad lies left of the image, +1: right of it, 0: inside
+};
+__device__ __forceinline__ QuadCol make_quadcol(int q, int width)
+{
+  const int nq = width >> 2;
+  QuadCol c;
+  c.edge = q < 0 ? -1 : (q > nq - 1 ? 1 : 0);
+  c.off = 4 * clampi(q, 0, nq - 1);
+  return c;
+}
+template <bool FAST>
+__device__ __forceinline__ float4 load_quad_t(const float *row, int q, int width, bool aligned, const QuadCol &c)
+{
+  if (FAST) {
+    float4 v = *reinterpret_cast<const float4 *>(row + c.off);
+    if (c.edge < 0) v = make_float4(v.x, v.x, v.x, v.x);
+    if (c.edge > 0) v = make_float4(v.w, v.w, v.w, v.w);
+    return v;
+  }
+  return load_quad(row, q, width, aligned);
+}
+
 // tex2D<float>() of a pitch2D texture with clamp addressing and linear filtering
 // (cudaSiftH.cu:196-205).  frac8: round the weights to 8 fractional bits like the
 // CUDA texture unit.  Same operation sequence as oracle tex2d().

@@ -18,6 +18,7 @@
 // Compiled with -ffp-contract=off: every multiply-add below that is meant to be
 // fused is an explicit __builtin_fmaf, exactly as in oracle/sift_oracle.c.
 #include <stdlib.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include "common.hpp"
@@ -30,7 +31,11 @@ struct ItemCoord { int frame, strip, seg; bool valid; };
 __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
 {
   const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
-  const long long item = (long long)lb * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  // the wave index is wave-uniform: keep it (and everything derived from it — frame, strip, segment,
+  // row bounds, row pointers) in SGPRs.  Besides cheaper scalar loop control this keeps the loop bounds
+  // out of reach of VGPR live-range splitting around divergent regions.
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long item = (long long)lb * WAVES_PER_BLOCK + wave;
   const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
   ItemCoord c;
   c.valid = item < nitems;
@@ -77,11 +82,64 @@ __device__ __forceinline__ float4 blur_quad(const float *k, float4 c, float4 p1,
   return h;
 }
 
+// Packed-math variant of blur_quad with the taps read from LDS as {k,k} pairs (one ds_read_b64 feeds
+// v_pk_fma_f32 operands).  Keeping the 40 taps out of the scalar register file matters for
+// dog_scan_kernel: with the taps as SGPR pairs (80 SGPRs) the detection code runs out of scalar
+// registers and the compiler spills them through v_readlane/v_writelane inside the row loop.  Same
+// fmaf chains (__builtin_elementwise_fma is llvm.fma — one rounding), hence the same bits as blur_quad().
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Quad2 { v2f lo, hi; };                 // pixels (x,y) and (z,w) of a quad
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+
+__device__ __forceinline__ void fill_lds_taps(v2f *s_taps, const LaplaceTaps &taps)
+{
+  for (int i = threadIdx.x; i < NUM_BLURS * 5; i += blockDim.x) {
+    const float k = taps.k[i / 5][i % 5];
+    s_taps[i] = mk2(k, k);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ Quad2 blur_quad2(const v2f *tk, Quad2 c, Quad2 p1, Quad2 p2, Quad2 p3, Quad2 p4)
+{
+  const v2f k0 = tk[0], k1 = tk[1], k2 = tk[2], k3 = tk[3], k4 = tk[4];
+  v2f a = k0 * c.lo, b = k0 * c.hi;           // vertical pass: (x,y) and (z,w)
+  a = pk_fma(k1, p1.lo, a); b = pk_fma(k1, p1.hi, b);
+  a = pk_fma(k2, p2.lo, a); b = pk_fma(k2, p2.hi, b);
+  a = pk_fma(k3, p3.lo, a); b = pk_fma(k3, p3.hi, b);
+  a = pk_fma(k4, p4.lo, a); b = pk_fma(k4, p4.hi, b);
+  const float vx = a.x, vy = a.y, vz = b.x, vw = b.y;
+  const float lx = lane_from_left(vx), ly = lane_from_left(vy), lz = lane_from_left(vz), lw = lane_from_left(vw);
+  const float rx = lane_from_right(vx), ry = lane_from_right(vy), rz = lane_from_right(vz), rw = lane_from_right(vw);
+  // horizontal pass; pair sums (value at -j) + (value at +j) for the four pixels
+  v2f h0 = k0 * a, h1 = k0 * b;
+  h0 = pk_fma(k1, mk2(lw, vx) + mk2(vy, vz), h0); h1 = pk_fma(k1, mk2(vy, vz) + mk2(vw, rx), h1);
+  h0 = pk_fma(k2, mk2(lz, lw) + mk2(vz, vw), h0); h1 = pk_fma(k2, mk2(vx, vy) + mk2(rx, ry), h1);
+  h0 = pk_fma(k3, mk2(ly, lz) + mk2(vw, rx), h0); h1 = pk_fma(k3, mk2(lw, vx) + mk2(ry, rz), h1);
+  h0 = pk_fma(k4, mk2(lx, ly) + mk2(rx, ry), h0); h1 = pk_fma(k4, mk2(lz, lw) + mk2(rz, rw), h1);
+  Quad2 o;
+  o.lo = h0; o.hi = h1;
+  return o;
+}
+__device__ __forceinline__ Quad2 q2(float4 v) { Quad2 r; r.lo = mk2(v.x, v.y); r.hi = mk2(v.z, v.w); return r; }
+__device__ __forceinline__ Quad2 add_q2(Quad2 a, Quad2 b) { Quad2 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; }
+__device__ __forceinline__ float4 sub_q2(Quad2 a, Quad2 b)
+{
+  const v2f l = a.lo - b.lo, h = a.hi - b.hi;
+  return make_float4(l.x, l.y, h.x, h.y);
+}
+
 // ------------------------------------------------------------------ Laplace
+template <bool FAST>
 __global__ __launch_bounds__(256) void laplace_kernel(const float *__restrict__ base, StripGeom g,
                                                       float *__restrict__ dog, long long dog_frame_stride,
                                                       LaplaceTaps taps, int aligned)
 {
+  __shared__ v2f s_taps[NUM_BLURS * 5];
+  fill_lds_taps(s_taps, taps);
+  const v2f *tk = s_taps;
   const ItemCoord it = decode_item(g);
   if (!it.valid) return;
   const int lane = threadIdx.x & 63;
@@ -92,23 +150,29 @@ __global__ __launch_bounds__(256) void laplace_kernel(const float *__restrict__ 
   const int y0 = it.seg * g.seg_rows;
   const int y1 = min(y0 + g.seg_rows, g.height);
   const bool al = aligned != 0;
+  const QuadCol qc = make_quadcol(q, g.width);
   auto ld = [&](int y) -> float4 {
-    return load_quad(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al);
+    return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
   };
   float4 r0 = ld(y0 - 4), r1 = ld(y0 - 3), r2 = ld(y0 - 2), r3 = ld(y0 - 1), r4 = ld(y0);
-  float4 r5 = ld(y0 + 1), r6 = ld(y0 + 2), r7 = ld(y0 + 3), r8;
+  float4 r5 = ld(y0 + 1), r6 = ld(y0 + 2), r7 = ld(y0 + 3), r8 = ld(y0 + 4);
   const bool writer = lane >= 1 && lane <= OUT_LANES && 4 * q < g.width;
   for (int y = y0; y < y1; y++) {
-    r8 = ld(y + 4);
-    const float4 p1 = add4(r3, r5), p2 = add4(r2, r6), p3 = add4(r1, r7), p4 = add4(r0, r8);
-    float4 old = blur_quad(taps.k[0], r4, p1, p2, p3, p4);
+    const float4 rnext = ld(y + 5);              // prefetch: latency hides under this row's math
+    const Quad2 c = q2(r4), p1 = add_q2(q2(r3), q2(r5)), p2 = add_q2(q2(r2), q2(r6)), p3 = add_q2(q2(r1), q2(r7)),
+                p4 = add_q2(q2(r0), q2(r8));
+    Quad2 old = blur_quad2(tk, c, p1, p2, p3, p4);
 #pragma unroll
     for (int s = 1; s < NUM_BLURS; s++) {
-      const float4 res = blur_quad(taps.k[s], r4, p1, p2, p3, p4);
-      if (writer) store_quad(out + (size_t)(s - 1) * plane + (size_t)y * g.pitch, q, g.width, al, sub4(res, old));
+      const Quad2 res = blur_quad2(tk + 5 * s, c, p1, p2, p3, p4);
+      float *dst = out + (size_t)(s - 1) * plane + (size_t)y * g.pitch;
+      if (writer) {
+        if (FAST) *reinterpret_cast<float4 *>(dst + 4 * q) = sub_q2(res, old);
+        else store_quad(dst, q, g.width, al, sub_q2(res, old));
+      }
       old = res;
     }
-    r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8;
+    r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8; r8 = rnext;
   }
 }
 
@@ -269,11 +333,14 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
 // applies the reference's full 26-neighbour test (cudaSiftD.cu:1337-1360) before refining.
 // Keeping only the current DoG row in registers (no 3-row window, no box minima) leaves the
 // kernel at ~1/2 the registers and ~1/3 the instructions of a full in-register 3x3x3 test.
-__global__ __launch_bounds__(256) void dog_scan_kernel(const float *__restrict__ base, StripGeom g,
+template <bool FAST, int OCC>
+__global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restrict__ base, StripGeom g,
                                                        LaplaceTaps taps, float thresh, int octave,
                                                        unsigned *__restrict__ counters,
                                                        unsigned *__restrict__ cand, unsigned cand_cap, int aligned)
 {
+  __shared__ v2f s_taps[NUM_BLURS * 5];
+  fill_lds_taps(s_taps, taps);
   const ItemCoord it = decode_item(g);
   if (!it.valid) return;
   const int lane = threadIdx.x & 63;
@@ -286,20 +353,27 @@ __global__ __launch_bounds__(256) void dog_scan_kernel(const float *__restrict__
   const int y1 = min(y0 + g.seg_rows, g.height);
   const bool al = aligned != 0;
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
+  const QuadCol qc = make_quadcol(q, g.width);
+  const v2f *tk = s_taps;
   auto ld = [&](int y) -> float4 {
-    return load_quad(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al);
+    return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
   };
   float4 r0 = ld(y0 - 4), r1 = ld(y0 - 3), r2 = ld(y0 - 2), r3 = ld(y0 - 1), r4 = ld(y0);
   float4 r5 = ld(y0 + 1), r6 = ld(y0 + 2), r7 = ld(y0 + 3), r8 = ld(y0 + 4);
   for (int y = y0; y < y1; y++) {
     const float4 rnext = ld(y + 5);              // prefetch for the next row: its latency hides under this row's math
-    const float4 p1 = add4(r3, r5), p2 = add4(r2, r6), p3 = add4(r1, r7), p4 = add4(r0, r8);
+    // re-read the taps from LDS every row instead of pinning 80 VGPRs across the loop
+    asm volatile("" ::: "memory");
+    const Quad2 c = q2(r4), p1 = add_q2(q2(r3), q2(r5)), p2 = add_q2(q2(r2), q2(r6)), p3 = add_q2(q2(r1), q2(r7)),
+                p4 = add_q2(q2(r0), q2(r8));
     float4 d[NUM_DOG];
-    float4 old = blur_quad(taps.k[0], r4, p1, p2, p3, p4);
+    Quad2 old = blur_quad2(tk, c, p1, p2, p3, p4);
 #pragma unroll
     for (int s = 1; s < NUM_BLURS; s++) {
-      const float4 res = blur_quad(taps.k[s], r4, p1, p2, p3, p4);
-      d[s - 1] = sub4(res, old);
+      asm volatile("" ::: "memory");            // keep each scale's 5 tap pairs a short-lived LDS read
+      __builtin_amdgcn_sched_barrier(0);        // and stop the scheduler from interleaving all 8 scales
+      const Quad2 res = blur_quad2(tk + 5 * s, c, p1, p2, p3, p4);
+      d[s - 1] = sub_q2(res, old);
       old = res;
     }
     float amax = 0.0f;
@@ -534,8 +608,12 @@ int launch_laplace(misift_ctx *ctx, const float *base, const StripGeom &g, float
   const int al = is_aligned16(base, g.pitch) && is_aligned16(dog, g.pitch) && (g.frame_stride & 3) == 0 &&
                  (dog_frame_stride & 3) == 0;
   LaunchScope ls(ctx, "laplace");
-  hipLaunchKernelGGL(laplace_kernel, grid_for(g), dim3(256), 0, ctx->stream, base, g, dog, dog_frame_stride,
-                     taps, al);
+  if (al && (g.width & 3) == 0)
+    hipLaunchKernelGGL(laplace_kernel<true>, grid_for(g), dim3(256), 0, ctx->stream, base, g, dog, dog_frame_stride,
+                       taps, al);
+  else
+    hipLaunchKernelGGL(laplace_kernel<false>, grid_for(g), dim3(256), 0, ctx->stream, base, g, dog,
+                       dog_frame_stride, taps, al);
   return ls.finish();
 }
 
@@ -552,10 +630,15 @@ int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long lo
 int launch_dog_scan(misift_ctx *ctx, const float *base, const StripGeom &g, const LaplaceTaps &taps,
                       float thresh, int octave)
 {
-  const int al = is_aligned16(base, g.pitch) && (g.frame_stride & 3) == 0;
+  const int al0 = is_aligned16(base, g.pitch) && (g.frame_stride & 3) == 0;
   LaunchScope ls(ctx, "dog_scan");
-  hipLaunchKernelGGL(dog_scan_kernel, grid_for(g), dim3(256), 0, ctx->stream, base, g, taps, thresh, octave,
-                     ctx->d_counters, ctx->d_cand, (unsigned)ctx->cand_cap, al);
+  // <FAST, 2>: two wavefronts per SIMD (<= 256 VGPRs) measured 1.29x faster than one
+  if (al0 && (g.width & 3) == 0)
+    hipLaunchKernelGGL((dog_scan_kernel<true, 2>), grid_for(g), dim3(256), 0, ctx->stream, base, g, taps, thresh,
+                       octave, ctx->d_counters, ctx->d_cand, (unsigned)ctx->cand_cap, al0);
+  else
+    hipLaunchKernelGGL((dog_scan_kernel<false, 2>), grid_for(g), dim3(256), 0, ctx->stream, base, g, taps, thresh,
+                       octave, ctx->d_counters, ctx->d_cand, (unsigned)ctx->cand_cap, al0);
   return ls.finish();
 }
 

@@ -24,7 +24,11 @@ struct ItemCoord { int frame, strip, seg; bool valid; };
 __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
 {
   const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
-  const long long item = (long long)lb * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  // the wave index is wave-uniform: keep it (and everything derived from it — frame, strip, segment,
+  // row bounds, row pointers) in SGPRs.  Besides cheaper scalar loop control this keeps the loop bounds
+  // out of reach of VGPR live-range splitting around divergent regions.
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long item = (long long)lb * WAVES_PER_BLOCK + wave;
   const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
   ItemCoord c;
   c.valid = item < nitems;
@@ -50,6 +54,7 @@ __device__ __forceinline__ void store_quad(float *row, int q, int width, bool al
 
 // ------------------------------------------------------------------ LowPass
 // out = G9^T (vertical) applied to G9 (horizontal) applied to in, clamp-to-edge.
+template <bool FAST>
 __global__ __launch_bounds__(256) void lowpass_kernel(const float *__restrict__ src, StripGeom g,
                                                       float *__restrict__ dst, int dpitch,
                                                       long long dst_frame_stride, Taps5 t, int src_aligned,
@@ -65,10 +70,12 @@ __global__ __launch_bounds__(256) void lowpass_kernel(const float *__restrict__ 
   const int y1 = min(y0 + g.seg_rows, g.height);
   const float k0 = t.k[0], k1 = t.k[1], k2 = t.k[2], k3 = t.k[3], k4 = t.k[4];
   const bool sal = src_aligned != 0, dal = dst_aligned != 0;
+  const QuadCol qc = make_quadcol(q, g.width);
+  auto ldraw = [&](int y) -> float4 {
+    return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, sal, qc);
+  };
 
-  auto hrow = [&](int y) -> float4 {
-    const int yc = clampi(y, 0, g.height - 1);
-    const float4 c = load_quad(img + (size_t)yc * g.pitch, q, g.width, sal);
+  auto hfilt = [&](const float4 c) -> float4 {
     const float4 l = quad_from_left(c);
     const float4 r = quad_from_right(c);
     float4 h;
@@ -78,18 +85,25 @@ __global__ __launch_bounds__(256) void lowpass_kernel(const float *__restrict__ 
     h.w = conv9(k0, k1, k2, k3, k4, c.w, r.x + c.z, r.y + c.y, r.z + c.x, r.w + l.w);
     return h;
   };
+  auto hrow = [&](int y) -> float4 { return hfilt(ldraw(y)); };
 
   float4 w0 = hrow(y0 - 4), w1 = hrow(y0 - 3), w2 = hrow(y0 - 2), w3 = hrow(y0 - 1), w4 = hrow(y0);
   float4 w5 = hrow(y0 + 1), w6 = hrow(y0 + 2), w7 = hrow(y0 + 3), w8;
+  float4 raw = ldraw(y0 + 4);
   const bool writer = lane >= 1 && lane <= OUT_LANES && 4 * q < g.width;
   for (int y = y0; y < y1; y++) {
-    w8 = hrow(y + 4);
+    const float4 rawnext = ldraw(y + 5);         // prefetch one row ahead of the horizontal filter
+    w8 = hfilt(raw);
+    raw = rawnext;
     float4 o;
     o.x = conv9(k0, k1, k2, k3, k4, w4.x, w3.x + w5.x, w2.x + w6.x, w1.x + w7.x, w0.x + w8.x);
     o.y = conv9(k0, k1, k2, k3, k4, w4.y, w3.y + w5.y, w2.y + w6.y, w1.y + w7.y, w0.y + w8.y);
     o.z = conv9(k0, k1, k2, k3, k4, w4.z, w3.z + w5.z, w2.z + w6.z, w1.z + w7.z, w0.z + w8.z);
     o.w = conv9(k0, k1, k2, k3, k4, w4.w, w3.w + w5.w, w2.w + w6.w, w1.w + w7.w, w0.w + w8.w);
-    if (writer) store_quad(out + (size_t)y * dpitch, q, g.width, dal, o);
+    if (writer) {
+      if (FAST) *reinterpret_cast<float4 *>(out + (size_t)y * dpitch + 4 * q) = o;
+      else store_quad(out + (size_t)y * dpitch, q, g.width, dal, o);
+    }
     w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
   }
 }
@@ -97,6 +111,7 @@ __global__ __launch_bounds__(256) void lowpass_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------- ScaleDown
 // 5-tap Gaussian (variance 0.5) + 2x decimation: horizontal then vertical.
 // Geometry `g` describes the SOURCE image; strips/segments tile the OUTPUT (w/2, h/2).
+template <bool FAST>
 __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict__ src, StripGeom g,
                                                         float *__restrict__ dst, int dpitch,
                                                         long long dst_frame_stride, Taps5 t, int src_aligned,
@@ -114,11 +129,17 @@ __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict_
   const float k0 = t.k[0], k1 = t.k[1], k2 = t.k[2];      // t.k[2] = centre tap here (reference order)
   const bool sal = src_aligned != 0, dal = dst_aligned != 0;
 
-  auto hrow = [&](int y) -> float4 {
-    const int yc = clampi(y, 0, g.height - 1);
-    const float *row = img + (size_t)yc * g.pitch;
-    const float4 A = load_quad(row, 2 * q, g.width, sal);       // input px 8q   .. 8q+3
-    const float4 B = load_quad(row, 2 * q + 1, g.width, sal);   // input px 8q+4 .. 8q+7
+  const QuadCol qa = make_quadcol(2 * q, g.width), qb = make_quadcol(2 * q + 1, g.width);
+  struct Raw2 { float4 A, B; };
+  auto ldraw = [&](int y) -> Raw2 {
+    const float *row = img + (size_t)clampi(y, 0, g.height - 1) * g.pitch;
+    Raw2 r;
+    r.A = load_quad_t<FAST>(row, 2 * q, g.width, sal, qa);       // input px 8q   .. 8q+3
+    r.B = load_quad_t<FAST>(row, 2 * q + 1, g.width, sal, qb);   // input px 8q+4 .. 8q+7
+    return r;
+  };
+  auto hfilt = [&](const Raw2 &rw) -> float4 {
+    const float4 A = rw.A, B = rw.B;
     const float lz = lane_from_left(B.z), lw = lane_from_left(B.w);   // px 8q-2, 8q-1
     const float rx = lane_from_right(A.x);                             // px 8q+8
     float4 h;
@@ -136,17 +157,25 @@ __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict_
     return s;
   };
 
+  auto hrow = [&](int y) -> float4 { return hfilt(ldraw(y)); };
   const bool writer = lane >= 1 && lane <= OUT_LANES && 4 * q < w2;
+  const bool fast_store = FAST && (w2 & 3) == 0 && dal;
   float4 t0 = hrow(2 * y0 - 2), t1 = hrow(2 * y0 - 1), t2 = hrow(2 * y0), t3, t4;
+  Raw2 ra = ldraw(2 * y0 + 1), rb = ldraw(2 * y0 + 2);
   for (int y = y0; y < y1; y++) {
-    t3 = hrow(2 * y + 1);
-    t4 = hrow(2 * y + 2);
+    const Raw2 na = ldraw(2 * y + 3), nb = ldraw(2 * y + 4);    // prefetch the next output row's two input rows
+    t3 = hfilt(ra);
+    t4 = hfilt(rb);
+    ra = na; rb = nb;
     float4 o;
     o.x = vcomb(t0.x, t1.x, t2.x, t3.x, t4.x);
     o.y = vcomb(t0.y, t1.y, t2.y, t3.y, t4.y);
     o.z = vcomb(t0.z, t1.z, t2.z, t3.z, t4.z);
     o.w = vcomb(t0.w, t1.w, t2.w, t3.w, t4.w);
-    if (writer) store_quad(out + (size_t)y * dpitch, q, w2, dal, o);
+    if (writer) {
+      if (fast_store) *reinterpret_cast<float4 *>(out + (size_t)y * dpitch + 4 * q) = o;
+      else store_quad(out + (size_t)y * dpitch, q, w2, dal, o);
+    }
     t0 = t2; t1 = t3; t2 = t4;
   }
 }
@@ -184,8 +213,12 @@ int launch_lowpass(misift_ctx *ctx, const float *src, const StripGeom &g, float 
   const int sal = is_aligned16(src, g.pitch) && (g.frame_stride & 3) == 0;
   const int dal = is_aligned16(dst, dpitch) && (dst_frame_stride & 3) == 0;
   LaunchScope ls(ctx, "lowpass");
-  hipLaunchKernelGGL(lowpass_kernel, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
-                     dst_frame_stride, t, sal, dal);
+  if (sal && dal && (g.width & 3) == 0)
+    hipLaunchKernelGGL(lowpass_kernel<true>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+                       dst_frame_stride, t, sal, dal);
+  else
+    hipLaunchKernelGGL(lowpass_kernel<false>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+                       dst_frame_stride, t, sal, dal);
   return ls.finish();
 }
 
@@ -197,8 +230,12 @@ int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, floa
   const int sal = is_aligned16(src, g.pitch) && (g.frame_stride & 3) == 0;
   const int dal = is_aligned16(dst, dpitch) && (dst_frame_stride & 3) == 0;
   LaunchScope ls(ctx, "scaledown");
-  hipLaunchKernelGGL(scaledown_kernel, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
-                     dst_frame_stride, t, sal, dal);
+  if (sal && (g.width & 3) == 0)
+    hipLaunchKernelGGL(scaledown_kernel<true>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+                       dst_frame_stride, t, sal, dal);
+  else
+    hipLaunchKernelGGL(scaledown_kernel<false>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+                       dst_frame_stride, t, sal, dal);
   return ls.finish();
 }
 
