@@ -19,7 +19,11 @@
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 #define MT_ROWS_PER_BLOCK 128
-#define MT_BSTRIDE 129           // floats per staged column: odd => conflict-free ds_read_b32 across 32 columns
+// LDS image of a 32-column tile of D2: column-major, each column split into its even-k and odd-k halves
+// ([col][half][64]) so that lane (col, half) — which feeds k = 2t + half to MFMA t — reads its 64 operands
+// as 16 contiguous ds_read_b128.  Column stride 132 floats: a b128 lane group (16 columns) then starts on
+// 16 distinct multiples of 4 banks => conflict-free.
+#define MT_BSTRIDE 132
 #define MT_TILE 32
 
 struct MatchGeom {
@@ -34,9 +38,12 @@ struct MatchGeom {
 
 __device__ __forceinline__ void top2_update(float sc, int p2, float &mx, float &sec, int &ix)
 {
-  // reference update rule (matching.cu:352-360): strict '>' so the earliest column wins ties
-  if (sc > mx) { sec = mx; mx = sc; ix = p2; }
-  else if (sc > sec) sec = sc;
+  // reference update rule (matching.cu:352-360): strict '>' so the earliest column wins ties.
+  // Branch-free (selects only): `if (sc > mx) {sec = mx; mx = sc; ix = p2;} else if (sc > sec) sec = sc;`
+  const bool gt = sc > mx;
+  sec = gt ? mx : fmaxf(sec, sc);       // sc <= mx here in the else case, so max(sec, sc) == the reference's update
+  ix = gt ? p2 : ix;
+  mx = gt ? sc : mx;
 }
 
 // exact merge of two top-2 summaries of disjoint column sets (ties -> smaller column index,
@@ -51,17 +58,24 @@ __device__ __forceinline__ void top2_merge(float &mx, float &sec, int &ix, float
   }
 }
 
+// One workgroup = 4 wavefronts = 128 rows of set 1; it sweeps a chunk of 64-column super-tiles of set 2.
+// Per super-tile every wavefront runs TWO independent accumulator chains (columns 0-31 and 32-63) of
+// 64 dependent v_mfma_f32_32x32x2_f32 each, interleaved, so the 64-cycle dependent-issue latency of one
+// chain is covered by the other (and by the second wavefront resident on the SIMD).
+#define MT_SUPER 64
 __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restrict__ pts1,
                                                        const SiftPointD *__restrict__ pts2, MatchGeom G,
                                                        float *__restrict__ partial)
 {
-  __shared__ float Bs[2][MT_TILE * MT_BSTRIDE];
+  __shared__ float Bs[2][MT_SUPER * MT_BSTRIDE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, col = lane & 31;
   const unsigned item = xcd_remap(blockIdx.x, gridDim.x);
-  const int rb = item / G.nchunks, chunk = item % G.nchunks;
-  const int tile0 = chunk * G.tiles_per_chunk;
-  const int tile1 = min(tile0 + G.tiles_per_chunk, G.ntiles);
+  // chunk-major: the workgroups resident on one XCD work on the same chunk of set 2 (it stays in that L2)
+  const int nrb = (G.row_count + MT_ROWS_PER_BLOCK - 1) / MT_ROWS_PER_BLOCK;
+  const int chunk = item / nrb, rb = item % nrb;
+  const int st0 = chunk * G.tiles_per_chunk;                       // super-tile range of this chunk
+  const int st1 = min(st0 + G.tiles_per_chunk, G.ntiles);
 
   // ---- A fragment: row (lane&31) of this wave, k = 2t + half, t = 0..63
   const int row_local = rb * MT_ROWS_PER_BLOCK + wave * 32 + col;          // within [0,row_count)
@@ -82,42 +96,75 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
 #pragma unroll
   for (int r = 0; r < 16; r++) { mx[r] = 0.0f; sec[r] = 0.0f; ix[r] = -1; }
 
-  // ---- B staging: thread -> (column scol + 8j, float4 index f4)
+  // ---- B staging: thread -> (column scol + 8j, float4 index f4), j = 0..7
   const int scol = tid >> 5, f4 = tid & 31;
-  float4 stage[4];
-  auto gload = [&](int tile) {
+  float4 stage[8];
+  auto gload = [&](int st) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int p2 = min(tile * MT_TILE + scol + 8 * j, G.n2 - 1);
+    for (int j = 0; j < 8; j++) {
+      const int p2 = min(st * MT_SUPER + scol + 8 * j, G.n2 - 1);
       stage[j] = reinterpret_cast<const float4 *>(pts2[p2].data)[f4];
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float *d = &Bs[buf][(scol + 8 * j) * MT_BSTRIDE + 4 * f4];
-      d[0] = stage[j].x; d[1] = stage[j].y; d[2] = stage[j].z; d[3] = stage[j].w;
+    for (int j = 0; j < 8; j++) {
+      float *d = &Bs[buf][(scol + 8 * j) * MT_BSTRIDE + 2 * f4];       // k = 4*f4 .. 4*f4+3
+      *reinterpret_cast<float2 *>(d) = make_float2(stage[j].x, stage[j].z);        // even k -> half 0
+      *reinterpret_cast<float2 *>(d + 64) = make_float2(stage[j].y, stage[j].w);   // odd k  -> half 1
     }
   };
 
-  if (tile0 < tile1) {
-    gload(tile0);
+  if (st0 < st1) {
+    gload(st0);
     lstore(0);
   }
   __syncthreads();
-  for (int tile = tile0; tile < tile1; tile++) {
-    const int buf = (tile - tile0) & 1;
-    if (tile + 1 < tile1) gload(tile + 1);
-    const float *bcol = &Bs[buf][col * MT_BSTRIDE + half];
-    floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int st = st0; st < st1; st++) {
+    const int buf = (st - st0) & 1;
+    if (st + 1 < st1) gload(st + 1);
+    const float4 *b0 = reinterpret_cast<const float4 *>(&Bs[buf][col * MT_BSTRIDE + half * 64]);
+    const float4 *b1 = reinterpret_cast<const float4 *>(&Bs[buf][(col + 32) * MT_BSTRIDE + half * 64]);
+    floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    floatx16 acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // software pipeline: the ds_read_b128 pair of the next 4 k-pairs is in flight while 8 MFMAs run
+    float4 p0 = b0[0], p1 = b1[0], q0, q1;
 #pragma unroll
-    for (int t = 0; t < 64; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bcol[2 * t], acc, 0, 0, 0);
-    const int p2 = tile * MT_TILE + col;
-    if (p2 < G.ncols) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) top2_update(acc[r], p2, mx[r], sec[r], ix[r]);
+    for (int i = 0; i < 16; i += 2) {
+      q0 = b0[i + 1]; q1 = b1[i + 1];
+      __builtin_amdgcn_sched_barrier(0);        // keep the prefetch ahead of the MFMAs that hide it
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 0], p0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 0], p1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 1], p0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 1], p1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 2], p0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 2], p1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 3], p0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 3], p1.w, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < 16) { p0 = b0[i + 2]; p1 = b1[i + 2]; }
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 4], q0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 4], q1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 5], q0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 5], q1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 6], q0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 6], q1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 7], q0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 7], q1.w, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (tile + 1 < tile1) lstore(buf ^ 1);
+    // ascending column order within the residue class: columns 0-31 of the super-tile first
+    const int c0 = st * MT_SUPER + col, c1 = c0 + 32;
+    if (c0 < G.ncols) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) top2_update(acc0[r], c0, mx[r], sec[r], ix[r]);
+    }
+    if (c1 < G.ncols) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) top2_update(acc1[r], c1, mx[r], sec[r], ix[r]);
+    }
+    if (st + 1 < st1) lstore(buf ^ 1);
     __syncthreads();
   }
 
@@ -197,11 +244,11 @@ int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count
   G.row_begin = row_begin; G.row_count = row_count; G.n1_total = row_begin + row_count;
   G.n2 = n2;
   G.ncols = ctx->opt.match_full ? n2 : MT_TILE * (n2 / MT_TILE);
-  G.ntiles = (G.ncols + MT_TILE - 1) / MT_TILE;
+  G.ntiles = (G.ncols + MT_SUPER - 1) / MT_SUPER;                 // 64-column super-tiles
   const int nrb = (row_count + MT_ROWS_PER_BLOCK - 1) / MT_ROWS_PER_BLOCK;
   const int slots = 2 * ctx->num_cus;
   int nchunks = (24 * slots + nrb - 1) / nrb;
-  int maxchunks = G.ntiles / 4;
+  int maxchunks = G.ntiles / 2;
   if (maxchunks < 1) maxchunks = 1;
   if (nchunks > maxchunks) nchunks = maxchunks;
   if (nchunks < 1) nchunks = 1;
