@@ -47,7 +47,7 @@ def algorithmic_bytes_per_frame():
     laplace = sum(32 * n for n in N)
     findpoints = sum(28 * n for n in N)
     return {"lowpass": lowpass, "scaledown": scaledown, "laplace": laplace, "detect": findpoints,
-            "dog_detect": laplace + findpoints}
+            "dog_scan": laplace + findpoints}
 
 
 def gen_frames_torch(torch, nframes, first, device):
@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--unfused", action="store_true", help="separate laplace/detect kernels (DoG planes in HBM)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (H2D + extract + D2H) side measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -168,12 +169,52 @@ def main():
     dom_ms = kernels[dom]["ms_per_step"]
     dom_launches = max(1, kernels[dom]["launches_per_step"])
     achieved = alg[dom] * B / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tj):                       # bytes per frame per kernel from the committed rocprofv3 PMC passes
+        try:
+            t = json.load(open(tj))
+            if dom in t.get("bytes_per_frame", {}):
+                traffic = int(t["bytes_per_frame"][dom] * B / dom_launches)
+        except Exception:
+            traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: "
+                                "2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), not collected live",
                 "alg_bytes_per_launch": int(alg[dom] * B / dom_launches),
                 "avg_launch_ms": round(dom_ms / dom_launches, 4),
                 "pipeline_alg_GBps": round(197.2e6 * fps / world / 1e9, 1),
                 "pipeline_frac": round(197.2e6 * fps / world / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---------------- PCIe-inclusive side measurement (never `value`): pinned host frames -> H2D -> extract -> D2H
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_pcie:
+        nb = min(B, 16)
+        host_frames = torch.empty((nb, H, W), dtype=torch.float32).pin_memory()
+        host_frames.copy_(frames[:nb].cpu())
+        host_pts = torch.empty((nb * MAX_PTS * 576,), dtype=torch.uint8).pin_memory()
+        dev_frames = torch.empty((nb, H, W), dtype=torch.float32, device=device)
+        cnts = (C.c_int * nb)()
+
+        def pstep():
+            dev_frames.copy_(host_frames, non_blocking=True)
+            capi.check(capi.lib().misift_extract_batch(ctx.h, dev_frames.data_ptr(), nb, H * W, W, H, W, NUM_OCTAVES,
+                                                       INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
+                                                       MAX_PTS, cnts), "misift_extract_batch")
+            nn = np.frombuffer(cnts, dtype=np.int32)
+            for f in range(nb):          # D2H of exactly the valid records of every frame (cudaSiftH.cu:139-140)
+                k = int(nn[f]) * 576
+                host_pts[f * MAX_PTS * 576: f * MAX_PTS * 576 + k].copy_(
+                    pts[f * MAX_PTS * 576: f * MAX_PTS * 576 + k], non_blocking=True)
+            torch.cuda.synchronize()
+        pstep()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pstep()
+        pdt = (time.perf_counter() - t0) / 3
+        pcie = {"frames_per_s_incl_h2d_d2h": round(nb / pdt, 1), "frames": nb,
+                "note": "pinned host fp32 frames uploaded per step + valid SiftPoint records downloaded; not `value`"}
 
     # ---------------- matcher: n x n x 128 brute force on fp32 MFMA, row-block split over ranks
     match = None
@@ -262,7 +303,7 @@ def main():
                                       (B, " + RCCL gather of SiftData to rank 0" if world > 1 else ""),
                           "frames_per_gpu": B, "path": "unfused" if args.unfused else "fused dog+detect",
                           "keypoints_per_frame": round(kp_per_frame, 1)},
-               "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu}
+               "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu, "pcie_inclusive": pcie}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -17,11 +17,13 @@
 #define NUM_SCALES 5
 #define NUM_BLURS  8          // NUM_SCALES + 3 (cudaSiftD.h:33 LAPLACE_S)
 #define NUM_DOG    7
-#define CNT_STRIDE 32         // uints per frame in the counter block
+#define CNT_STRIDE 64         // uints per frame in the counter block
 #define CNT_MAXPTS 17         // slot holding maxPts (reference d_MaxNumPoints)
 #define CNT_CAND   20         // CNT_CAND + octave : candidate count of that octave
 #define CNT_CANDOVF 28        // candidates dropped because the list was full
 #define CNT_PTOVF  29         // points dropped because maxPts was reached
+#define CNT_DET    32         // CNT_DET + octave : detections of that octave (merged-octave pipeline)
+#define CNT_DUP    40         // CNT_DUP + octave : second-orientation duplicates of that octave
 
 struct alignas(16) SiftPointD {   // device view of the 576-byte record
   float xpos, ypos, scale, sharpness, edgeness, orientation, score, ambiguity;
@@ -34,6 +36,25 @@ static_assert(sizeof(SiftPointD) == MISIFT_POINT_BYTES, "record size");
 
 struct Taps5 { float k[5]; };                    // k[0] = centre tap
 struct LaplaceTaps { float k[NUM_BLURS][5]; };   // per blur scale, k[.][0] = centre
+
+// Merged-octave pipeline: one pyramid level as seen by the per-keypoint kernels.  Index = reference
+// octave number (1 = coarsest ... noct = finest); img_off = float offset of the level inside a frame's arena.
+struct OctaveInfo {
+  int w, h, p;
+  long long img_off;
+  float subsampling, lowest_scale;
+  unsigned cand_off, cand_cap;     // this octave's slice of the frame's candidate list
+};
+struct PyramidInfo {
+  int noct, nframes;
+  long long frame_stride;          // floats between frames' arenas
+  OctaveInfo o[MISIFT_MAX_OCTAVES + 1];
+};
+// A detection waiting in the staging area (32 bytes): refine fills the first five fields, orient the rest.
+struct alignas(16) Detection {
+  float xpos, ypos, scale, sharpness, edgeness, ori1, ori2;
+  int dupslot;                     // slot among this octave's duplicates, -1 = no second orientation
+};
 
 // Geometry of one batched streaming launch.
 struct StripGeom {
@@ -175,6 +196,8 @@ struct misift_ctx {
   int cap_frames;
   unsigned int *d_cand;         // candidate lists [cap_frames][cand_cap]
   size_t cand_cap;              // entries per frame
+  Detection *d_det;             // staging [cap_det_frames][MISIFT_MAX_OCTAVES][det_max_pts]
+  int cap_det_frames, det_max_pts;
   float *d_own_scratch;         // scratch allocated on behalf of the caller (NULL tempMemory)
   size_t own_scratch_floats;
   void *d_match_tmp;            // matcher partial results
@@ -229,5 +252,12 @@ int launch_orient(misift_ctx *ctx, const float *base, long long base_frame_strid
 int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride, int w, int h, int pitch,
                  int nframes, float subsampling, int octave, SiftPointD *pts, int max_pts);
 int launch_rescale(misift_ctx *ctx, SiftPointD *pts, int npts, float scale);
+int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts);
+int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts);
+struct ScanAll;
+int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
+                        float thresh);
+int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
+                      float thresh, float edge_limit, float factor, int max_pts);
 int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2);
 int launch_selftest(misift_ctx *ctx);

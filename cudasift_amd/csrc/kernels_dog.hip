@@ -102,9 +102,16 @@ __device__ __forceinline__ void fill_lds_taps(v2f *s_taps, const LaplaceTaps &ta
   __syncthreads();
 }
 
-__device__ __forceinline__ Quad2 blur_quad2(const v2f *tk, Quad2 c, Quad2 p1, Quad2 p2, Quad2 p3, Quad2 p4)
+struct Taps2 { v2f k0, k1, k2, k3, k4; };
+__device__ __forceinline__ Taps2 load_taps2(const v2f *tk)
 {
-  const v2f k0 = tk[0], k1 = tk[1], k2 = tk[2], k3 = tk[3], k4 = tk[4];
+  Taps2 t;
+  t.k0 = tk[0]; t.k1 = tk[1]; t.k2 = tk[2]; t.k3 = tk[3]; t.k4 = tk[4];
+  return t;
+}
+__device__ __forceinline__ Quad2 blur_quad2(const Taps2 &t, Quad2 c, Quad2 p1, Quad2 p2, Quad2 p3, Quad2 p4)
+{
+  const v2f k0 = t.k0, k1 = t.k1, k2 = t.k2, k3 = t.k3, k4 = t.k4;
   v2f a = k0 * c.lo, b = k0 * c.hi;           // vertical pass: (x,y) and (z,w)
   a = pk_fma(k1, p1.lo, a); b = pk_fma(k1, p1.hi, b);
   a = pk_fma(k2, p2.lo, a); b = pk_fma(k2, p2.hi, b);
@@ -161,10 +168,16 @@ __global__ __launch_bounds__(256) void laplace_kernel(const float *__restrict__ 
     const float4 rnext = ld(y + 5);              // prefetch: latency hides under this row's math
     const Quad2 c = q2(r4), p1 = add_q2(q2(r3), q2(r5)), p2 = add_q2(q2(r2), q2(r6)), p3 = add_q2(q2(r1), q2(r7)),
                 p4 = add_q2(q2(r0), q2(r8));
-    Quad2 old = blur_quad2(tk, c, p1, p2, p3, p4);
+    // tap pairs of scale s+1 are fetched from LDS while scale s is computed
+    Taps2 tcur = load_taps2(tk), tnext = load_taps2(tk + 5);
+    __builtin_amdgcn_sched_barrier(0);
+    Quad2 old = blur_quad2(tcur, c, p1, p2, p3, p4);
 #pragma unroll
     for (int s = 1; s < NUM_BLURS; s++) {
-      const Quad2 res = blur_quad2(tk + 5 * s, c, p1, p2, p3, p4);
+      tcur = tnext;
+      if (s + 1 < NUM_BLURS) tnext = load_taps2(tk + 5 * (s + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      const Quad2 res = blur_quad2(tcur, c, p1, p2, p3, p4);
       float *dst = out + (size_t)(s - 1) * plane + (size_t)y * g.pitch;
       if (writer) {
         if (FAST) *reinterpret_cast<float4 *>(dst + 4 * q) = sub_q2(res, old);
@@ -333,28 +346,15 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
 // applies the reference's full 26-neighbour test (cudaSiftD.cu:1337-1360) before refining.
 // Keeping only the current DoG row in registers (no 3-row window, no box minima) leaves the
 // kernel at ~1/2 the registers and ~1/3 the instructions of a full in-register 3x3x3 test.
-template <bool FAST, int OCC>
-__global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restrict__ base, StripGeom g,
-                                                       LaplaceTaps taps, float thresh, int octave,
-                                                       unsigned *__restrict__ counters,
-                                                       unsigned *__restrict__ cand, unsigned cand_cap, int aligned)
+// One wavefront's strip/segment of the fused DoG scan (see dog_scan_kernel above for the method).
+template <bool FAST>
+__device__ __forceinline__ void scan_strip(const float *img, int width, int height, int pitch, int q, int lane,
+                                           int y0, int y1, const v2f *tk, float thresh, unsigned *cnt,
+                                           unsigned *list, unsigned cand_cap, int octave, bool al)
 {
-  __shared__ v2f s_taps[NUM_BLURS * 5];
-  fill_lds_taps(s_taps, taps);
-  const ItemCoord it = decode_item(g);
-  if (!it.valid) return;
-  const int lane = threadIdx.x & 63;
-  // lanes 0,63: blur halo; lanes 1,62: DoG column-neighbour halo; lanes 2..61 test their quads
-  const int q = it.strip * (OUT_LANES - 2) + lane - 2;
-  const float *img = base + (long long)it.frame * g.frame_stride;
-  unsigned *cnt = counters + (size_t)it.frame * CNT_STRIDE;
-  unsigned *list = cand + (size_t)it.frame * cand_cap;
-  const int y0 = it.seg * g.seg_rows;
-  const int y1 = min(y0 + g.seg_rows, g.height);
-  const bool al = aligned != 0;
+  struct { int width, height, pitch; } g = {width, height, pitch};
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
   const QuadCol qc = make_quadcol(q, g.width);
-  const v2f *tk = s_taps;
   auto ld = [&](int y) -> float4 {
     return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
   };
@@ -367,12 +367,17 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
     const Quad2 c = q2(r4), p1 = add_q2(q2(r3), q2(r5)), p2 = add_q2(q2(r2), q2(r6)), p3 = add_q2(q2(r1), q2(r7)),
                 p4 = add_q2(q2(r0), q2(r8));
     float4 d[NUM_DOG];
-    Quad2 old = blur_quad2(tk, c, p1, p2, p3, p4);
+    // tap pairs of scale s+1 are fetched from LDS while scale s is computed
+    Taps2 tcur = load_taps2(tk), tnext = load_taps2(tk + 5);
+    __builtin_amdgcn_sched_barrier(0);
+    Quad2 old = blur_quad2(tcur, c, p1, p2, p3, p4);
 #pragma unroll
     for (int s = 1; s < NUM_BLURS; s++) {
-      asm volatile("" ::: "memory");            // keep each scale's 5 tap pairs a short-lived LDS read
-      __builtin_amdgcn_sched_barrier(0);        // and stop the scheduler from interleaving all 8 scales
-      const Quad2 res = blur_quad2(tk + 5 * s, c, p1, p2, p3, p4);
+      tcur = tnext;
+      asm volatile("" ::: "memory");            // re-read from LDS: do not pin 80 VGPRs across the row loop
+      if (s + 1 < NUM_BLURS) tnext = load_taps2(tk + 5 * (s + 1));
+      __builtin_amdgcn_sched_barrier(0);        // prefetch stays ahead of the math that hides it
+      const Quad2 res = blur_quad2(tcur, c, p1, p2, p3, p4);
       d[s - 1] = sub_q2(res, old);
       old = res;
     }
@@ -432,6 +437,78 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
   }
 }
 
+template <bool FAST, int OCC>
+__global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restrict__ base, StripGeom g,
+                                                            LaplaceTaps taps, float thresh, int octave,
+                                                            unsigned *__restrict__ counters,
+                                                            unsigned *__restrict__ cand, unsigned cand_cap, int aligned)
+{
+  __shared__ v2f s_taps[NUM_BLURS * 5];
+  fill_lds_taps(s_taps, taps);
+  const ItemCoord it = decode_item(g);
+  if (!it.valid) return;
+  const int lane = threadIdx.x & 63;
+  // lanes 0,63: blur halo; lanes 1,62: DoG column-neighbour halo; lanes 2..61 test their quads
+  const int q = it.strip * (OUT_LANES - 2) + lane - 2;
+  const int y0 = it.seg * g.seg_rows;
+  scan_strip<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
+                   min(y0 + g.seg_rows, g.height), s_taps, thresh, counters + (size_t)it.frame * CNT_STRIDE,
+                   cand + (size_t)it.frame * cand_cap, cand_cap, octave, aligned != 0);
+}
+
+// ---- merged-octave scan: ONE launch walks the strips of every pyramid level of every frame.
+struct AllTaps { LaplaceTaps t[MISIFT_MAX_OCTAVES + 1]; };      // index = reference octave number
+struct ScanOct {
+  int w, h, p, nstrips, nsegs, seg_rows, octave;
+  long long img_off, item_begin;
+  unsigned cand_off, cand_cap;
+};
+struct ScanAllGeom {
+  int nlev, nframes;
+  long long frame_stride, total_items;
+  unsigned cand_stride;                       // candidate words per frame (all octaves)
+  ScanOct o[MISIFT_MAX_OCTAVES];              // o[0] = finest level: the long items are dispatched first
+};
+
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
+                                                              AllTaps taps, float thresh,
+                                                              unsigned *__restrict__ counters,
+                                                              unsigned *__restrict__ cand)
+{
+  __shared__ v2f s_taps[WAVES_PER_BLOCK][NUM_BLURS * 5];
+  // no XCD remap here: items of different levels cost differently, and the hardware's round-robin
+  // block -> XCD placement is what keeps the eight XCDs evenly loaded across the level boundaries
+  const unsigned lb = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  long long item = (long long)lb * WAVES_PER_BLOCK + wave;
+  if (item >= G.total_items) return;
+  int lev = 0;
+  for (int k = 1; k < G.nlev; k++)
+    if (item >= G.o[k].item_begin) lev = k;
+  lev = __builtin_amdgcn_readfirstlane(lev);
+  const ScanOct &L = G.o[lev];
+  item -= L.item_begin;
+  const int seg = (int)(item % L.nsegs);
+  const long long r = item / L.nsegs;
+  const int strip = (int)(r % L.nstrips);
+  const int frame = (int)(r / L.nstrips);
+  // this wavefront's private copy of its octave's tap pairs
+  if (lane < NUM_BLURS * 5) {
+    const float k = taps.t[L.octave].k[lane / 5][lane % 5];
+    s_taps[wave][lane] = mk2(k, k);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int q = strip * (OUT_LANES - 2) + lane - 2;
+  const int y0 = seg * L.seg_rows;
+  scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
+                   min(y0 + L.seg_rows, L.h), s_taps[wave], thresh, counters + (size_t)frame * CNT_STRIDE,
+                   cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
+}
+
 // ------------------------------------------------------------------- refine
 struct RefineParams {
   int width, height, pitch, nframes;
@@ -441,39 +518,124 @@ struct RefineParams {
   unsigned cand_cap;
 };
 
-// 3x3 neighbourhood of 4 consecutive blur scales around (x, y), recomputed from the octave
-// base image with the blur chains of blur_quad() / oracle orc_laplace (vertical pass first,
-// then horizontal; clamp-to-edge), so the values are bit-identical to the streamed DoG.
-__device__ __forceinline__ void blur_patch(const float *img, int w, int h, int pitch, const float (&tk)[4][5],
-                                           int x, int y, float (&b)[4][3][3])
+// 3x3x3 DoG neighbourhood of candidate (x, y, scale s): d[p] = B[s+p+1] - B[s+p], the blurs recomputed from
+// the octave base image with the chains of blur_quad2() / oracle orc_laplace (vertical pass first, then
+// horizontal; clamp-to-edge) — bit-identical to the streamed DoG.
+__device__ __forceinline__ void dog_patch(const float *img, int w, int h, int pitch, const float (&tk)[4][5],
+                                          int x, int y, float (&d)[3][3][3])
 {
-  float vres[4][3][11];                 // vertical results: [blur][row y-1..y+1][col x-5..x+5]
+  int xo[11];
 #pragma unroll
-  for (int cx = 0; cx < 11; cx++) {
-    const float *col = img + clampi(x + cx - 5, 0, w - 1);
-    float r[11];                        // rows y-5 .. y+5 (clamped)
+  for (int cx = 0; cx < 11; cx++) xo[cx] = clampi(x + cx - 5, 0, w - 1);
+  float prev[3][3];
 #pragma unroll
-    for (int j = 0; j < 11; j++) r[j] = col[(size_t)clampi(y + j - 5, 0, h - 1) * pitch];
+  for (int bs = 0; bs < 4; bs++) {
+    const float k0 = tk[bs][0], k1 = tk[bs][1], k2 = tk[bs][2], k3 = tk[bs][3], k4 = tk[bs][4];
+    float vres[3][11];                   // vertical results: [row y-1..y+1][col x-5..x+5]
 #pragma unroll
-    for (int dy = 0; dy < 3; dy++) {
-      const float c = r[dy + 4];
-      const float p1 = r[dy + 3] + r[dy + 5], p2 = r[dy + 2] + r[dy + 6];
-      const float p3 = r[dy + 1] + r[dy + 7], p4 = r[dy + 0] + r[dy + 8];
+    for (int cx = 0; cx < 11; cx++) {
+      const float *col = img + xo[cx];
+      float r[11];                       // rows y-5 .. y+5 (clamped)
 #pragma unroll
-      for (int bs = 0; bs < 4; bs++)
-        vres[bs][dy][cx] = conv9(tk[bs][0], tk[bs][1], tk[bs][2], tk[bs][3], tk[bs][4], c, p1, p2, p3, p4);
+      for (int j = 0; j < 11; j++) r[j] = col[(size_t)clampi(y + j - 5, 0, h - 1) * pitch];
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++)
+        vres[dy][cx] = conv9(k0, k1, k2, k3, k4, r[dy + 4], r[dy + 3] + r[dy + 5], r[dy + 2] + r[dy + 6],
+                             r[dy + 1] + r[dy + 7], r[dy + 0] + r[dy + 8]);
     }
-  }
-#pragma unroll
-  for (int bs = 0; bs < 4; bs++)
 #pragma unroll
     for (int dy = 0; dy < 3; dy++)
 #pragma unroll
       for (int dx = 0; dx < 3; dx++) {
-        const float *v = &vres[bs][dy][dx];     // v[4] is the centre column
-        b[bs][dy][dx] = conv9(tk[bs][0], tk[bs][1], tk[bs][2], tk[bs][3], tk[bs][4], v[4], v[3] + v[5],
-                              v[2] + v[6], v[1] + v[7], v[0] + v[8]);
+        const float *v = &vres[dy][dx];       // v[4] is the centre column
+        const float cur = conv9(k0, k1, k2, k3, k4, v[4], v[3] + v[5], v[2] + v[6], v[1] + v[7], v[0] + v[8]);
+        if (bs > 0) d[bs - 1][dy][dx] = cur - prev[dy][dx];
+        prev[dy][dx] = cur;
       }
+  }
+}
+
+// Full 26-neighbour test + edge test + 3-D quadratic refinement of one candidate whose 3x3x3 DoG
+// neighbourhood is d[plane s..s+2][dy][dx] (cudaSiftD.cu:1337-1360, :1383-1417; same expression order
+// as oracle orc_findpoints()).  Returns false if the candidate is rejected.
+struct Refined { float xpos, ypos, scale, sharpness, edgeness; };
+__device__ __forceinline__ bool refine_math(const float (&d)[3][3][3], int x, int y, int s, float thresh,
+                                            float edge_limit, float factor, float lowest_scale,
+                                            const float (&scmul)[NUM_SCALES], Refined &out)
+{
+  const float val = d[1][1][1];
+  {
+    // candidates are interior pixels, so the reference's clamped neighbour addressing never applies here
+    float minv = INFINITY, maxv = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+          if (!(p == 1 && dy == 1 && dx == 1)) {
+            minv = fminf(minv, d[p][dy][dx]);
+            maxv = fmaxf(maxv, d[p][dy][dx]);
+          }
+    if (!((val < fminf(-thresh, minv)) || (val > fmaxf(thresh, maxv)))) return false;
+  }
+  const float dxx = 2.0f * val - d[1][1][0] - d[1][1][2];
+  const float dyy = 2.0f * val - d[1][0][1] - d[1][2][1];
+  const float dxy = 0.25f * (d[1][2][2] + d[1][0][0] - d[1][0][2] - d[1][2][0]);
+  const float tra = dxx + dyy;
+  const float det = dxx * dyy - dxy * dxy;
+  if (!(tra * tra < edge_limit * det)) return false;
+  const float edge = (tra * tra) / det;
+  const float dx = 0.5f * (d[1][1][2] - d[1][1][0]);
+  const float dy = 0.5f * (d[1][2][1] - d[1][0][1]);
+  const float ds = 0.5f * (d[0][1][1] - d[2][1][1]);
+  const float dss = 2.0f * val - d[2][1][1] - d[0][1][1];
+  const float dxs = 0.25f * (d[2][1][2] + d[0][1][0] - d[0][1][2] - d[2][1][0]);
+  const float dys = 0.25f * (d[2][2][1] + d[0][0][1] - d[2][0][1] - d[0][2][1]);
+  const float idxx = dyy * dss - dys * dys;
+  const float idxy = dys * dxs - dxy * dss;
+  const float idxs = dxy * dys - dyy * dxs;
+  const float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
+  const float idyy = dxx * dss - dxs * dxs;
+  const float idys = dxy * dxs - dxx * dys;
+  const float idss = dxx * dyy - dxy * dxy;
+  float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
+  float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
+  float pds = idet * (idxs * dx + idys * dy + idss * ds);
+  if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
+    pdx = dx / dxx;
+    pdy = dy / dyy;
+    pds = ds / dss;
+  }
+  const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
+  float scm = scmul[0];
+#pragma unroll
+  for (int j = 1; j < NUM_SCALES; j++) scm = (s == j) ? scmul[j] : scm;
+  const float sc = scm * exp2f(pds * factor);
+  if (!(sc >= lowest_scale)) return false;
+  out.xpos = x + pdx;
+  out.ypos = y + pdy;
+  out.scale = sc;
+  out.sharpness = val + dval;
+  out.edgeness = edge;
+  return true;
+}
+
+// 3x3x3 DoG neighbourhood of candidate (x, y, s) recomputed from the octave base image.
+__device__ __forceinline__ void dog_from_base(const float *img, int w, int h, int pitch, const LaplaceTaps &taps,
+                                              int x, int y, int s, float (&d)[3][3][3])
+{
+  float tk[4][5];                    // taps of blur scales s .. s+3 (static selects, no dynamic register indexing)
+#pragma unroll
+  for (int bs = 0; bs < 4; bs++)
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      float t = taps.k[bs][j];
+#pragma unroll
+      for (int ss = 1; ss < NUM_SCALES; ss++) t = (s == ss) ? taps.k[ss + bs][j] : t;
+      tk[bs][j] = t;
+    }
+  dog_patch(img, w, h, pitch, tk, x, y, d);
 }
 
 template <bool FROM_BASE>
@@ -501,24 +663,7 @@ __global__ __launch_bounds__(64) void refine_kernel(const float *__restrict__ sr
     const int x = code & 0x3fff, y = (code >> 14) & 0x3fff, s = code >> 28;
     float d[3][3][3];       // [plane s..s+2][dy][dx]
     if (FROM_BASE) {
-      float tk[4][5];                    // taps of blur scales s .. s+3 (static selects, no dynamic indexing)
-#pragma unroll
-      for (int bs = 0; bs < 4; bs++)
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          float t = taps.k[bs][j];
-#pragma unroll
-          for (int ss = 1; ss < NUM_SCALES; ss++) t = (s == ss) ? taps.k[ss + bs][j] : t;
-          tk[bs][j] = t;
-        }
-      float b[4][3][3];
-      blur_patch(img, P.width, P.height, P.pitch, tk, x, y, b);
-#pragma unroll
-      for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-          for (int dx = 0; dx < 3; dx++) d[p][dy][dx] = b[p + 1][dy][dx] - b[p][dy][dx];
+      dog_from_base(img, P.width, P.height, P.pitch, taps, x, y, s, d);
     } else {
 #pragma unroll
       for (int p = 0; p < 3; p++)
@@ -528,68 +673,71 @@ __global__ __launch_bounds__(64) void refine_kernel(const float *__restrict__ sr
           for (int dx = 0; dx < 3; dx++)
             d[p][dy][dx] = img[(size_t)(s + p) * plane + (size_t)(y + dy - 1) * P.pitch + (x + dx - 1)];
     }
-    const float val = d[1][1][1];
-    {
-      // the reference's 26-neighbour strict-extremum test (cudaSiftD.cu:1337-1360); candidates are
-      // interior pixels, so the clamped neighbour addressing never applies here
-      float minv = INFINITY, maxv = -INFINITY;
-#pragma unroll
-      for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-          for (int dx = 0; dx < 3; dx++)
-            if (!(p == 1 && dy == 1 && dx == 1)) {
-              minv = fminf(minv, d[p][dy][dx]);
-              maxv = fmaxf(maxv, d[p][dy][dx]);
-            }
-      if (!((val < fminf(-P.thresh, minv)) || (val > fmaxf(P.thresh, maxv)))) continue;
-    }
-    // cudaSiftD.cu:1383-1417, same expression order as oracle orc_findpoints()
-    const float dxx = 2.0f * val - d[1][1][0] - d[1][1][2];
-    const float dyy = 2.0f * val - d[1][0][1] - d[1][2][1];
-    const float dxy = 0.25f * (d[1][2][2] + d[1][0][0] - d[1][0][2] - d[1][2][0]);
-    const float tra = dxx + dyy;
-    const float det = dxx * dyy - dxy * dxy;
-    if (!(tra * tra < P.edge_limit * det)) continue;
-    const float edge = (tra * tra) / det;
-    const float dx = 0.5f * (d[1][1][2] - d[1][1][0]);
-    const float dy = 0.5f * (d[1][2][1] - d[1][0][1]);
-    const float ds = 0.5f * (d[0][1][1] - d[2][1][1]);
-    const float dss = 2.0f * val - d[2][1][1] - d[0][1][1];
-    const float dxs = 0.25f * (d[2][1][2] + d[0][1][0] - d[0][1][2] - d[2][1][0]);
-    const float dys = 0.25f * (d[2][2][1] + d[0][0][1] - d[2][0][1] - d[0][2][1]);
-    const float idxx = dyy * dss - dys * dys;
-    const float idxy = dys * dxs - dxy * dss;
-    const float idxs = dxy * dys - dyy * dxs;
-    const float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
-    const float idyy = dxx * dss - dxs * dxs;
-    const float idys = dxy * dxs - dxx * dys;
-    const float idss = dxx * dyy - dxy * dxy;
-    float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
-    float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
-    float pds = idet * (idxs * dx + idys * dy + idss * ds);
-    if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
-      pdx = dx / dxx;
-      pdy = dy / dyy;
-      pds = ds / dss;
-    }
-    const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
-    float scm = P.scmul[0];
-#pragma unroll
-    for (int j = 1; j < NUM_SCALES; j++) scm = (s == j) ? P.scmul[j] : scm;
-    const float sc = scm * exp2f(pds * P.factor);
-    if (!(sc >= P.lowest_scale)) continue;
+    Refined r;
+    if (!refine_math(d, x, y, s, P.thresh, P.edge_limit, P.factor, P.lowest_scale, P.scmul, r)) continue;
     atomicMax(&cnt[2 * o + 0], cnt[2 * o - 1]);
     const unsigned idx = atomicAdd(&cnt[2 * o + 0], 1u);
     if (idx >= (unsigned)P.max_pts) { atomicAdd(&cnt[CNT_PTOVF], 1u); continue; }
     SiftPointD *p = &out[idx];
-    p->xpos = x + pdx;
-    p->ypos = y + pdy;
-    p->scale = sc;
-    p->sharpness = val + dval;
-    p->edgeness = edge;
+    p->xpos = r.xpos;
+    p->ypos = r.ypos;
+    p->scale = r.scale;
+    p->sharpness = r.sharpness;
+    p->edgeness = r.edgeness;
     p->subsampling = P.subsampling;
+  }
+}
+
+// Merged-octave refine: all candidates of all octaves of a frame in one launch; survivors go to the
+// per-octave staging area as Detection records (orient_all_kernel / descr_all_kernel take it from there).
+struct RefineAllParams {
+  float thresh, edge_limit, factor;
+  float scmul[NUM_SCALES];
+  int max_pts;
+  unsigned cand_stride;
+};
+__global__ __launch_bounds__(64) void refine_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                        AllTaps taps, RefineAllParams R,
+                                                        unsigned *__restrict__ counters,
+                                                        const unsigned *__restrict__ cand,
+                                                        Detection *__restrict__ det)
+{
+  const int frame = blockIdx.y;
+  unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * R.max_pts;
+  // candidates of all octaves are flattened (finest first): every lane takes ONE candidate per pass,
+  // whatever its octave, so a wavefront never idles through the octaves it has no work in
+  unsigned total = 0;
+  for (int o = P.noct; o >= 1; o--) total += min(cnt[CNT_CAND + o], P.o[o].cand_cap);
+  for (unsigned fi = blockIdx.x * blockDim.x + threadIdx.x; fi < total; fi += gridDim.x * blockDim.x) {
+    int o = P.noct;
+    unsigned ci = fi;
+    for (int k = P.noct; k >= 1; k--) {
+      const unsigned n = min(cnt[CNT_CAND + k], P.o[k].cand_cap);
+      if (ci < n) { o = k; break; }
+      ci -= n;
+    }
+    const int lw = P.o[o].w, lh = P.o[o].h, lp = P.o[o].p;
+    const float *img = scratch + (long long)frame * P.frame_stride + P.o[o].img_off;
+    const unsigned code = cand[(size_t)frame * R.cand_stride + P.o[o].cand_off + ci];
+    const int x = code & 0x3fff, y = (code >> 14) & 0x3fff, s = code >> 28;
+    float tk[4][5];                                   // taps of blur scales s .. s+3 of this lane's octave
+#pragma unroll
+    for (int bs = 0; bs < 4; bs++)
+#pragma unroll
+      for (int j = 0; j < 5; j++) tk[bs][j] = taps.t[o].k[s + bs][j];
+    float d[3][3][3];
+    dog_patch(img, lw, lh, lp, tk, x, y, d);
+    Refined r;
+    if (!refine_math(d, x, y, s, R.thresh, R.edge_limit, R.factor, P.o[o].lowest_scale, R.scmul, r)) continue;
+    const unsigned idx = atomicAdd(&cnt[CNT_DET + o], 1u);
+    if (idx >= (unsigned)R.max_pts) { atomicAdd(&cnt[CNT_PTOVF], 1u); continue; }
+    Detection *p = &fdet[(size_t)(o - 1) * R.max_pts + idx];
+    p->xpos = r.xpos;
+    p->ypos = r.ypos;
+    p->scale = r.scale;
+    p->sharpness = r.sharpness;
+    p->edgeness = r.edgeness;
   }
 }
 
@@ -663,5 +811,77 @@ int launch_refine(misift_ctx *ctx, const float *dog, long long dog_frame_stride,
   else
     hipLaunchKernelGGL(refine_kernel<true>, grid, dim3(64), 0, ctx->stream, base, base_frame_stride, t, P,
                        ctx->d_counters, ctx->d_cand, pts);
+  return ls.finish();
+}
+
+// ---- merged-octave launchers -------------------------------------------------------------------
+static AllTaps pack_taps(const LaplaceTaps *taps, int noct)
+{
+  AllTaps a;
+  memset(&a, 0, sizeof(a));
+  for (int o = 1; o <= noct; o++) a.t[o] = taps[o];
+  return a;
+}
+
+int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
+                        float thresh)
+{
+  ScanAllGeom G;
+  memset(&G, 0, sizeof(G));
+  G.nlev = P.noct; G.nframes = P.nframes; G.frame_stride = P.frame_stride;
+  bool fast = (is_aligned16(scratch, 4) && (P.frame_stride & 3) == 0);
+  long long items = 0;
+  unsigned cand_stride = 0;
+  for (int o = 1; o <= P.noct; o++) cand_stride += P.o[o].cand_cap;
+  G.cand_stride = cand_stride;
+  // total wavefronts aimed at: ~16 per CU; every level gets segments sized for its share
+  for (int lev = 0; lev < P.noct; lev++) {
+    const int o = P.noct - lev;                           // finest first
+    const OctaveInfo &L = P.o[o];
+    ScanOct &S = G.o[lev];
+    S.w = L.w; S.h = L.h; S.p = L.p; S.octave = o; S.img_off = L.img_off;
+    S.cand_off = L.cand_off; S.cand_cap = L.cand_cap;
+    const int nquads = (L.w + 3) / 4;
+    S.nstrips = (nquads + (OUT_LANES - 2) - 1) / (OUT_LANES - 2);
+    if (S.nstrips < 1) S.nstrips = 1;
+    const long long target = (long long)ctx->num_cus * 16;
+    long long want = (target + (long long)P.nframes * S.nstrips - 1) / ((long long)P.nframes * S.nstrips);
+    if (want < 1) want = 1;
+    int seg = (int)((L.h + want - 1) / want);
+    seg = (seg + 7) / 8 * 8;
+    if (seg < 16) seg = 16;
+    if (seg > 128) seg = 128;
+    S.seg_rows = seg;
+    S.nsegs = (L.h + seg - 1) / seg;
+    S.item_begin = items;
+    items += (long long)P.nframes * S.nstrips * S.nsegs;
+    if ((L.w & 3) != 0 || (L.p & 3) != 0 || (L.img_off & 3) != 0) fast = false;
+  }
+  G.total_items = items;
+  const AllTaps at = pack_taps(taps, P.noct);
+  const dim3 grid((unsigned)((items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+  LaunchScope ls(ctx, "dog_scan");
+  if (fast)
+    hipLaunchKernelGGL(dog_scan_all_kernel<true>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
+                       ctx->d_counters, ctx->d_cand);
+  else
+    hipLaunchKernelGGL(dog_scan_all_kernel<false>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
+                       ctx->d_counters, ctx->d_cand);
+  return ls.finish();
+}
+
+int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
+                      float thresh, float edge_limit, float factor, int max_pts)
+{
+  RefineAllParams R;
+  R.thresh = thresh; R.edge_limit = edge_limit; R.factor = factor; R.max_pts = max_pts;
+  for (int s = 0; s < NUM_SCALES; s++) R.scmul[s] = powf(2.0f, (float)s / NUM_SCALES);
+  unsigned cand_stride = 0;
+  for (int o = 1; o <= P.noct; o++) cand_stride += P.o[o].cand_cap;
+  R.cand_stride = cand_stride;
+  const AllTaps at = pack_taps(taps, P.noct);
+  LaunchScope ls(ctx, "refine");
+  hipLaunchKernelGGL(refine_all_kernel, dim3(128, P.nframes), dim3(64), 0, ctx->stream, scratch, P, at, R,
+                     ctx->d_counters, ctx->d_cand, ctx->d_det);
   return ls.finish();
 }

@@ -31,6 +31,91 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // ------------------------------------------------------------- orientation
+struct OrientResult { float ori1, ori2; bool has2; };      // meaningful in lane 0 only
+
+// Orientation of one keypoint by one wavefront (reference cudaSiftD.cu:984-1037).  hist[64], gauss[16] and
+// smp[128] are wave-private LDS slices; smp[121..127] must hold bin -1 (never matches).
+__device__ __forceinline__ OrientResult orient_core(const float *img, int w, int h, int pitch, bool q8, float xpos,
+                                                    float ypos, float scale, float *hist, float *gauss,
+                                                    float2 *smp, int lane)
+{
+  const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
+  if (lane < 11) gauss[lane] = expf(i2sigma2 * (lane - 5) * (lane - 5));
+  wave_sync();
+  const float xp = xpos - 4.5f;
+  const float yp = ypos - 4.5f;
+#pragma unroll
+  for (int rep = 0; rep < 2; rep++) {
+    const int tx = lane + 64 * rep;
+    if (tx < 121) {
+      const int yd = tx / 11;
+      const int xd = tx - yd * 11;
+      const float xf = xp + xd;
+      const float yf = yp + yd;
+      const float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q8) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q8);
+      const float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q8) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q8);
+      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+      if (bin > 31) bin = 0;
+      const float grad = sqrtf(dx * dx + dy * dy);
+      smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
+    }
+  }
+  wave_sync();
+  // privatized histogram (no LDS atomics): lane (b, half) sums the samples of its half that fall in bin b
+  {
+    const float fb = (float)(lane & 31);
+    const float2 *sp = smp + (lane >> 5) * 64;
+    float acc = 0.0f;
+#pragma unroll 16
+    for (int j = 0; j < 64; j++) {
+      const float2 e = sp[j];
+      acc += (e.x == fb) ? e.y : 0.0f;
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < 32) hist[lane] = acc;
+  }
+  wave_sync();
+  const int t = lane & 31;
+  const int x1m = (t >= 1 ? t - 1 : t + 31), x1p = (t <= 30 ? t + 1 : t - 31);
+  const int x2m = (t >= 2 ? t - 2 : t + 30), x2p = (t <= 29 ? t + 2 : t - 30);
+  if (lane < 32) hist[t + 32] = 6.0f * hist[t] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
+  wave_sync();
+  if (lane < 32) {
+    const float v = hist[32 + t];
+    hist[t] = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
+  }
+  wave_sync();
+  OrientResult r;
+  r.ori1 = 0.0f; r.ori2 = 0.0f; r.has2 = false;
+  if (lane == 0) {
+    float maxval1 = 0.0f, maxval2 = 0.0f;
+    int i1 = -1, i2 = -1;
+    for (int i = 0; i < 32; i++) {
+      const float v = hist[i];
+      if (v > maxval1) {
+        maxval2 = maxval1; maxval1 = v; i2 = i1; i1 = i;
+      } else if (v > maxval2) {
+        maxval2 = v; i2 = i;
+      }
+    }
+    if (i1 >= 0) {                                      // empty histogram -> orientation 0
+      const float val1 = hist[32 + ((i1 + 1) & 31)];
+      const float val2 = hist[32 + ((i1 + 31) & 31)];
+      const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
+      r.ori1 = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+      if (maxval2 > 0.8f * maxval1) {
+        const float v1 = hist[32 + ((i2 + 1) & 31)];
+        const float v2 = hist[32 + ((i2 + 31) & 31)];
+        const float peak2 = i2 + 0.5f * (v1 - v2) / (2.0f * maxval2 - v1 - v2);
+        r.ori2 = 11.25f * (peak2 < 0.0f ? peak2 + 32.0f : peak2);
+        r.has2 = true;
+      }
+    }
+  }
+  wave_sync();
+  return r;
+}
+
 __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ base, long long base_frame_stride,
                                                      int w, int h, int pitch, int octave,
                                                      unsigned *__restrict__ counters, SiftPointD *__restrict__ pts,
@@ -44,104 +129,34 @@ __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ b
   const float *img = base + (long long)frame * base_frame_stride;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   SiftPointD *sift = pts + (size_t)frame * max_pts;
-  float *hist = s_hist[wave];
-  float *gauss = s_gauss[wave];
-  float2 *smp = s_smp[wave];
   const bool q8 = frac8 != 0;
 
   const int fstPts = (int)min(cnt[2 * octave - 1], (unsigned)max_pts);
   const int totPts = (int)min(cnt[2 * octave + 0], (unsigned)max_pts);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&cnt[2 * octave + 1], cnt[2 * octave + 0]);
-  if (lane >= 57) smp[64 + lane] = make_float2(-1.0f, 0.0f);     // slots 121..127 never match a bin
+  if (lane >= 57) s_smp[wave][64 + lane] = make_float2(-1.0f, 0.0f);     // slots 121..127 never match a bin
 
   for (int bx = fstPts + blockIdx.x * WAVES_PER_BLOCK + wave; bx < totPts; bx += gridDim.x * WAVES_PER_BLOCK) {
-    const float scale = sift[bx].scale;
-    const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
-    if (lane < 11) gauss[lane] = expf(i2sigma2 * (lane - 5) * (lane - 5));
-    wave_sync();
-    const float xp = sift[bx].xpos - 4.5f;
-    const float yp = sift[bx].ypos - 4.5f;
-#pragma unroll
-    for (int rep = 0; rep < 2; rep++) {
-      const int tx = lane + 64 * rep;
-      if (tx < 121) {
-        const int yd = tx / 11;
-        const int xd = tx - yd * 11;
-        const float xf = xp + xd;
-        const float yf = yp + yd;
-        const float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q8) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q8);
-        const float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q8) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q8);
-        int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
-        if (bin > 31) bin = 0;
-        const float grad = sqrtf(dx * dx + dy * dy);
-        smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
-      }
-    }
-    wave_sync();
-    // privatized histogram (no LDS atomics): lane (b, half) sums the samples of its half that fall in bin b
-    {
-      const float fb = (float)(lane & 31);
-      const float2 *sp = smp + (lane >> 5) * 64;
-      float acc = 0.0f;
-#pragma unroll 16
-      for (int j = 0; j < 64; j++) {
-        const float2 e = sp[j];
-        acc += (e.x == fb) ? e.y : 0.0f;
-      }
-      acc += __shfl_xor(acc, 32, 64);
-      if (lane < 32) hist[lane] = acc;
-    }
-    wave_sync();
-    const int t = lane & 31;
-    const int x1m = (t >= 1 ? t - 1 : t + 31), x1p = (t <= 30 ? t + 1 : t - 31);
-    const int x2m = (t >= 2 ? t - 2 : t + 30), x2p = (t <= 29 ? t + 2 : t - 30);
-    if (lane < 32)
-      hist[t + 32] = 6.0f * hist[t] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
-    wave_sync();
-    if (lane < 32) {
-      const float v = hist[32 + t];
-      hist[t] = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
-    }
-    wave_sync();
+    const OrientResult r = orient_core(img, w, h, pitch, q8, sift[bx].xpos, sift[bx].ypos, sift[bx].scale,
+                                       s_hist[wave], s_gauss[wave], s_smp[wave], lane);
     if (lane == 0) {
-      float maxval1 = 0.0f, maxval2 = 0.0f;
-      int i1 = -1, i2 = -1;
-      for (int i = 0; i < 32; i++) {
-        const float v = hist[i];
-        if (v > maxval1) {
-          maxval2 = maxval1; maxval1 = v; i2 = i1; i1 = i;
-        } else if (v > maxval2) {
-          maxval2 = v; i2 = i;
-        }
-      }
-      if (i1 < 0) {
-        sift[bx].orientation = 0.0f;                  // empty histogram
-      } else {
-        const float val1 = hist[32 + ((i1 + 1) & 31)];
-        const float val2 = hist[32 + ((i1 + 31) & 31)];
-        const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
-        sift[bx].orientation = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
-        if (maxval2 > 0.8f * maxval1) {
-          const float v1 = hist[32 + ((i2 + 1) & 31)];
-          const float v2 = hist[32 + ((i2 + 31) & 31)];
-          const float peak2 = i2 + 0.5f * (v1 - v2) / (2.0f * maxval2 - v1 - v2);
-          atomicMax(&cnt[2 * octave + 1], cnt[2 * octave + 0]);
-          const unsigned idx = atomicAdd(&cnt[2 * octave + 1], 1u);
-          if (idx < (unsigned)max_pts) {
-            sift[idx].xpos = sift[bx].xpos;
-            sift[idx].ypos = sift[bx].ypos;
-            sift[idx].scale = sift[bx].scale;
-            sift[idx].sharpness = sift[bx].sharpness;
-            sift[idx].edgeness = sift[bx].edgeness;
-            sift[idx].orientation = 11.25f * (peak2 < 0.0f ? peak2 + 32.0f : peak2);
-            sift[idx].subsampling = sift[bx].subsampling;
-          } else {
-            atomicAdd(&cnt[CNT_PTOVF], 1u);
-          }
+      sift[bx].orientation = r.ori1;
+      if (r.has2) {                                     // duplicate with the second orientation (cudaSiftD.cu:1038-1052)
+        atomicMax(&cnt[2 * octave + 1], cnt[2 * octave + 0]);
+        const unsigned idx = atomicAdd(&cnt[2 * octave + 1], 1u);
+        if (idx < (unsigned)max_pts) {
+          sift[idx].xpos = sift[bx].xpos;
+          sift[idx].ypos = sift[bx].ypos;
+          sift[idx].scale = sift[bx].scale;
+          sift[idx].sharpness = sift[bx].sharpness;
+          sift[idx].edgeness = sift[bx].edgeness;
+          sift[idx].orientation = r.ori2;
+          sift[idx].subsampling = sift[bx].subsampling;
+        } else {
+          atomicAdd(&cnt[CNT_PTOVF], 1u);
         }
       }
     }
-    wave_sync();
   }
 }
 
@@ -163,13 +178,94 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
 // Descriptor accumulation without LDS atomics.  Phase 1: every lane evaluates 4 of the 256 rotated
 // samples and stores (iangf*grad, angf*grad, angi) into a 20x20 zero-bordered table in LDS.  Phase 2
 // is output-centric: lane = (cell c = lane>>2, angle bins a and a+4); the 8x8 samples whose trilinear
-// footprint reaches cell c are read back (fully unrolled, immediate LDS offsets, border slots read
-// as zero) and accumulated in two registers.  Same votes as cudaSiftD.cu:346-386, summed in a
-// different order (the reference's shared-memory atomics have no defined order either).
+// footprint reaches cell c are read back (immediate LDS offsets, border slots read as zero) and
+// accumulated in two registers.  Same votes as cudaSiftD.cu:346-386, summed in a different order (the
+// reference's shared-memory atomics have no defined order either).
 #define SMP_W 20
 __device__ __forceinline__ float spatial_w(int m)      // horf/verf for m<4, 1-horf/1-verf for m>=4
 {
   return m < 4 ? (m + 0.5f) * 0.25f : (7.5f - m) * 0.25f;
+}
+
+__device__ __forceinline__ void descr_init(float4 *smp, float *gauss, int lane)
+{
+  if (lane < 16) gauss[lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
+  for (int i = lane; i < SMP_W * SMP_W; i += 64) smp[i] = make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // border stays zero
+}
+
+// Normalised descriptor bins (8*cell + (lane&3)) and (+4) of one keypoint, cell = lane >> 2.
+__device__ __forceinline__ void descr_core(const float *img, int w, int h, int pitch, bool q8, float px, float py,
+                                           float pscale, float orientation, float4 *smp, const float *gauss,
+                                           int lane, float &out0, float &out1)
+{
+  const int cell = lane >> 2, cx = cell & 3, cy = cell >> 2;
+  const float a0 = (float)(lane & 3), a1 = a0 + 4.0f;
+  const float am0 = (lane & 3) == 0 ? 7.0f : a0 - 1.0f;      // angi whose angp lands on a0 (7 and 8 both wrap to 0)
+  const float am1 = a1 - 1.0f;
+  const bool a0_is0 = (lane & 3) == 0;
+  const float4 *cellbase = smp + (4 * cy) * SMP_W + 4 * cx;   // table slot of sample (tx,y) is (y+2)*20 + tx+2
+  wave_sync();
+  const float theta = 2.0f * 3.1415f / 360.0f * orientation;
+  const float sina = sinf(theta);
+  const float cosa = cosf(theta);
+  const float scale = 12.0f / 16.0f * pscale;
+  const float ssina = scale * sina;
+  const float scosa = scale * cosa;
+  bool has8 = false;
+#pragma unroll
+  for (int rep = 0; rep < 4; rep++) {
+    const int id = lane + 64 * rep;
+    const int tx = id & 15, y = id >> 4;
+    const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
+    const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+    const float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q8) -
+                     tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, q8);
+    const float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, q8) -
+                     tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q8);
+    const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+    float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+    const int angi = (int)angf;
+    angf -= angi;
+    const float iangf = 1.0f - angf;
+    has8 |= angi >= 8;
+    smp[(y + 2) * SMP_W + tx + 2] = make_float4(iangf * grad, angf * grad, (float)angi, 0.0f);
+  }
+  wave_sync();
+  float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 2
+  for (int my = 0; my < 8; my++) {
+    const float wy = spatial_w(my);
+#pragma unroll
+    for (int mx = 0; mx < 8; mx++) {
+      const float4 e = cellbase[my * SMP_W + mx];
+      const float wgt = wy * spatial_w(mx);
+      const float t0 = (e.z == a0) ? e.x : ((e.z == am0 || (a0_is0 && e.z == 8.0f)) ? e.y : 0.0f);
+      const float t1 = (e.z == a1) ? e.x : ((e.z == am1) ? e.y : 0.0f);
+      acc0 = __builtin_fmaf(wgt, t0, acc0);
+      acc1 = __builtin_fmaf(wgt, t1, acc1);
+    }
+  }
+  if (__any(has8)) {
+    // rare (dy == +0 and dx < 0): angi == 8 makes the iangf vote land in
+    // bin 0 of the NEXT cell of the flattened 4x4 grid; cell 16 does not exist (dropped)
+    if (a0_is0 && cell >= 1) {
+      const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
+      const float4 *pb = smp + (4 * pcy) * SMP_W + 4 * pcx;
+      for (int my = 0; my < 8; my++)
+        for (int mx = 0; mx < 8; mx++) {
+          const float4 e = pb[my * SMP_W + mx];
+          if (e.z == 8.0f) acc0 = __builtin_fmaf(spatial_w(my) * spatial_w(mx), e.x, acc0);
+        }
+    }
+  }
+  // normalise, clamp at 0.2, normalise again (reference cudaSiftD.cu:390-409)
+  const float tsum1 = wave_sum(acc0 * acc0 + acc1 * acc1);
+  const float rs1 = 1.0f / sqrtf(tsum1);
+  const float c0 = fminf(acc0 * rs1, 0.2f), c1 = fminf(acc1 * rs1, 0.2f);
+  const float tsum2 = wave_sum(c0 * c0 + c1 * c1);
+  const float rs2 = 1.0f / sqrtf(tsum2);
+  out0 = c0 * rs2;
+  out1 = c1 * rs2;
 }
 
 __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ base, long long base_frame_stride,
@@ -184,90 +280,128 @@ __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ ba
   const float *img = base + (long long)frame * base_frame_stride;
   const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   SiftPointD *sift = pts + (size_t)frame * max_pts;
-  float4 *smp = s_smp[wave];
-  float *gauss = s_gauss[wave];
   const bool q8 = frac8 != 0;
-  if (lane < 16) gauss[lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
-  for (int i = lane; i < SMP_W * SMP_W; i += 64) smp[i] = make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // border stays zero
-
-  // this lane's output bins
-  const int cell = lane >> 2, cx = cell & 3, cy = cell >> 2;
-  const float a0 = (float)(lane & 3), a1 = a0 + 4.0f;
-  const float am0 = (lane & 3) == 0 ? 7.0f : a0 - 1.0f;      // angi whose angp lands on a0 (7 and 8 both wrap to 0)
-  const float am1 = a1 - 1.0f;
-  const bool a0_is0 = (lane & 3) == 0;
-  const float4 *cellbase = smp + (4 * cy) * SMP_W + 4 * cx;   // table slot of sample (tx,y) is (y+2)*20 + tx+2
+  descr_init(s_smp[wave], s_gauss[wave], lane);
+  const int cell = lane >> 2;
 
   const int fstPts = (int)min(cnt[2 * octave - 1], (unsigned)max_pts);
   const int totPts = (int)min(cnt[2 * octave + 1], (unsigned)max_pts);
   for (int bx = fstPts + blockIdx.x * WAVES_PER_BLOCK + wave; bx < totPts; bx += gridDim.x * WAVES_PER_BLOCK) {
-    wave_sync();
     const float px = sift[bx].xpos, py = sift[bx].ypos, pscale = sift[bx].scale;
-    const float theta = 2.0f * 3.1415f / 360.0f * sift[bx].orientation;
-    const float sina = sinf(theta);
-    const float cosa = cosf(theta);
-    const float scale = 12.0f / 16.0f * pscale;
-    const float ssina = scale * sina;
-    const float scosa = scale * cosa;
-    bool has8 = false;
-#pragma unroll
-    for (int rep = 0; rep < 4; rep++) {
-      const int id = lane + 64 * rep;
-      const int tx = id & 15, y = id >> 4;
-      const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
-      const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
-      const float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q8) -
-                       tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, q8);
-      const float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, q8) -
-                       tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q8);
-      const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
-      float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
-      const int angi = (int)angf;
-      angf -= angi;
-      const float iangf = 1.0f - angf;
-      has8 |= angi >= 8;
-      smp[(y + 2) * SMP_W + tx + 2] = make_float4(iangf * grad, angf * grad, (float)angi, 0.0f);
-    }
-    wave_sync();
-    float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll 2
-    for (int my = 0; my < 8; my++) {
-      const float wy = spatial_w(my);
-#pragma unroll
-      for (int mx = 0; mx < 8; mx++) {
-        const float4 e = cellbase[my * SMP_W + mx];
-        const float wgt = wy * spatial_w(mx);
-        const float t0 = (e.z == a0) ? e.x : ((e.z == am0 || (a0_is0 && e.z == 8.0f)) ? e.y : 0.0f);
-        const float t1 = (e.z == a1) ? e.x : ((e.z == am1) ? e.y : 0.0f);
-        acc0 = __builtin_fmaf(wgt, t0, acc0);
-        acc1 = __builtin_fmaf(wgt, t1, acc1);
-      }
-    }
-    if (__any(has8)) {
-      // rare (dy == +0 and dx < 0): angi == 8 makes the iangf vote land in
-      // bin 0 of the NEXT cell of the flattened 4x4 grid; cell 16 does not exist (dropped)
-      if (a0_is0 && cell >= 1) {
-        const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
-        const float4 *pb = smp + (4 * pcy) * SMP_W + 4 * pcx;
-        for (int my = 0; my < 8; my++)
-          for (int mx = 0; mx < 8; mx++) {
-            const float4 e = pb[my * SMP_W + mx];
-            if (e.z == 8.0f) acc0 = __builtin_fmaf(spatial_w(my) * spatial_w(mx), e.x, acc0);
-          }
-      }
-    }
-    // normalise, clamp at 0.2, normalise again (reference cudaSiftD.cu:390-409)
-    const float tsum1 = wave_sum(acc0 * acc0 + acc1 * acc1);
-    const float rs1 = 1.0f / sqrtf(tsum1);
-    const float c0 = fminf(acc0 * rs1, 0.2f), c1 = fminf(acc1 * rs1, 0.2f);
-    const float tsum2 = wave_sum(c0 * c0 + c1 * c1);
-    const float rs2 = 1.0f / sqrtf(tsum2);
-    sift[bx].data[8 * cell + (lane & 3)] = c0 * rs2;
-    sift[bx].data[8 * cell + (lane & 3) + 4] = c1 * rs2;
+    float o0, o1;
+    descr_core(img, w, h, pitch, q8, px, py, pscale, sift[bx].orientation, s_smp[wave], s_gauss[wave], lane, o0, o1);
+    sift[bx].data[8 * cell + (lane & 3)] = o0;
+    sift[bx].data[8 * cell + (lane & 3) + 4] = o1;
     if (lane == 0) {
       sift[bx].xpos = px * subsampling;
       sift[bx].ypos = py * subsampling;
       sift[bx].scale = pscale * subsampling;
+    }
+  }
+}
+
+// ------------------------------------------------- merged-octave variants
+// One launch each over ALL octaves of ALL frames (instead of one per octave): detections wait in a
+// per-octave staging area (Detection records written by refine_all_kernel); orient_all_kernel adds the
+// orientation(s) and hands out duplicate slots; descr_all_kernel lays the final SiftPoint array out in
+// the reference's segment order  [oct 1 detections | oct 1 duplicates | oct 2 detections | ...]
+// (cudaSiftD.cu:1297-1300, :1038-1044) and writes the reference's 17 counters.
+__device__ __forceinline__ bool flat_to_octave(const unsigned *cnt, int noct, int idx, int &o, int &i, int max_pts)
+{
+  for (int k = 1; k <= noct; k++) {
+    const int n = (int)min(cnt[CNT_DET + k], (unsigned)max_pts);
+    if (idx < n) { o = k; i = idx; return true; }
+    idx -= n;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                         unsigned *__restrict__ counters,
+                                                         Detection *__restrict__ det, int max_pts, int frac8)
+{
+  __shared__ float s_hist[WAVES_PER_BLOCK][64];
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  __shared__ float2 s_smp[WAVES_PER_BLOCK][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
+  const bool q8 = frac8 != 0;
+  if (lane >= 57) s_smp[wave][64 + lane] = make_float2(-1.0f, 0.0f);
+  for (int idx = blockIdx.x * WAVES_PER_BLOCK + wave;; idx += gridDim.x * WAVES_PER_BLOCK) {
+    int o, i;
+    if (!flat_to_octave(cnt, P.noct, idx, o, i, max_pts)) break;
+    const OctaveInfo &L = P.o[o];
+    const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
+    Detection *d = &fdet[(size_t)(o - 1) * max_pts + i];
+    const OrientResult r = orient_core(img, L.w, L.h, L.p, q8, d->xpos, d->ypos, d->scale, s_hist[wave],
+                                       s_gauss[wave], s_smp[wave], lane);
+    if (lane == 0) {
+      d->ori1 = r.ori1;
+      d->ori2 = r.ori2;
+      d->dupslot = r.has2 ? (int)atomicAdd(&cnt[CNT_DUP + o], 1u) : -1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                        unsigned *__restrict__ counters,
+                                                        const Detection *__restrict__ det,
+                                                        SiftPointD *__restrict__ pts, int max_pts, int frac8)
+{
+  __shared__ float4 s_smp[WAVES_PER_BLOCK][SMP_W * SMP_W];
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
+  SiftPointD *sift = pts + (size_t)frame * max_pts;
+  const bool q8 = frac8 != 0;
+  descr_init(s_smp[wave], s_gauss[wave], lane);
+  const int cell = lane >> 2;
+  // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
+  if (blockIdx.x == 0 && threadIdx.x == 0) {             // publish the reference's counters (cudaSiftD.cu:14)
+    unsigned b = 0;
+    for (int k = 1; k <= P.noct; k++) {
+      cnt[2 * k - 1] = b;
+      b += cnt[CNT_DET + k];
+      cnt[2 * k] = b;
+      b += cnt[CNT_DUP + k];
+      cnt[2 * k + 1] = b;
+    }
+  }
+  for (int idx = blockIdx.x * WAVES_PER_BLOCK + wave;; idx += gridDim.x * WAVES_PER_BLOCK) {
+    int o, i;
+    if (!flat_to_octave(cnt, P.noct, idx, o, i, max_pts)) break;
+    const OctaveInfo &L = P.o[o];
+    const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
+    const Detection d = fdet[(size_t)(o - 1) * max_pts + i];
+    unsigned bdet = 0, bdup = 0;                          // segment bases of octave o
+    for (int k = 1; k <= o; k++) {
+      bdet = bdup + (k > 1 ? cnt[CNT_DUP + k - 1] : 0u);
+      bdup = bdet + cnt[CNT_DET + k];
+    }
+#pragma unroll 1
+    for (int which = 0; which < 2; which++) {
+      if (which == 1 && d.dupslot < 0) break;
+      const unsigned dst = which == 0 ? bdet + (unsigned)i : bdup + (unsigned)d.dupslot;
+      if (dst >= (unsigned)max_pts) continue;             // capacity: dropped, still counted
+      float o0, o1;
+      descr_core(img, L.w, L.h, L.p, q8, d.xpos, d.ypos, d.scale, which == 0 ? d.ori1 : d.ori2, s_smp[wave],
+                 s_gauss[wave], lane, o0, o1);
+      SiftPointD *p = &sift[dst];
+      p->data[8 * cell + (lane & 3)] = o0;
+      p->data[8 * cell + (lane & 3) + 4] = o1;
+      if (lane == 0) {
+        p->xpos = d.xpos * L.subsampling;
+        p->ypos = d.ypos * L.subsampling;
+        p->scale = d.scale * L.subsampling;
+        p->sharpness = d.sharpness;
+        p->edgeness = d.edgeness;
+        p->orientation = which == 0 ? d.ori1 : d.ori2;
+        p->subsampling = L.subsampling;
+      }
     }
   }
 }
@@ -311,6 +445,23 @@ int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride
   hipLaunchKernelGGL(descr_kernel, dim3(points_grid_x(ctx, nframes), nframes), dim3(256), 0, ctx->stream, base,
                      base_frame_stride, w, h, pitch, subsampling, octave, ctx->d_counters, pts, max_pts,
                      ctx->opt.texfrac_bits == 8 ? 1 : 0);
+  return ls.finish();
+}
+
+int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts)
+{
+  (void)pts;
+  LaunchScope ls(ctx, "orient_all");
+  hipLaunchKernelGGL(orient_all_kernel, dim3(points_grid_x(ctx, P.nframes), P.nframes), dim3(256), 0, ctx->stream,
+                     scratch, P, ctx->d_counters, ctx->d_det, max_pts, ctx->opt.texfrac_bits == 8 ? 1 : 0);
+  return ls.finish();
+}
+
+int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts)
+{
+  LaunchScope ls(ctx, "descr_all");
+  hipLaunchKernelGGL(descr_all_kernel, dim3(points_grid_x(ctx, P.nframes), P.nframes), dim3(256), 0, ctx->stream,
+                     scratch, P, ctx->d_counters, ctx->d_det, pts, max_pts, ctx->opt.texfrac_bits == 8 ? 1 : 0);
   return ls.finish();
 }
 

@@ -192,6 +192,7 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   if (ctx->d_counters) hipFree(ctx->d_counters);
   if (ctx->h_counters) hipHostFree(ctx->h_counters);
   if (ctx->d_cand) hipFree(ctx->d_cand);
+  if (ctx->d_det) hipFree(ctx->d_det);
   if (ctx->d_own_scratch) hipFree(ctx->d_own_scratch);
   if (ctx->d_match_tmp) hipFree(ctx->d_match_tmp);
   hipEventDestroy(ctx->ev0);
@@ -247,6 +248,20 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
     HIP_TRY(hipMalloc((void **)&ctx->d_cand, sizeof(unsigned) * cc * nf));
     ctx->cand_cap = cc;
     ctx->cap_frames = nf;
+  }
+  return MISIFT_OK;
+}
+
+static int ensure_det(misift_ctx *ctx, int nframes, int max_pts)
+{
+  if (nframes > ctx->cap_det_frames || max_pts > ctx->det_max_pts) {
+    const int nf = nframes > ctx->cap_det_frames ? nframes : ctx->cap_det_frames;
+    const int mp = max_pts > ctx->det_max_pts ? max_pts : ctx->det_max_pts;
+    if (ctx->d_det) HIP_TRY(hipFree(ctx->d_det));
+    ctx->d_det = nullptr; ctx->cap_det_frames = 0; ctx->det_max_pts = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->d_det, sizeof(Detection) * (size_t)nf * MISIFT_MAX_OCTAVES * mp));
+    ctx->cap_det_frames = nf;
+    ctx->det_max_pts = mp;
   }
   return MISIFT_OK;
 }
@@ -562,19 +577,46 @@ static int extract_impl(misift_ctx *ctx, const float *d_imgs, int nframes, long 
     rc = launch_scaledown(ctx, src.img, g, dst.img, dst.p, SS, k5);
     if (rc) return rc;
   }
+  if (ctx->opt.fused) {
+    // --- merged-octave path: scan / refine / orient / descr each run ONCE over all pyramid levels; the
+    // final array is laid out in the reference's segment order by descr_all_kernel
+    PyramidInfo P;
+    memset(&P, 0, sizeof(P));
+    P.noct = num_octaves; P.nframes = nframes; P.frame_stride = SS;
+    std::vector<LaplaceTaps> tapsv(num_octaves + 1);
+    unsigned off = 0;
+    for (int o = 1; o <= num_octaves; o++) {
+      OctaveInfo &L = P.o[o];
+      L.w = lv[o].w; L.h = lv[o].h; L.p = lv[o].p;
+      L.img_off = (long long)(lv[o].img - d_scratch);
+      L.subsampling = (float)(1 << (num_octaves - o));
+      L.lowest_scale = lowest_scale / L.subsampling;
+      size_t c = (size_t)L.w * L.h / 4;
+      if (c < 16384) c = 16384;
+      L.cand_cap = (unsigned)c;
+      L.cand_off = off;
+      off += L.cand_cap;
+      tapsv[o] = octave_taps(table, o);
+    }
+    rc = misift_ensure_frames(ctx, nframes, off);
+    if (rc) return rc;
+    // the staging area is indexed with the CURRENT max_pts (kernels use it as the per-octave stride)
+    rc = ensure_det(ctx, nframes, max_pts);
+    if (rc) return rc;
+    rc = launch_dog_scan_all(ctx, d_scratch, P, tapsv.data(), thresh);
+    if (rc) return rc;
+    rc = launch_refine_all(ctx, d_scratch, P, tapsv.data(), thresh, 10.0f, 1.0f / NUM_SCALES, max_pts);
+    if (rc) return rc;
+    rc = launch_orient_all(ctx, d_scratch, P, pts, max_pts);
+    if (rc) return rc;
+    return launch_descr_all(ctx, d_scratch, P, pts, max_pts);
+  }
   // --- octaves, coarsest first (cudaSiftH.cu:161 after the recursion)
   for (int o = 1; o <= num_octaves; o++) {
     const Level &L = lv[o];
     const float subsampling = (float)(1 << (num_octaves - o));
     const LaplaceTaps taps = octave_taps(table, o);
-    if (ctx->opt.fused) {
-      StripGeom g = make_geom(ctx, L.w, L.h, L.p, nframes, SS, L.w, L.h, 60);
-      rc = launch_dog_scan(ctx, L.img, g, taps, thresh, o);
-      if (rc) return rc;
-      rc = launch_refine(ctx, nullptr, 0, L.img, SS, &taps, L.w, L.h, L.p, nframes, thresh, 10.0f, 1.0f / NUM_SCALES,
-                         lowest_scale / subsampling, subsampling, o, pts, max_pts);
-      if (rc) return rc;
-    } else {
+    {
       StripGeom g = make_geom(ctx, L.w, L.h, L.p, nframes, SS, L.w, L.h, 62);
       rc = launch_laplace(ctx, L.img, g, memoryTmp, SS, taps);
       if (rc) return rc;
