@@ -62,6 +62,7 @@ struct StripGeom {
   int nstrips, nsegs, seg_rows;    // decomposition
   int nframes;
   long long frame_stride;          // floats between frames of the source
+  int noremap;                     // 1 = keep the hardware's block order (no XCD remap)
 };
 
 // ---------------------------------------------------------------- device helpers

@@ -30,7 +30,7 @@ struct ItemCoord { int frame, strip, seg; bool valid; };
 
 __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
 {
-  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lb = g.noremap ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   // the wave index is wave-uniform: keep it (and everything derived from it — frame, strip, segment,
   // row bounds, row pointers) in SGPRs.  Besides cheaper scalar loop control this keeps the loop bounds
   // out of reach of VGPR live-range splitting around divergent regions.
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
 // ------------------------------------------------------- fused DoG + scan
 // dog_scan_kernel: blur -> DoG in registers (nothing but the base image is read, nothing but
 // a short candidate list is written) and a cheap NECESSARY test per pixel and scale:
-//   |v| > thresh  and  v is a strict extremum of its 8 neighbours IN THE SAME ROW
-//   (3 planes x 3 columns).
+//   |v| > thresh  and  v is a strict extremum of its neighbours IN THE SAME ROW
+//   (3 columns of the centre plane and of the adjacent centre planes).
 // Survivors ("pre-candidates", typically < 0.1 % of the pixels) go to the frame's candidate
 // list; refine_kernel<true> recomputes their 3x3x3 DoG neighbourhood bit-identically and
 // applies the reference's full 26-neighbour test (cudaSiftD.cu:1337-1360) before refining.
@@ -366,44 +366,49 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
     asm volatile("" ::: "memory");
     const Quad2 c = q2(r4), p1 = add_q2(q2(r3), q2(r5)), p2 = add_q2(q2(r2), q2(r6)), p3 = add_q2(q2(r1), q2(r7)),
                 p4 = add_q2(q2(r0), q2(r8));
-    float4 d[NUM_DOG];
+    // Only blurs 1..6 are computed here: they give the five centre DoG planes d[0..4] (= reference planes
+    // 1..5), which is all the necessary condition below needs; the outermost planes 0 and 6 (blurs 0 and 7)
+    // are evaluated only for the survivors, by refine.  A quarter of the blur work of the dense path is saved.
+    float4 d[NUM_SCALES];
     // tap pairs of scale s+1 are fetched from LDS while scale s is computed
-    Taps2 tcur = load_taps2(tk), tnext = load_taps2(tk + 5);
+    Taps2 tcur = load_taps2(tk + 5), tnext = load_taps2(tk + 10);
     __builtin_amdgcn_sched_barrier(0);
     Quad2 old = blur_quad2(tcur, c, p1, p2, p3, p4);
 #pragma unroll
-    for (int s = 1; s < NUM_BLURS; s++) {
+    for (int s = 2; s < NUM_BLURS - 1; s++) {
       tcur = tnext;
-      asm volatile("" ::: "memory");            // re-read from LDS: do not pin 80 VGPRs across the row loop
-      if (s + 1 < NUM_BLURS) tnext = load_taps2(tk + 5 * (s + 1));
+      asm volatile("" ::: "memory");            // re-read from LDS: do not pin the tap pairs across the row loop
+      if (s + 1 < NUM_BLURS - 1) tnext = load_taps2(tk + 5 * (s + 1));
       __builtin_amdgcn_sched_barrier(0);        // prefetch stays ahead of the math that hides it
       const Quad2 res = blur_quad2(tcur, c, p1, p2, p3, p4);
-      d[s - 1] = sub_q2(res, old);
+      d[s - 2] = sub_q2(res, old);
       old = res;
     }
     float amax = 0.0f;
 #pragma unroll
-    for (int p = 1; p <= NUM_SCALES; p++)
+    for (int p = 0; p < NUM_SCALES; p++)
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(d[p].x), fabsf(d[p].y)), fmaxf(fabsf(d[p].z), fabsf(d[p].w))));
     // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
     if (y >= 1 && y <= g.height - 2 && __any(amax > thresh)) {
       unsigned mask = 0;
 #pragma unroll
       for (int s = 0; s < NUM_SCALES; s++) {
-        // in-row neighbourhood of centre plane s+1: planes s, s+1, s+2, columns x-1, x, x+1
+        // in-row neighbourhood of centre plane d[s]: columns x-1, x, x+1 of d[s-1], d[s], d[s+1] (where available)
         float lo[4], hi[4];
 #pragma unroll
-        for (int dp = 0; dp < 3; dp += 2) {                    // planes below and above: full 3-column rows
+        for (int i = 0; i < 4; i++) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+#pragma unroll
+        for (int dp = -1; dp <= 1; dp += 2) {
+          if (s + dp < 0 || s + dp >= NUM_SCALES) continue;
           const float4 e = d[s + dp];
           const float v[6] = {lane_from_left(e.w), e.x, e.y, e.z, e.w, lane_from_right(e.x)};
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            const float mn = min3f(v[i], v[i + 1], v[i + 2]), mx = max3f(v[i], v[i + 1], v[i + 2]);
-            lo[i] = dp == 0 ? mn : fminf(lo[i], mn);
-            hi[i] = dp == 0 ? mx : fmaxf(hi[i], mx);
+            lo[i] = fminf(lo[i], min3f(v[i], v[i + 1], v[i + 2]));
+            hi[i] = fmaxf(hi[i], max3f(v[i], v[i + 1], v[i + 2]));
           }
         }
-        const float4 c = d[s + 1];
+        const float4 c = d[s];
         const float v[6] = {lane_from_left(c.w), c.x, c.y, c.z, c.w, lane_from_right(c.x)};
 #pragma unroll
         for (int i = 0; i < 4; i++) {

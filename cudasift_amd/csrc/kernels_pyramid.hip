@@ -23,7 +23,7 @@ struct ItemCoord { int frame, strip, seg; bool valid; };
 
 __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
 {
-  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lb = g.noremap ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   // the wave index is wave-uniform: keep it (and everything derived from it — frame, strip, segment,
   // row bounds, row pointers) in SGPRs.  Besides cheaper scalar loop control this keeps the loop bounds
   // out of reach of VGPR live-range splitting around divergent regions.

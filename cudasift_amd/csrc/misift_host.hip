@@ -462,6 +462,8 @@ static StripGeom make_geom(misift_ctx *ctx, int w, int h, int pitch, int nframes
   g.seg_rows = seg;
   g.nsegs = (out_rows + seg - 1) / seg;
   if (g.nsegs < 1) g.nsegs = 1;
+  static const int noremap = getenv("MISIFT_NOREMAP") ? atoi(getenv("MISIFT_NOREMAP")) : 0;
+  g.noremap = noremap;
   return g;
 }
 
