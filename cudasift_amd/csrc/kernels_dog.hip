@@ -30,7 +30,7 @@ struct ItemCoord { int frame, strip, seg; bool valid; };
 
 __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
 {
-  const unsigned lb = g.noremap ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lb = (g.noremap & 1) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   // the wave index is wave-uniform: keep it (and everything derived from it — frame, strip, segment,
   // row bounds, row pointers) in SGPRs.  Besides cheaper scalar loop control this keeps the loop bounds
   // out of reach of VGPR live-range splitting around divergent regions.
@@ -39,10 +39,17 @@ __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
   const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
   ItemCoord c;
   c.valid = item < nitems;
-  c.seg = (int)(item % g.nsegs);
-  const long long r = item / g.nsegs;
-  c.strip = (int)(r % g.nstrips);
-  c.frame = (int)(r / g.nstrips);
+  if (g.noremap & 2) {             // strip-fastest: the 4 waves of a workgroup read 4 KB contiguous per row
+    c.strip = (int)(item % g.nstrips);
+    const long long r = item / g.nstrips;
+    c.seg = (int)(r % g.nsegs);
+    c.frame = (int)(r / g.nsegs);
+  } else {
+    c.seg = (int)(item % g.nsegs);
+    const long long r = item / g.nsegs;
+    c.strip = (int)(r % g.nstrips);
+    c.frame = (int)(r / g.nstrips);
+  }
   return c;
 }
 

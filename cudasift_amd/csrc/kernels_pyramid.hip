@@ -23,7 +23,7 @@ struct ItemCoord { int frame, strip, seg; bool valid; };
 
 __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
 {
-  const unsigned lb = g.noremap ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lb = (g.noremap & 1) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   // the wave index is wave-uniform: keep it (and everything derived from it — frame, strip, segment,
   // row bounds, row pointers) in SGPRs.  Besides cheaper scalar loop control this keeps the loop bounds
   // out of reach of VGPR live-range splitting around divergent regions.
@@ -32,10 +32,17 @@ __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
   const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
   ItemCoord c;
   c.valid = item < nitems;
-  c.seg = (int)(item % g.nsegs);
-  const long long r = item / g.nsegs;
-  c.strip = (int)(r % g.nstrips);
-  c.frame = (int)(r / g.nstrips);
+  if (g.noremap & 2) {             // strip-fastest: the 4 waves of a workgroup read 4 KB contiguous per row
+    c.strip = (int)(item % g.nstrips);
+    const long long r = item / g.nstrips;
+    c.seg = (int)(r % g.nsegs);
+    c.frame = (int)(r / g.nsegs);
+  } else {
+    c.seg = (int)(item % g.nsegs);
+    const long long r = item / g.nsegs;
+    c.strip = (int)(r % g.nstrips);
+    c.frame = (int)(r / g.nstrips);
+  }
   return c;
 }
 
@@ -55,7 +62,7 @@ __device__ __forceinline__ void store_quad(float *row, int q, int width, bool al
 // ------------------------------------------------------------------ LowPass
 // out = G9^T (vertical) applied to G9 (horizontal) applied to in, clamp-to-edge.
 template <bool FAST>
-__global__ __launch_bounds__(256) void lowpass_kernel(const float *__restrict__ src, StripGeom g,
+__global__ __launch_bounds__(256, 4) void lowpass_kernel(const float *__restrict__ src, StripGeom g,
                                                       float *__restrict__ dst, int dpitch,
                                                       long long dst_frame_stride, Taps5 t, int src_aligned,
                                                       int dst_aligned)
@@ -89,12 +96,15 @@ __global__ __launch_bounds__(256) void lowpass_kernel(const float *__restrict__ 
 
   float4 w0 = hrow(y0 - 4), w1 = hrow(y0 - 3), w2 = hrow(y0 - 2), w3 = hrow(y0 - 1), w4 = hrow(y0);
   float4 w5 = hrow(y0 + 1), w6 = hrow(y0 + 2), w7 = hrow(y0 + 3), w8;
-  float4 raw = ldraw(y0 + 4);
+  // two rows of loads stay in flight per wavefront: with ~4 resident waves per SIMD one row ahead only
+  // keeps ~4 MB in flight chip-wide, which caps the stream near 4 TB/s at ~1 us of HBM latency
+  float4 raw = ldraw(y0 + 4), raw1 = ldraw(y0 + 5);
   const bool writer = lane >= 1 && lane <= OUT_LANES && 4 * q < g.width;
   for (int y = y0; y < y1; y++) {
-    const float4 rawnext = ldraw(y + 5);         // prefetch one row ahead of the horizontal filter
+    const float4 rawnext = ldraw(y + 6);
     w8 = hfilt(raw);
-    raw = rawnext;
+    raw = raw1;
+    raw1 = rawnext;
     float4 o;
     o.x = conv9(k0, k1, k2, k3, k4, w4.x, w3.x + w5.x, w2.x + w6.x, w1.x + w7.x, w0.x + w8.x);
     o.y = conv9(k0, k1, k2, k3, k4, w4.y, w3.y + w5.y, w2.y + w6.y, w1.y + w7.y, w0.y + w8.y);
@@ -161,12 +171,12 @@ __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict_
   const bool writer = lane >= 1 && lane <= OUT_LANES && 4 * q < w2;
   const bool fast_store = FAST && (w2 & 3) == 0 && dal;
   float4 t0 = hrow(2 * y0 - 2), t1 = hrow(2 * y0 - 1), t2 = hrow(2 * y0), t3, t4;
-  Raw2 ra = ldraw(2 * y0 + 1), rb = ldraw(2 * y0 + 2);
+  Raw2 ra = ldraw(2 * y0 + 1), rb = ldraw(2 * y0 + 2), rc = ldraw(2 * y0 + 3), rd = ldraw(2 * y0 + 4);
   for (int y = y0; y < y1; y++) {
-    const Raw2 na = ldraw(2 * y + 3), nb = ldraw(2 * y + 4);    // prefetch the next output row's two input rows
+    const Raw2 na = ldraw(2 * y + 5), nb = ldraw(2 * y + 6);    // prefetch two output rows (four input rows) ahead
     t3 = hfilt(ra);
     t4 = hfilt(rb);
-    ra = na; rb = nb;
+    ra = rc; rb = rd; rc = na; rd = nb;
     float4 o;
     o.x = vcomb(t0.x, t1.x, t2.x, t3.x, t4.x);
     o.y = vcomb(t0.y, t1.y, t2.y, t3.y, t4.y);
