@@ -195,6 +195,23 @@ def main():
             a = alg[k] * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
             hbm_kernels[k] = {"achieved": round(a, 1), "frac": round(a / HBM_PEAK_GBS, 4)}
     roofline["hbm_bound_kernels"] = hbm_kernels
+    # achievable-copy ceiling: device-to-device copy of 1 GiB, read + write bytes counted
+    if rank == 0:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=device)
+        b = torch.empty_like(a)
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+        roofline["copy_ceiling_GBps"] = round(copy_gbs, 1)
+        for k in hbm_kernels:
+            hbm_kernels[k]["frac_of_copy_ceiling"] = round(hbm_kernels[k]["achieved"] / copy_gbs, 4)
 
     # ---------------- PCIe-inclusive side measurement (never `value`): pinned host frames -> H2D -> extract -> D2H
     pcie = None

@@ -214,6 +214,7 @@ struct misift_ctx {
 
 void misift_set_error(const char *fmt, ...);
 int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap);
+int misift_ensure_tmp(misift_ctx *ctx, size_t bytes);
 
 #define HIP_TRY(expr)                                                                        \
   do {                                                                                       \

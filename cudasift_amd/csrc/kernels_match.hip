@@ -256,11 +256,9 @@ int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count
   nchunks = G.ntiles > 0 ? (G.ntiles + G.tiles_per_chunk - 1) / G.tiles_per_chunk : 1;
   G.nchunks = nchunks;
   const size_t need = (size_t)row_count * nchunks * MT_PART_WORDS * sizeof(float);
-  if (need > ctx->match_tmp_bytes) {
-    if (ctx->d_match_tmp) HIP_TRY(hipFree(ctx->d_match_tmp));
-    ctx->d_match_tmp = nullptr; ctx->match_tmp_bytes = 0;
-    HIP_TRY(hipMalloc(&ctx->d_match_tmp, need));
-    ctx->match_tmp_bytes = need;
+  {
+    int rc = misift_ensure_tmp(ctx, need);
+    if (rc) return rc;
   }
   float *partial = reinterpret_cast<float *>(ctx->d_match_tmp);
   {

@@ -252,6 +252,21 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
   return MISIFT_OK;
 }
 
+// grow-only temporary device buffer shared by the matcher (chunk partials) and the homography search
+int misift_ensure_tmp(misift_ctx *ctx, size_t bytes)
+{
+  if (bytes > ctx->match_tmp_bytes) {
+    if (ctx->d_match_tmp) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(hipFree(ctx->d_match_tmp));
+    }
+    ctx->d_match_tmp = nullptr; ctx->match_tmp_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->d_match_tmp, bytes));
+    ctx->match_tmp_bytes = bytes;
+  }
+  return MISIFT_OK;
+}
+
 static int ensure_det(misift_ctx *ctx, int nframes, int max_pts)
 {
   if (nframes > ctx->cap_det_frames || max_pts > ctx->det_max_pts) {

@@ -71,6 +71,8 @@ def lib():
         L.orc_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
         L.orc_match_rows.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
         L.orc_match_argmax.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+        L.orc_find_homography.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.c_float]
+        L.orc_find_homography.restype = C.c_int
         L.orc_stats_get.argtypes = [C.POINTER(OrcStats)]
         L.orc_sizeof_point.restype = C.c_int
         assert L.orc_sizeof_point() == 576
@@ -200,6 +202,20 @@ def match_argmax(a, b):
     index = np.zeros(a.shape[0], np.int32)
     lib().orc_match_argmax(_p(a), a.shape[0], _p(b), b.shape[0], _p(score), _p(index))
     return score, index
+
+
+def find_homography(pts, npts, num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0):
+    """FindHomography on a structured SiftPoint array; consumes libc rand() like the reference.
+    Returns (H 3x3, inlier count, winning loop index)."""
+    H = (C.c_float * 9)()
+    nm = C.c_int(0)
+    best = lib().orc_find_homography(_p(pts), npts, H, C.byref(nm), num_loops, min_score, max_ambiguity, thresh)
+    return np.array(list(H), np.float32).reshape(3, 3), nm.value, best
+
+
+def srand(seed):
+    """Seed the process-wide libc rand() that FindHomography (oracle and HIP host side) draws from."""
+    C.CDLL(None).srand(C.c_uint(seed))
 
 
 def stats():

@@ -781,3 +781,170 @@ void orc_match_argmax(const float *pts1, int n1, const float *pts2, int n2, floa
     index[p1] = bi;
   }
 }
+
+/* ------------------------------------------------------------------ FindHomography
+ * RANSAC homography over the matches stored in a SiftPoint array.  Follows
+ * FindHomography (matching.cu:1000-1087): valid points = score > minScore &&
+ * ambiguity < maxAmbiguity (:1033-1037); numLoops rounded up to 16 (:1013); per loop
+ * four distinct valid points drawn with libc rand() in the order of :1041-1053;
+ * hypothesis = inverse(A)·b with the 8x8 matrix of ComputeHomographies (:907-948)
+ * inverted by InvertMatrix<8> (:821-905: Crout LU, implicit row scaling, one
+ * forward/back substitution per unit vector); inliers counted over ALL numPts points
+ * with TestHomographies' round-toward-zero products (:971-984); winner = first loop
+ * with the largest count (:1063-1068).
+ * Contraction: a·b accumulated into sum (":sum -= a*b", "sum += a*b") is one fmaf, as
+ * nvcc contracts it; __fmul_rz products are never contracted.
+ * Deviation: the reference counts over numPts rounded up to 16, i.e.
+ * reads up to 15 uninitialised coordinates; exactly numPts points are tested here. */
+static float mul_rz(float a, float b)
+{
+  float p = a * b;
+  float e = fmaf(a, b, -p);                 /* exact residual of the RN product */
+  if ((p > 0.0f && e < 0.0f) || (p < 0.0f && e > 0.0f)) {
+    uint32_t u;
+    memcpy(&u, &p, 4);
+    u -= 1u;                                /* one ulp toward zero */
+    memcpy(&p, &u, 4);
+  }
+  return p;
+}
+
+static void invert8(float a[8][8], float res[8][8])
+{
+  int indx[8];
+  float vv[8], col[8];
+  int imax = 0;
+  for (int i = 0; i < 8; i++) {
+    float big = 0.0f;
+    for (int j = 0; j < 8; j++) {
+      float t = fabsf(a[i][j]);
+      if (t > big) big = t;
+    }
+    vv[i] = big > 0.0f ? 1.0f / big : 1e16f;
+  }
+  for (int j = 0; j < 8; j++) {
+    for (int i = 0; i < j; i++) {
+      float sum = a[i][j];
+      for (int k = 0; k < i; k++) sum = fmaf(-a[i][k], a[k][j], sum);
+      a[i][j] = sum;
+    }
+    float big = 0.0f;
+    for (int i = j; i < 8; i++) {
+      float sum = a[i][j];
+      for (int k = 0; k < j; k++) sum = fmaf(-a[i][k], a[k][j], sum);
+      a[i][j] = sum;
+      float dum = vv[i] * fabsf(sum);
+      if (dum >= big) { big = dum; imax = i; }
+    }
+    if (j != imax) {
+      for (int k = 0; k < 8; k++) { float t = a[imax][k]; a[imax][k] = a[j][k]; a[j][k] = t; }
+      vv[imax] = vv[j];
+    }
+    indx[j] = imax;
+    if (a[j][j] == 0.0f) a[j][j] = 1e-16f;
+    if (j != 7) {
+      float dum = 1.0f / a[j][j];
+      for (int i = j + 1; i < 8; i++) a[i][j] *= dum;
+    }
+  }
+  for (int j = 0; j < 8; j++) {
+    for (int k = 0; k < 8; k++) col[k] = 0.0f;
+    col[j] = 1.0f;
+    int ii = -1;
+    for (int i = 0; i < 8; i++) {
+      int ip = indx[i];
+      float sum = col[ip];
+      col[ip] = col[i];
+      if (ii != -1) {
+        for (int k = ii; k < i; k++) sum = fmaf(-a[i][k], col[k], sum);
+      } else if (sum != 0.0f) {
+        ii = i;
+      }
+      col[i] = sum;
+    }
+    for (int i = 7; i >= 0; i--) {
+      float sum = col[i];
+      for (int k = i + 1; k < 8; k++) sum = fmaf(-a[i][k], col[k], sum);
+      col[i] = sum / a[i][i];
+    }
+    for (int i = 0; i < 8; i++) res[i][j] = col[i];
+  }
+}
+
+int orc_find_homography(const SiftPoint *pts, int numPts, float *homography, int *numMatches, int numLoops,
+                        float minScore, float maxAmbiguity, float thresh)
+{
+  *numMatches = 0;
+  for (int i = 0; i < 9; i++) homography[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+  if (!pts || numPts < 8) return -1;
+  numLoops = (numLoops + 15) / 16 * 16;
+  int *validPts = (int *)malloc(sizeof(int) * (size_t)numPts);
+  int numValid = 0;
+  for (int i = 0; i < numPts; i++)
+    if (pts[i].score > minScore && pts[i].ambiguity < maxAmbiguity) validPts[numValid++] = i;
+  int bestLoop = -1;
+  if (numValid >= 8) {
+    int *sel = (int *)malloc(sizeof(int) * 4 * (size_t)numLoops);
+    for (int i = 0; i < numLoops; i++) {
+      int p1 = rand() % numValid;
+      int p2 = rand() % numValid;
+      int p3 = rand() % numValid;
+      int p4 = rand() % numValid;
+      while (p2 == p1) p2 = rand() % numValid;
+      while (p3 == p1 || p3 == p2) p3 = rand() % numValid;
+      while (p4 == p1 || p4 == p2 || p4 == p3) p4 = rand() % numValid;
+      sel[4 * i + 0] = validPts[p1];
+      sel[4 * i + 1] = validPts[p2];
+      sel[4 * i + 2] = validPts[p3];
+      sel[4 * i + 3] = validPts[p4];
+    }
+    float *homo = (float *)malloc(sizeof(float) * 8 * (size_t)numLoops);
+    int *counts = (int *)malloc(sizeof(int) * (size_t)numLoops);
+    const float thresh2 = thresh * thresh;
+#pragma omp parallel for schedule(static)
+    for (int loop = 0; loop < numLoops; loop++) {
+      float a[8][8], ia[8][8], b[8];
+      for (int i = 0; i < 4; i++) {
+        const SiftPoint *p = &pts[sel[4 * loop + i]];
+        float x1 = p->xpos, y1 = p->ypos, x2 = p->match_xpos, y2 = p->match_ypos;
+        float *r1 = a[2 * i], *r2 = a[2 * i + 1];
+        r1[0] = x1; r1[1] = y1; r1[2] = 1.0f; r1[3] = r1[4] = r1[5] = 0.0f;
+        r1[6] = -x2 * x1; r1[7] = -x2 * y1;
+        r2[0] = r2[1] = r2[2] = 0.0f; r2[3] = x1; r2[4] = y1; r2[5] = 1.0f;
+        r2[6] = -y2 * x1; r2[7] = -y2 * y1;
+        b[2 * i] = x2;
+        b[2 * i + 1] = y2;
+      }
+      invert8(a, ia);
+      float *h = homo + 8 * (size_t)loop;
+      for (int j = 0; j < 8; j++) {
+        float sum = 0.0f;
+        for (int i = 0; i < 8; i++) sum = fmaf(ia[j][i], b[i], sum);
+        h[j] = sum;
+      }
+      int cnt = 0;
+      for (int i = 0; i < numPts; i++) {
+        float x1 = pts[i].xpos, y1 = pts[i].ypos, x2 = pts[i].match_xpos, y2 = pts[i].match_ypos;
+        float nomx = mul_rz(h[0], x1) + mul_rz(h[1], y1) + h[2];
+        float nomy = mul_rz(h[3], x1) + mul_rz(h[4], y1) + h[5];
+        float deno = mul_rz(h[6], x1) + mul_rz(h[7], y1) + 1.0f;
+        float errx = mul_rz(x2, deno) - nomx;
+        float erry = mul_rz(y2, deno) - nomy;
+        float err2 = mul_rz(errx, errx) + mul_rz(erry, erry);
+        if (err2 < mul_rz(thresh2, mul_rz(deno, deno))) cnt++;
+      }
+      counts[loop] = cnt;
+    }
+    int maxCount = -1;
+    for (int i = 0; i < numLoops; i++)
+      if (counts[i] > maxCount) { maxCount = counts[i]; bestLoop = i; }
+    *numMatches = maxCount;
+    memcpy(homography, homo + 8 * (size_t)bestLoop, 8 * sizeof(float));
+    homography[8] = 1.0f;
+    free(counts);
+    free(homo);
+    free(sel);
+  }
+  free(validPts);
+  return bestLoop;
+}

@@ -46,3 +46,28 @@ def descriptors_to_points(d, dtype):
     pts["ypos"] = np.arange(d.shape[0], dtype=np.float32) // 1920
     pts["match"] = -2
     return pts
+
+
+def synth_matches(n, inlier_frac=0.6, seed=0, width=1920, height=1080, noise=0.7, dtype=None):
+    """A SiftPoint array whose stored matches follow a known homography for `inlier_frac` of the
+    points (plus `noise` px jitter) and are random for the rest; scores/ambiguities are mixed so
+    that FindHomography's validity filter (matching.cu:1033-1037) selects an ordered subset.
+    Returns (points, H_true 3x3, inlier mask)."""
+    from cudasift_amd.capi import POINT_DTYPE
+    rng = np.random.default_rng(seed)
+    pts = np.zeros(n, dtype or POINT_DTYPE)
+    x = rng.uniform(0, width, n).astype(np.float32)
+    y = rng.uniform(0, height, n).astype(np.float32)
+    H = np.array([[0.98, 0.03, 14.0], [-0.025, 1.01, -9.0], [1.5e-5, -1.0e-5, 1.0]], np.float64)
+    den = H[2, 0] * x + H[2, 1] * y + 1.0
+    mx = (H[0, 0] * x + H[0, 1] * y + H[0, 2]) / den
+    my = (H[1, 0] * x + H[1, 1] * y + H[1, 2]) / den
+    inl = rng.uniform(size=n) < inlier_frac
+    mx = np.where(inl, mx + rng.normal(0, noise, n), rng.uniform(0, width, n))
+    my = np.where(inl, my + rng.normal(0, noise, n), rng.uniform(0, height, n))
+    pts["xpos"], pts["ypos"] = x, y
+    pts["match_xpos"], pts["match_ypos"] = mx.astype(np.float32), my.astype(np.float32)
+    pts["score"] = np.where(inl, rng.uniform(0.86, 1.0, n), rng.uniform(0.5, 1.0, n)).astype(np.float32)
+    pts["ambiguity"] = np.where(inl, rng.uniform(0.3, 0.99, n), rng.uniform(0.6, 1.0, n)).astype(np.float32)
+    pts["match"] = rng.integers(0, max(n, 1), n)
+    return pts, H.astype(np.float32), inl

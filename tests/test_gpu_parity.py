@@ -365,3 +365,46 @@ def test_homography_from_matches(ctx, stereo):
     frac = float((ex * ex + ey * ey < 25.0).mean())
     record("homography", reprojected_within_5px=frac)
     assert frac > 0.5
+
+
+@pytest.mark.parametrize("n,loops,seed", [(1500, 1000, 1), (777, 10000, 2), (40, 50, 3), (5000, 2000, 4)])
+def test_find_homography_bit_exact_vs_oracle(ctx, n, loops, seed):
+    """GPU FindHomography (gather / solve / count / pick kernels) against orc_find_homography with the
+    same libc rand() state: H (8 floats) and the inlier count must be bit-identical."""
+    from synth import synth_matches
+    pts, _, inl = synth_matches(n, inlier_frac=0.55, seed=seed)
+    orc().srand(seed)
+    Ho, co, _ = orc().find_homography(pts, n, num_loops=loops, min_score=0.85, max_ambiguity=0.95, thresh=5.0)
+    d = ctx.upload(pts)
+    orc().srand(seed)
+    Hg, cg = ctx.find_homography(d.ptr, n, num_loops=loops, min_score=0.85, max_ambiguity=0.95, thresh=5.0)
+    record("homography_parity", n=n, loops=loops, inliers_oracle=co, inliers_hip=cg,
+           H_equal=bool(np.array_equal(Ho, Hg)))
+    assert cg == co
+    assert np.array_equal(Ho.view(np.uint32), Hg.view(np.uint32))
+    assert co >= 0.8 * inl.sum()
+
+
+def test_find_homography_degenerate(ctx):
+    from synth import synth_matches
+    pts, _, _ = synth_matches(64, seed=5)
+    d = ctx.upload(pts)
+    H, c = ctx.find_homography(d.ptr, 7)
+    assert np.array_equal(H, np.eye(3, dtype=np.float32)) and c == 0
+    pts["score"] = 0.1
+    d = ctx.upload(pts)
+    H, c = ctx.find_homography(d.ptr, 64)
+    assert np.array_equal(H, np.eye(3, dtype=np.float32)) and c == 0
+
+
+def test_find_homography_stereo_vs_oracle(ctx, stereo):
+    """End of the reference demo (mainSift.cpp:72-77): extract, match, FindHomography — vs the oracle chain."""
+    a, na, _ = ctx.extract(stereo[0], thresh=4.5)
+    b, nb, _ = ctx.extract(stereo[1], thresh=4.5)
+    m = ctx.match(a, na, b, nb)
+    d = ctx.upload(m)
+    orc().srand(7)
+    Hg, cg = ctx.find_homography(d.ptr, na, num_loops=10000, min_score=0.0, max_ambiguity=0.80, thresh=5.0)
+    orc().srand(7)
+    Ho, co, _ = orc().find_homography(m, na, num_loops=10000, min_score=0.0, max_ambiguity=0.80, thresh=5.0)
+    assert cg == co and np.array_equal(Ho.view(np.uint32), Hg.view(np.uint32))

@@ -260,3 +260,41 @@ def test_matcher_row_blocks_equal_full():
     orc.match_rows(part, 50, 80, p2, n2)
     for f in ("score", "ambiguity", "match"):
         assert np.array_equal(full[f], part[f])
+
+
+def test_find_homography_recovers_known_transform():
+    """orc_find_homography (matching.cu:1000-1087 restated): on matches generated from a known
+    homography the winning hypothesis reprojects the true inliers and counts (about) all of them."""
+    from synth import synth_matches
+    pts, Ht, inl = synth_matches(1500, inlier_frac=0.6, seed=3)
+    orc.srand(1)
+    H, cnt, best = orc.find_homography(pts, len(pts), num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0)
+    assert H[2, 2] == 1.0 and best >= 0
+    assert cnt >= 0.9 * inl.sum()
+    g = pts[inl]
+    den = H[2, 0] * g["xpos"] + H[2, 1] * g["ypos"] + 1.0
+    ex = (H[0, 0] * g["xpos"] + H[0, 1] * g["ypos"] + H[0, 2]) / den - g["match_xpos"]
+    ey = (H[1, 0] * g["xpos"] + H[1, 1] * g["ypos"] + H[1, 2]) / den - g["match_ypos"]
+    assert ((ex * ex + ey * ey) < 25.0).mean() > 0.9
+    # same rand() state -> same answer; count = independent numpy recount within the rounding band
+    orc.srand(1)
+    H2, cnt2, best2 = orc.find_homography(pts, len(pts), num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0)
+    assert np.array_equal(H, H2) and cnt == cnt2 and best == best2
+    x1, y1 = pts["xpos"].astype(np.float64), pts["ypos"].astype(np.float64)
+    den = H[2, 0] * x1 + H[2, 1] * y1 + 1.0
+    e2 = (pts["match_xpos"] * den - (H[0, 0] * x1 + H[0, 1] * y1 + H[0, 2])) ** 2 + \
+         (pts["match_ypos"] * den - (H[1, 0] * x1 + H[1, 1] * y1 + H[1, 2])) ** 2
+    lim = 25.0 * den * den
+    sure_in = (e2 < lim * (1 - 1e-4)).sum()
+    sure_out = (e2 > lim * (1 + 1e-4)).sum()
+    assert sure_in <= cnt <= len(pts) - sure_out
+
+
+def test_find_homography_degenerate_inputs():
+    from synth import synth_matches
+    pts, _, _ = synth_matches(64, seed=5)
+    H, cnt, best = orc.find_homography(pts, 7)                     # < 8 points: identity (matching.cu:1016-1017)
+    assert np.array_equal(H, np.eye(3, dtype=np.float32)) and cnt == 0 and best == -1
+    pts["score"] = 0.1                                            # nothing passes the filter (:1038)
+    H, cnt, best = orc.find_homography(pts, len(pts))
+    assert np.array_equal(H, np.eye(3, dtype=np.float32)) and cnt == 0 and best == -1
