@@ -9,7 +9,7 @@ BUILD    := build
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) \
             -Wno-unused-result -Wno-unused-value
 HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_points.hip \
-            $(CSRC)/kernels_match.hip $(CSRC)/misift_host.hip $(CSRC)/homography.hip
+            $(CSRC)/kernels_match.hip $(CSRC)/misift_host.hip $(CSRC)/homography.hip $(CSRC)/pipeline.hip
 HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
 all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle dropin

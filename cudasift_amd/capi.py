@@ -73,6 +73,14 @@ SIGNATURES = {
     "misift_match": (_i, [_vp, _vp, _i, _vp, _i]),
     "misift_match_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
     "misift_find_homography": (_i, [_vp, _vp, _i, _fp, _ip, _i, _f, _f, _f]),
+    "misift_extract_batch_u8": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _ip]),
+    "misift_pipe_create": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, C.POINTER(_vp)]),
+    "misift_pipe_destroy": (None, [_vp]),
+    "misift_pipe_submit": (_i, [_vp, _vp, _i]),
+    "misift_pipe_collect": (_i, [_vp, _ip, _ip, _vp, _sz, C.POINTER(_sz)]),
+    "misift_pipe_pending": (_i, [_vp]),
+    "misift_host_alloc": (_i, [_sz, C.POINTER(_vp)]),
+    "misift_host_free": (_i, [_vp]),
     "misift_timer_start": (_i, [_vp]),
     "misift_timer_stop_ms": (_i, [_vp, _fp]),
     "misift_profile_enable": (_i, [_vp, _i]),
@@ -333,6 +341,19 @@ class Context:
                                          lowest_scale, sc.ptr, pts.ptr, max_pts, n), "misift_extract_batch")
         return self.download(pts, (B, max_pts), POINT_DTYPE), np.array(list(n), np.int32)
 
+    def extract_batch_u8(self, imgs, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, max_pts=32768):
+        """imgs: [B,h,w] uint8 host array (tightly packed).  Returns (points[B,max_pts], numPts[B])."""
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        B, h, w = imgs.shape
+        d = self.upload(imgs)
+        S = scratch_floats(w, h, num_octaves, False)
+        sc = DevBuf(4 * S * B)
+        pts = self.zeros(576 * max_pts * B)
+        n = (C.c_int * B)()
+        check(lib().misift_extract_batch_u8(self.h, d.ptr, B, h * w, w, h, w, num_octaves, init_blur, thresh,
+                                            lowest_scale, sc.ptr, pts.ptr, max_pts, n), "misift_extract_batch_u8")
+        return self.download(pts, (B, max_pts), POINT_DTYPE), np.array(list(n), np.int32)
+
     def match(self, pts1, n1, pts2, n2, row_begin=0, row_count=None):
         """MatchSiftData on host structured arrays; returns the updated copy of pts1."""
         d1 = self.upload(pts1)
@@ -370,3 +391,69 @@ class Context:
             nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
             out[nm] = {"total_ms": float(ms[i]), "calls": int(calls[i])}
         return out
+
+
+class PinnedArray:
+    """numpy view over pinned host memory (misift_host_alloc) — uploads/downloads from it are asynchronous."""
+
+    def __init__(self, shape, dtype):
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(shape)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().misift_host_alloc(max(nbytes, 1), C.byref(p)), "misift_host_alloc")
+        self.ptr = p.value
+        buf = (C.c_char * nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().misift_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Pipe:
+    """Host-fed extraction pipeline (misift_pipe_*): submit batches of host frames, collect packed records."""
+
+    def __init__(self, ctx, width, height, batch_frames, src_u8=True, num_octaves=5, init_blur=1.0, thresh=3.0,
+                 lowest_scale=0.0, max_pts=32768, depth=2):
+        h = C.c_void_p()
+        check(lib().misift_pipe_create(ctx.h, width, height, batch_frames, int(bool(src_u8)), num_octaves, init_blur,
+                                       thresh, lowest_scale, max_pts, depth, C.byref(h)), "misift_pipe_create")
+        self.h = h
+        self.ctx = ctx
+        self.batch = batch_frames
+        self.max_pts = max_pts
+
+    def submit(self, host_ptr, nframes):
+        check(lib().misift_pipe_submit(self.h, host_ptr, nframes), "misift_pipe_submit")
+
+    def collect(self, out_ptr=None, capacity_records=0):
+        """Returns (counts[nframes], nrecords).  Records go to out_ptr (capacity in records) when given."""
+        nf = C.c_int(0)
+        cnt = (C.c_int * self.batch)()
+        nrec = C.c_size_t(0)
+        check(lib().misift_pipe_collect(self.h, C.byref(nf), cnt, out_ptr, capacity_records, C.byref(nrec)),
+              "misift_pipe_collect")
+        return np.array(list(cnt)[:nf.value], np.int32), int(nrec.value)
+
+    def pending(self):
+        return lib().misift_pipe_pending(self.h)
+
+    def close(self):
+        if self.h:
+            lib().misift_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

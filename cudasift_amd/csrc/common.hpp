@@ -152,6 +152,32 @@ __device__ __forceinline__ float4 load_quad_t(const float *row, int q, int width
   return load_quad(row, q, width, aligned);
 }
 
+// 8-bit source rows (misift_extract_batch_u8: camera frames uploaded as bytes, §8f-2): one dword load per
+// lane, v_cvt_f32_ubyte0..3 — exact, so the result equals an fp32 upload of the same pixel values.
+__device__ __forceinline__ float4 load_quad(const unsigned char *row, int q, int width, bool aligned)
+{
+  const int x = 4 * q;
+  if (aligned && x >= 0 && x + 3 < width) {
+    const uchar4 v = *reinterpret_cast<const uchar4 *>(row + x);
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+  }
+  const int w1 = width - 1;
+  return make_float4((float)row[clampi(x, 0, w1)], (float)row[clampi(x + 1, 0, w1)], (float)row[clampi(x + 2, 0, w1)],
+                     (float)row[clampi(x + 3, 0, w1)]);
+}
+template <bool FAST>
+__device__ __forceinline__ float4 load_quad_t(const unsigned char *row, int q, int width, bool aligned, const QuadCol &c)
+{
+  if (FAST) {
+    const uchar4 u = *reinterpret_cast<const uchar4 *>(row + c.off);
+    float4 v = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+    if (c.edge < 0) v = make_float4(v.x, v.x, v.x, v.x);
+    if (c.edge > 0) v = make_float4(v.w, v.w, v.w, v.w);
+    return v;
+  }
+  return load_quad(row, q, width, aligned);
+}
+
 // tex2D<float>() of a pitch2D texture with clamp addressing and linear filtering
 // (cudaSiftH.cu:196-205).  frac8: round the weights to 8 fractional bits like the
 // CUDA texture unit.  Same operation sequence as oracle tex2d().
@@ -215,6 +241,15 @@ struct misift_ctx {
 void misift_set_error(const char *fmt, ...);
 int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap);
 int misift_ensure_tmp(misift_ctx *ctx, size_t bytes);
+int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride,
+                           int width, int height, int pitch, int num_octaves, float init_blur, float thresh,
+                           float lowest_scale, int scale_up, float *d_scratch, SiftPointD *pts, int max_pts);
+// counts_out[f] = numPts of frame f (clamped to max_pts), or -1 when a candidate list of that frame overflowed;
+// offsets_out (optional, nframes+1 entries): exclusive prefix sum of the non-negative counts
+int launch_export_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *counts_out,
+                         int *offsets_out);
+int launch_pack_records(misift_ctx *ctx, const SiftPointD *pts, int max_pts, int nframes, const int *offsets,
+                        SiftPointD *packed);
 
 #define HIP_TRY(expr)                                                                        \
   do {                                                                                       \
@@ -234,11 +269,11 @@ struct LaunchScope {
 };
 
 // kernel launch wrappers (defined in the .hip files)
-int launch_lowpass(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
+int launch_lowpass(misift_ctx *ctx, const void *src, int src_u8, const StripGeom &g, float *dst, int dpitch,
                    long long dst_frame_stride, const float k9[9]);
 int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
                      long long dst_frame_stride, const float k5[5]);
-int launch_scaleup(misift_ctx *ctx, const float *src, int w, int h, int spitch, float *dst, int dpitch);
+int launch_scaleup(misift_ctx *ctx, const void *src, int src_u8, int w, int h, int spitch, float *dst, int dpitch);
 int launch_laplace(misift_ctx *ctx, const float *base, const StripGeom &g, float *dog,
                    long long dog_frame_stride, const LaplaceTaps &taps);
 int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long long dog_frame_stride,

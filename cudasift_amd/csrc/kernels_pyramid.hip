@@ -61,8 +61,8 @@ __device__ __forceinline__ void store_quad(float *row, int q, int width, bool al
 
 // ------------------------------------------------------------------ LowPass
 // out = G9^T (vertical) applied to G9 (horizontal) applied to in, clamp-to-edge.
-template <bool FAST>
-__global__ __launch_bounds__(256, 4) void lowpass_kernel(const float *__restrict__ src, StripGeom g,
+template <bool FAST, typename SRC>
+__global__ __launch_bounds__(256, 4) void lowpass_kernel(const SRC *__restrict__ src, StripGeom g,
                                                       float *__restrict__ dst, int dpitch,
                                                       long long dst_frame_stride, Taps5 t, int src_aligned,
                                                       int dst_aligned)
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 4) void lowpass_kernel(const float *__restrict
   if (!it.valid) return;
   const int lane = threadIdx.x & 63;
   const int q = it.strip * OUT_LANES + lane - 1;
-  const float *img = src + (long long)it.frame * g.frame_stride;
+  const SRC *img = src + (long long)it.frame * g.frame_stride;
   float *out = dst + (long long)it.frame * dst_frame_stride;
   const int y0 = it.seg * g.seg_rows;
   const int y1 = min(y0 + g.seg_rows, g.height);
@@ -191,15 +191,16 @@ __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------ ScaleUp
-__global__ __launch_bounds__(256) void scaleup_kernel(const float *__restrict__ src, int w, int h, int spitch,
+template <typename SRC>
+__global__ __launch_bounds__(256) void scaleup_kernel(const SRC *__restrict__ src, int w, int h, int spitch,
                                                       float *__restrict__ dst, int dpitch)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
   const int xr = min(x + 1, w - 1), yd = min(y + 1, h - 1);
-  const float vul = src[(size_t)y * spitch + x], vur = src[(size_t)y * spitch + xr];
-  const float vdl = src[(size_t)yd * spitch + x], vdr = src[(size_t)yd * spitch + xr];
+  const float vul = (float)src[(size_t)y * spitch + x], vur = (float)src[(size_t)y * spitch + xr];
+  const float vdl = (float)src[(size_t)yd * spitch + x], vdr = (float)src[(size_t)yd * spitch + xr];
   float2 top = make_float2(vul, 0.50f * (vul + vur));
   float2 bot = make_float2(0.50f * (vul + vdl), 0.25f * (vul + vur + vdl + vdr));
   *reinterpret_cast<float2 *>(dst + (size_t)(2 * y) * dpitch + 2 * x) = top;
@@ -215,19 +216,32 @@ static inline dim3 grid_for(const StripGeom &g)
   return dim3((unsigned)((nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
 }
 
-int launch_lowpass(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
+int launch_lowpass(misift_ctx *ctx, const void *src, int src_u8, const StripGeom &g, float *dst, int dpitch,
                    long long dst_frame_stride, const float k9[9])
 {
   Taps5 t;
   for (int j = 0; j <= 4; j++) t.k[j] = k9[4 - j];    // centre first, then outward
-  const int sal = is_aligned16(src, g.pitch) && (g.frame_stride & 3) == 0;
   const int dal = is_aligned16(dst, dpitch) && (dst_frame_stride & 3) == 0;
   LaunchScope ls(ctx, "lowpass");
+  if (src_u8) {
+    // one dword (4 pixels) per lane: rows must be 4-byte aligned for the fast path
+    const unsigned char *s8 = static_cast<const unsigned char *>(src);
+    const int sal = (((uintptr_t)s8) & 3) == 0 && (g.pitch & 3) == 0 && (g.frame_stride & 3) == 0;
+    if (sal && dal && (g.width & 3) == 0)
+      hipLaunchKernelGGL((lowpass_kernel<true, unsigned char>), grid_for(g), dim3(256), 0, ctx->stream, s8, g, dst,
+                         dpitch, dst_frame_stride, t, sal, dal);
+    else
+      hipLaunchKernelGGL((lowpass_kernel<false, unsigned char>), grid_for(g), dim3(256), 0, ctx->stream, s8, g, dst,
+                         dpitch, dst_frame_stride, t, sal, dal);
+    return ls.finish();
+  }
+  const float *sf = static_cast<const float *>(src);
+  const int sal = is_aligned16(sf, g.pitch) && (g.frame_stride & 3) == 0;
   if (sal && dal && (g.width & 3) == 0)
-    hipLaunchKernelGGL(lowpass_kernel<true>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+    hipLaunchKernelGGL((lowpass_kernel<true, float>), grid_for(g), dim3(256), 0, ctx->stream, sf, g, dst, dpitch,
                        dst_frame_stride, t, sal, dal);
   else
-    hipLaunchKernelGGL(lowpass_kernel<false>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+    hipLaunchKernelGGL((lowpass_kernel<false, float>), grid_for(g), dim3(256), 0, ctx->stream, sf, g, dst, dpitch,
                        dst_frame_stride, t, sal, dal);
   return ls.finish();
 }
@@ -249,10 +263,15 @@ int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, floa
   return ls.finish();
 }
 
-int launch_scaleup(misift_ctx *ctx, const float *src, int w, int h, int spitch, float *dst, int dpitch)
+int launch_scaleup(misift_ctx *ctx, const void *src, int src_u8, int w, int h, int spitch, float *dst, int dpitch)
 {
   LaunchScope ls(ctx, "scaleup");
-  hipLaunchKernelGGL(scaleup_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, ctx->stream, src, w, h,
-                     spitch, dst, dpitch);
+  const dim3 grid((w + 63) / 64, (h + 3) / 4);
+  if (src_u8)
+    hipLaunchKernelGGL(scaleup_kernel<unsigned char>, grid, dim3(256), 0, ctx->stream,
+                       static_cast<const unsigned char *>(src), w, h, spitch, dst, dpitch);
+  else
+    hipLaunchKernelGGL(scaleup_kernel<float>, grid, dim3(256), 0, ctx->stream, static_cast<const float *>(src), w, h,
+                       spitch, dst, dpitch);
   return ls.finish();
 }

@@ -518,9 +518,11 @@ int launch_selftest(misift_ctx *ctx)
 // -------------------------------------------------------------- extraction
 struct Level { int w, h, p; float *img; };   // img = frame-0 pointer of that pyramid level
 
-static int extract_impl(misift_ctx *ctx, const float *d_imgs, int nframes, long long frame_stride, int width,
-                        int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
-                        int scale_up, float *d_scratch, SiftPointD *pts, int max_pts)
+// Enqueue the whole launch sequence of one batch on the context stream (no synchronisation).
+// d_imgs: fp32 frames, or 8-bit frames when src_u8 (pitch / frame_stride in source elements).
+int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride,
+                           int width, int height, int pitch, int num_octaves, float init_blur, float thresh,
+                           float lowest_scale, int scale_up, float *d_scratch, SiftPointD *pts, int max_pts)
 {
   ARG_CHECK(ctx && d_imgs && pts);
   ARG_CHECK(nframes >= 1 && width >= 16 && height >= 16 && pitch >= width);
@@ -576,14 +578,14 @@ static int extract_impl(misift_ctx *ctx, const float *d_imgs, int nframes, long 
     const Level &L = lv[num_octaves];
     if (!scale_up) {
       StripGeom g = make_geom(ctx, width, height, pitch, nframes, frame_stride, width, height, 62);
-      rc = launch_lowpass(ctx, d_imgs, g, L.img, L.p, SS, k9);
+      rc = launch_lowpass(ctx, d_imgs, src_u8, g, L.img, L.p, SS, k9);
       if (rc) return rc;
     } else {
       float *upImg = memoryTmp;
-      rc = launch_scaleup(ctx, d_imgs, width, height, pitch, upImg, L.p);
+      rc = launch_scaleup(ctx, d_imgs, src_u8, width, height, pitch, upImg, L.p);
       if (rc) return rc;
       StripGeom g = make_geom(ctx, W, H, L.p, 1, SS, W, H, 62);
-      rc = launch_lowpass(ctx, upImg, g, L.img, L.p, SS, k9);
+      rc = launch_lowpass(ctx, upImg, 0, g, L.img, L.p, SS, k9);
       if (rc) return rc;
       lowest_scale *= 2.0f;
     }
@@ -671,14 +673,14 @@ static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pt
 // path (possible only for extreme thresh/contrast), redo the batch with the dense unfused kernels,
 // whose list holds true 3x3x3 extrema only; an overflow there is reported as an error, never dropped
 // silently (the reference silently caps at 32 candidates per 30x8 tile, cudaSiftD.cu:1371).
-static int extract_sync(misift_ctx *ctx, const float *d_imgs, int nframes, long long frame_stride, int width,
+static int extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride, int width,
                         int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
                         int scale_up, float *d_scratch, SiftPointD *pts, int max_pts, int *num_pts_out)
 {
   const int fused_saved = ctx->opt.fused;
   for (int attempt = 0; attempt < 2; attempt++) {
-    int rc = extract_impl(ctx, d_imgs, nframes, frame_stride, width, height, pitch, num_octaves, init_blur, thresh,
-                          lowest_scale, scale_up, d_scratch, pts, max_pts);
+    int rc = misift_extract_enqueue(ctx, d_imgs, src_u8, nframes, frame_stride, width, height, pitch, num_octaves,
+                                    init_blur, thresh, lowest_scale, scale_up, d_scratch, pts, max_pts);
     bool ovf = false;
     if (!rc) rc = read_counts(ctx, nframes, num_octaves, max_pts, num_pts_out, &ovf);
     if (rc) { ctx->opt.fused = fused_saved; return rc; }
@@ -701,7 +703,7 @@ extern "C" int misift_extract(misift_ctx *ctx, const float *d_img, int width, in
                               void *d_pts, int max_pts, int *num_pts_out)
 {
   ARG_CHECK(num_pts_out != nullptr);
-  int rc = extract_sync(ctx, d_img, 1, 0, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
+  int rc = extract_sync(ctx, d_img, 0, 1, 0, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
                         scale_up, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
   if (scale_up) {                                    // cudaSiftH.cu:130
@@ -717,7 +719,19 @@ extern "C" int misift_extract_batch(misift_ctx *ctx, const float *d_imgs, int nf
                                     int *num_pts_out)
 {
   ARG_CHECK(num_pts_out != nullptr);
-  int rc = extract_sync(ctx, d_imgs, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
+  int rc = extract_sync(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
+                        init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
+  if (rc) return rc;
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_extract_batch_u8(misift_ctx *ctx, const unsigned char *d_imgs, int nframes, size_t frame_stride,
+                                       int width, int height, int pitch, int num_octaves, float init_blur,
+                                       float thresh, float lowest_scale, float *d_scratch, void *d_pts, int max_pts,
+                                       int *num_pts_out)
+{
+  ARG_CHECK(num_pts_out != nullptr);
+  int rc = extract_sync(ctx, d_imgs, 1, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
                         init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
   return resolve_profile(ctx);
@@ -728,14 +742,11 @@ extern "C" int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, 
                                           float thresh, float lowest_scale, float *d_scratch, void *d_pts,
                                           int max_pts, int *d_counts_out)
 {
-  int rc = extract_impl(ctx, d_imgs, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
-                        init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts);
+  int rc = misift_extract_enqueue(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch,
+                                  num_octaves, init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts,
+                                  max_pts);
   if (rc) return rc;
-  if (d_counts_out) {
-    const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
-    HIP_TRY(hipMemcpy2DAsync(d_counts_out, sizeof(int), ctx->d_counters + slot, sizeof(unsigned) * CNT_STRIDE,
-                             sizeof(int), nframes, hipMemcpyDeviceToDevice, ctx->stream));
-  }
+  if (d_counts_out) return launch_export_counts(ctx, nframes, num_octaves, max_pts, d_counts_out, nullptr);
   return MISIFT_OK;
 }
 
@@ -770,7 +781,7 @@ extern "C" int misift_lowpass(misift_ctx *ctx, const float *d_src, int width, in
   float k9[9];
   lowpass_taps(sigma, k9);
   StripGeom g = make_geom(ctx, width, height, spitch, 1, 0, width, height, 62);
-  int rc = launch_lowpass(ctx, d_src, g, d_dst, dpitch, 0, k9);
+  int rc = launch_lowpass(ctx, d_src, 0, g, d_dst, dpitch, 0, k9);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return resolve_profile(ctx);
@@ -794,7 +805,7 @@ extern "C" int misift_scaleup(misift_ctx *ctx, const float *d_src, int width, in
 {
   ARG_CHECK(ctx && d_src && d_dst && width > 0 && height > 0 && spitch >= width && dpitch >= 2 * width &&
             (dpitch & 1) == 0);
-  int rc = launch_scaleup(ctx, d_src, width, height, spitch, d_dst, dpitch);
+  int rc = launch_scaleup(ctx, d_src, 0, width, height, spitch, d_dst, dpitch);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return resolve_profile(ctx);

@@ -136,6 +136,42 @@ int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, int nframes
                                float lowest_scale, float *d_scratch, void *d_pts,
                                int max_pts, int *d_counts_out);
 
+/* As misift_extract_batch, but the frames are 8-bit (pitch and frame_stride in
+ * bytes): the prefilter converts in registers, so the result is bit-identical
+ * to an fp32 upload of the same pixel values (what mainSift.cpp:41-42 does on
+ * the host with convertTo(CV_32FC1)) at a quarter of the PCIe and HBM read bytes. */
+int misift_extract_batch_u8(misift_ctx *ctx, const unsigned char *d_imgs, int nframes,
+                            size_t frame_stride, int width, int height, int pitch,
+                            int num_octaves, float init_blur, float thresh,
+                            float lowest_scale, float *d_scratch, void *d_pts,
+                            int max_pts, int *num_pts_out);
+
+/* ------------------------------------------------- host-fed pipeline
+ * Streams batches of HOST frames through upload -> extraction -> read-back on three
+ * HIP streams, replacing the blocking CudaImage::Download (cudaImage.cu:55-66) and the
+ * blocking SiftPoint read-back of ExtractSift (cudaSiftH.cu:139-140).  Frames are tightly
+ * packed (row stride = width, as CudaImage::Download assumes for h_data), fp32 or 8-bit.
+ * Up to `depth` batches may be in flight; batches are collected in submission order.
+ *   misift_pipe_submit   enqueues upload + extraction of `nframes` (<= batch_frames) frames and
+ *                        returns at once; host_frames must stay valid until the batch is
+ *                        collected (pinned memory from misift_host_alloc makes the upload async).
+ *   misift_pipe_collect  waits for the oldest batch: counts_out[f] = numPts of frame f (or -1 if
+ *                        that frame's candidate list overflowed -> MISIFT_ENOMEM, nothing is
+ *                        dropped silently); the valid records of all frames, frame after frame,
+ *                        are copied to host_records (capacity in records; may be NULL to skip). */
+typedef struct misift_pipe misift_pipe;
+int misift_pipe_create(misift_ctx *ctx, int width, int height, int batch_frames, int src_u8,
+                       int num_octaves, float init_blur, float thresh, float lowest_scale,
+                       int max_pts, int depth, misift_pipe **out);
+void misift_pipe_destroy(misift_pipe *pipe);
+int misift_pipe_submit(misift_pipe *pipe, const void *host_frames, int nframes);
+int misift_pipe_collect(misift_pipe *pipe, int *nframes_out, int *counts_out, void *host_records,
+                        size_t capacity_records, size_t *nrecords_out);
+int misift_pipe_pending(const misift_pipe *pipe);
+/* Pinned host memory for frames / records (truly asynchronous copies). */
+int misift_host_alloc(size_t bytes, void **out);
+int misift_host_free(void *ptr);
+
 /* Per-frame point counters of the last extraction, 17 per frame, in the
  * reference's layout (cudaSiftD.cu:14, protocol cudaSiftD.cu:1297-1300). */
 int misift_get_counters(misift_ctx *ctx, int frame, unsigned int *counters17);

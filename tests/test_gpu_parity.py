@@ -408,3 +408,92 @@ def test_find_homography_stereo_vs_oracle(ctx, stereo):
     orc().srand(7)
     Ho, co, _ = orc().find_homography(m, na, num_loops=10000, min_score=0.0, max_ambiguity=0.80, thresh=5.0)
     assert cg == co and np.array_equal(Ho.view(np.uint32), Hg.view(np.uint32))
+
+
+# ------------------------------------------------------------------ 8-bit frames + host-fed pipeline
+def _canon(recs):
+    """Records of one frame in a canonical order (appends within an octave are atomic, so the order varies)."""
+    k = [recs[f].view(np.uint32) for f in ("orientation", "scale", "ypos", "xpos")]
+    return recs[np.lexsort(k)].tobytes()
+
+
+def _u8_frames(n, h, w, seed0=100):
+    return np.stack([np.clip(np.rint(synth_frame(seed0 + i, width=w, height=h)), 0, 255).astype(np.uint8) for i in range(n)])
+
+
+@pytest.mark.parametrize("h,w,noct", [(272, 480, 5), (131, 203, 3), (160, 330, 4)])
+def test_extract_u8_bit_identical_to_f32_upload(ctx, h, w, noct):
+    """misift_extract_batch_u8 == misift_extract_batch on the same pixel values (the in-register conversion is
+    exact), for the aligned fast path and for widths that are not a multiple of 4."""
+    f8 = _u8_frames(2, h, w)
+    pf, nf = ctx.extract_batch(f8.astype(np.float32), num_octaves=noct, thresh=2.0, max_pts=4096)
+    pu, nu = ctx.extract_batch_u8(f8, num_octaves=noct, thresh=2.0, max_pts=4096)
+    assert np.array_equal(nf, nu) and nf.min() > 20
+    for b in range(2):
+        assert _canon(pf[b, :nf[b]]) == _canon(pu[b, :nu[b]])
+    # ... and equal to the oracle on that image (same bar as the fp32 path)
+    o, no_, _ = orc().extract(f8[0].astype(np.float32), num_octaves=noct, thresh=2.0, max_pts=4096)
+    rep = compare_points(o[:no_], pu[0, :nu[0]], "extract_u8_%dx%d" % (w, h), record)
+    assert rep["paired_exact"] == rep["paired"]
+
+
+@pytest.mark.parametrize("src_u8", [True, False])
+def test_pipe_matches_batch_extraction(ctx, src_u8):
+    """The 3-stream pipeline returns, batch after batch and frame after frame, exactly the records the
+    synchronous batch call returns (ragged last batch, more batches than slots)."""
+    from cudasift_amd import capi
+    h, w, B, nb = 272, 480, 3, 5
+    frames = _u8_frames(B * nb - 1, h, w, seed0=300)           # last batch has B-1 frames
+    src = frames if src_u8 else frames.astype(np.float32)
+    ref_fn = ctx.extract_batch_u8 if src_u8 else ctx.extract_batch
+    pin = capi.PinnedArray(src.shape, src.dtype)
+    pin.array[...] = src
+    out = capi.PinnedArray((B * 4096,), capi.POINT_DTYPE)
+    pipe = capi.Pipe(ctx, w, h, B, src_u8=src_u8, thresh=2.0, max_pts=4096, depth=2)
+    esz = src.dtype.itemsize * h * w
+    got = []
+
+    def collect():
+        counts, nrec = pipe.collect(out.ptr, B * 4096)
+        assert nrec == counts.sum()
+        got.append((counts, out.array[:nrec].copy()))
+
+    for k in range(nb):
+        if pipe.pending() == 2:
+            collect()
+        n = min(B, len(src) - k * B)
+        pipe.submit(pin.ptr + k * B * esz, n)
+    while pipe.pending():
+        collect()
+    pipe.close()
+    assert len(got) == nb
+    for k, (counts, recs) in enumerate(got):
+        n = min(B, len(src) - k * B)
+        rp, rn = ref_fn(src[k * B:k * B + n], thresh=2.0, max_pts=4096)
+        assert np.array_equal(counts, rn) and counts.min() > 20
+        off = 0
+        for f in range(n):
+            assert _canon(recs[off:off + rn[f]]) == _canon(rp[f, :rn[f]])
+            off += rn[f]
+    record("pipe_parity_u8" if src_u8 else "pipe_parity_f32", batches=nb, frames=len(src), identical=True)
+
+
+def test_pipe_error_paths(ctx):
+    from cudasift_amd import capi
+    h, w = 128, 128
+    pin = capi.PinnedArray((1, h, w), np.uint8)
+    pin.array[...] = _u8_frames(1, h, w)
+    pipe = capi.Pipe(ctx, w, h, 1, src_u8=True, num_octaves=3, thresh=1.0, max_pts=2048, depth=1)
+    with pytest.raises(capi.MisiftError):
+        pipe.collect()                                           # nothing in flight
+    pipe.submit(pin.ptr, 1)
+    with pytest.raises(capi.MisiftError):
+        pipe.submit(pin.ptr, 1)                                  # all slots busy
+    out = capi.PinnedArray((4,), capi.POINT_DTYPE)
+    with pytest.raises(capi.MisiftError):
+        pipe.collect(out.ptr, 4)                                 # room for 4 records only
+    assert pipe.pending() == 0
+    pipe.submit(pin.ptr, 1)
+    counts, nrec = pipe.collect()                                # counts only
+    assert nrec == counts.sum() and counts[0] > 4
+    pipe.close()
