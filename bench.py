@@ -158,6 +158,12 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     alg = algorithmic_bytes_per_frame()
+    if "lowpass_down" in prof:
+        # fused prefilter + first ScaleDown: its algorithmic bytes are the sum of the two reference kernels' figures
+        # (LowPass 8*N0 + ScaleDown_1 4*N0 + 4*N1); the remaining ScaleDown launches cover levels 2..
+        N = octave_pixels(W, H, NUM_OCTAVES)
+        alg["lowpass_down"] = 8 * N[0] + 4 * N[0] + 4 * N[1]
+        alg["scaledown"] = sum(4 * N[i] + 4 * N[i + 1] for i in range(1, NUM_OCTAVES - 1))
     kernels = {}
     for name, p in prof.items():
         per_step_ms = p["total_ms"] / psteps
@@ -190,7 +196,7 @@ def main():
                         "reach HBM (see traffic), so achieved > peak is possible; the kernel itself is fp32-VALU-bound"}
     # the genuinely HBM-bound kernels, same definition (algorithmic bytes / summed launch time)
     hbm_kernels = {}
-    for k in ("lowpass", "scaledown"):
+    for k in ("lowpass", "lowpass_down", "scaledown"):
         if k in kernels:
             a = alg[k] * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
             hbm_kernels[k] = {"achieved": round(a, 1), "frac": round(a / HBM_PEAK_GBS, 4)}

@@ -73,6 +73,7 @@ SIGNATURES = {
     "misift_match": (_i, [_vp, _vp, _i, _vp, _i]),
     "misift_match_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
     "misift_find_homography": (_i, [_vp, _vp, _i, _fp, _ip, _i, _f, _f, _f]),
+    "misift_lowpass_scaledown": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f, _vp, _i]),
     "misift_extract_batch_u8": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _ip]),
     "misift_pipe_create": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, C.POINTER(_vp)]),
     "misift_pipe_destroy": (None, [_vp]),
@@ -246,6 +247,18 @@ class Context:
         dst = DevBuf(4 * p2 * max(h2, 1))
         check(lib().misift_scaledown(self.h, src.ptr, w, h, p, dst.ptr, p2), "misift_scaledown")
         return self.download_image(dst.ptr, w2, h2, p2)
+
+    def lowpass_scaledown(self, img, sigma):
+        """Fused LowPass + first ScaleDown.  Returns (lowpassed [h,w], decimated [h//2,w//2])."""
+        h, w = img.shape
+        src, p = self.upload_image(img)
+        dst = DevBuf(4 * p * h)
+        w2, h2 = w // 2, h // 2
+        p2 = (w2 + 127) // 128 * 128
+        dst2 = DevBuf(4 * p2 * max(h2, 1))
+        check(lib().misift_lowpass_scaledown(self.h, src.ptr, w, h, p, dst.ptr, p, sigma, dst2.ptr, p2),
+              "misift_lowpass_scaledown")
+        return self.download_image(dst.ptr, w, h, p), self.download_image(dst2.ptr, w2, h2, p2)
 
     def scaleup(self, img):
         h, w = img.shape

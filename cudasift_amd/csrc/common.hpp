@@ -271,6 +271,9 @@ struct LaunchScope {
 // kernel launch wrappers (defined in the .hip files)
 int launch_lowpass(misift_ctx *ctx, const void *src, int src_u8, const StripGeom &g, float *dst, int dpitch,
                    long long dst_frame_stride, const float k9[9]);
+int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const StripGeom &g, float *dst, int dpitch,
+                        long long dst_frame_stride, const float k9[9], float *dst2, int dpitch2,
+                        long long dst2_frame_stride, const float k5[5], int *done);
 int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
                      long long dst_frame_stride, const float k5[5]);
 int launch_scaleup(misift_ctx *ctx, const void *src, int src_u8, int w, int h, int spitch, float *dst, int dpitch);

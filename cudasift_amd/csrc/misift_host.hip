@@ -573,25 +573,36 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     }
   }
   const long long SS = (long long)S;
-  // --- prefilter (cudaSiftH.cu:112 / :119-123)
+  // --- prefilter (cudaSiftH.cu:112 / :119-123); when the shape allows, the first ScaleDown of the pyramid is
+  // produced by the same kernel (the prefiltered rows are decimated while still in registers)
+  int first_down_done = 0;
   {
     const Level &L = lv[num_octaves];
-    if (!scale_up) {
-      StripGeom g = make_geom(ctx, width, height, pitch, nframes, frame_stride, width, height, 62);
-      rc = launch_lowpass(ctx, d_imgs, src_u8, g, L.img, L.p, SS, k9);
-      if (rc) return rc;
-    } else {
+    const void *pre_src = d_imgs;
+    int pre_u8 = src_u8, pre_pitch = pitch, pre_frames = nframes;
+    long long pre_stride = frame_stride;
+    if (scale_up) {
       float *upImg = memoryTmp;
       rc = launch_scaleup(ctx, d_imgs, src_u8, width, height, pitch, upImg, L.p);
       if (rc) return rc;
-      StripGeom g = make_geom(ctx, W, H, L.p, 1, SS, W, H, 62);
-      rc = launch_lowpass(ctx, upImg, 0, g, L.img, L.p, SS, k9);
-      if (rc) return rc;
+      pre_src = upImg; pre_u8 = 0; pre_pitch = L.p; pre_frames = 1; pre_stride = SS;
       lowest_scale *= 2.0f;
+    }
+    if (num_octaves >= 2 && ctx->opt.fused) {
+      const Level &D = lv[num_octaves - 1];
+      StripGeom g = make_geom(ctx, W, H, pre_pitch, pre_frames, pre_stride, W, H, 60);
+      rc = launch_lowpass_down(ctx, pre_src, pre_u8, g, L.img, L.p, SS, k9, D.img, D.p, SS, k5, &first_down_done);
+      if (rc) return rc;
+    }
+    if (!first_down_done) {
+      StripGeom g = make_geom(ctx, W, H, pre_pitch, pre_frames, pre_stride, W, H, 62);
+      rc = launch_lowpass(ctx, pre_src, pre_u8, g, L.img, L.p, SS, k9);
+      if (rc) return rc;
     }
   }
   // --- pyramid (ScaleDown chain of cudaSiftH.cu:153-160), finest to coarsest
   for (int o = num_octaves; o >= 2; o--) {
+    if (o == num_octaves && first_down_done) continue;
     const Level &src = lv[o], &dst = lv[o - 1];
     StripGeom g = make_geom(ctx, src.w, src.h, src.p, nframes, SS, dst.w, dst.h, 62);
     rc = launch_scaledown(ctx, src.img, g, dst.img, dst.p, SS, k5);
@@ -784,6 +795,25 @@ extern "C" int misift_lowpass(misift_ctx *ctx, const float *d_src, int width, in
   int rc = launch_lowpass(ctx, d_src, 0, g, d_dst, dpitch, 0, k9);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_lowpass_scaledown(misift_ctx *ctx, const float *d_src, int width, int height, int spitch,
+                                        float *d_dst, int dpitch, float sigma, float *d_dst2, int dpitch2)
+{
+  ARG_CHECK(ctx && d_src && d_dst && d_dst2 && width >= 4 && height >= 8);
+  HIP_TRY(hipSetDevice(ctx->device));
+  float k9[9], k5[5];
+  lowpass_taps(sigma, k9);
+  scaledown_taps(0.5f, k5);
+  StripGeom g = make_geom(ctx, width, height, spitch, 1, 0, width, height, 60);
+  int done = 0;
+  int rc = launch_lowpass_down(ctx, d_src, 0, g, d_dst, dpitch, 0, k9, d_dst2, dpitch2, 0, k5, &done);
+  if (rc) return rc;
+  if (!done) {
+    misift_set_error("misift_lowpass_scaledown: shape not supported by the fused kernel (width %% 4, alignment)");
+    return MISIFT_EINVAL;
+  }
   return resolve_profile(ctx);
 }
 

@@ -184,6 +184,12 @@ int misift_set_counters(misift_ctx *ctx, int frame, const unsigned int *counters
 /* LowPass (cudaSiftH.cu:406-435, LowPassBlock cudaSiftD.cu:1986-2037). */
 int misift_lowpass(misift_ctx *ctx, const float *d_src, int width, int height, int spitch,
                    float *d_dst, int dpitch, float sigma);
+/* LowPass and the first ScaleDown of the pyramid in one pass (what ExtractSift does
+ * back to back, cudaSiftH.cu:112 + :153-154): dst = LowPass(src), dst2 = ScaleDown(dst),
+ * bit-identical to the two separate calls.  Needs width % 4 == 0 and 16-byte aligned rows
+ * (MISIFT_EINVAL otherwise; misift_extract falls back to the separate kernels by itself). */
+int misift_lowpass_scaledown(misift_ctx *ctx, const float *d_src, int width, int height, int spitch,
+                             float *d_dst, int dpitch, float sigma, float *d_dst2, int dpitch2);
 /* ScaleDown (cudaSiftH.cu:308-338, cudaSiftD.cu:84-168): dst is (w/2,h/2). */
 int misift_scaledown(misift_ctx *ctx, const float *d_src, int width, int height,
                      int spitch, float *d_dst, int dpitch);

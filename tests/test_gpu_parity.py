@@ -497,3 +497,19 @@ def test_pipe_error_paths(ctx):
     counts, nrec = pipe.collect()                                # counts only
     assert nrec == counts.sum() and counts[0] > 4
     pipe.close()
+
+
+@pytest.mark.parametrize("h,w", [(1080, 1920), (960, 1280), (135, 240), (37, 260), (8, 4), (270, 480), (539, 484),
+                                 (67, 1024)])
+def test_fused_lowpass_scaledown_bit_exact(ctx, h, w):
+    """lowpass_down_kernel == LowPass then ScaleDown (oracle), bit for bit: strip seams (w > 240), segment
+    seams, odd and even heights (bottom clamp), tiny images."""
+    rng = np.random.default_rng(h * 10007 + w)
+    img = (rng.random((h, w), dtype=np.float32) * 255.0).astype(np.float32)
+    lp, dn = ctx.lowpass_scaledown(img, 1.0)
+    ref_lp = orc().lowpass(img, 1.0)
+    ref_dn = orc().scaledown(ref_lp)
+    record("fused_lowpass_scaledown_%dx%d" % (w, h), lowpass_equal=bool(np.array_equal(lp, ref_lp)),
+           down_equal=bool(np.array_equal(dn, ref_dn)))
+    assert np.array_equal(lp, ref_lp)
+    assert dn.shape == ref_dn.shape and np.array_equal(dn, ref_dn)
