@@ -175,42 +175,69 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
   return r;
 }
 
-// Descriptor accumulation without LDS atomics.  Phase 1: every lane evaluates 4 of the 256 rotated
-// samples and stores (iangf*grad, angf*grad, angi) into a 20x20 zero-bordered table in LDS.  Phase 2
-// is output-centric: lane = (cell c = lane>>2, angle bins a and a+4); the 8x8 samples whose trilinear
-// footprint reaches cell c are read back (immediate LDS offsets, border slots read as zero) and
-// accumulated in two registers.  Same votes as cudaSiftD.cu:346-386, summed in a different order (the
-// reference's shared-memory atomics have no defined order either).
+// Descriptor accumulation without LDS atomics and without searching.
+// Phase 1: every lane evaluates 4 of the 256 rotated samples; a sample votes iangf*grad into angle bin
+// angi and angf*grad into bin angi+1 (mod 8) of the (up to) 2x2 cells around it (cudaSiftD.cu:346-386).
+// Phase 2 is output-centric: lane = (cell c = lane>>2, angle bins a and a+4).  The votes are laid out in
+// LDS as per-bin planes [bin][20][20] over the 16x16 sample grid with a 2-sample zero border, so a lane
+// reads the 8x8 footprint of its cell in ITS bin's plane with 16 b128 loads and sums it with 64 FMAs
+// whose spatial weights are compile-time literals — no compares, no selects (the previous version
+// searched (angi, vote) records: 770 VALU instead of 130 per keypoint-lane; rocprof showed the kernel
+// VALU-bound at 4 waves/SIMD).  Only four planes exist: bins 0..3 are accumulated first, then the same
+// four planes are re-used for bins 4..7; every slot a lane writes it zeroes again afterwards, so the
+// table stays all-zero between passes and keypoints.  Same votes and the same summation order as before.
+// A fifth plane takes the rare angi == 8 votes (dy == +0, dx < 0).
 #define SMP_W 20
-__device__ __forceinline__ float spatial_w(int m)      // horf/verf for m<4, 1-horf/1-verf for m>=4
+#define SMP_PLANE (SMP_W * SMP_W)        // 400 floats: plane stride / 4 = 100 = 4 (mod 16) -> conflict-free b128 reads
+#define DESCR_TBL (5 * SMP_PLANE)
+__device__ __forceinline__ constexpr float spatial_w(int m)      // horf/verf for m<4, 1-horf/1-verf for m>=4
 {
   return m < 4 ? (m + 0.5f) * 0.25f : (7.5f - m) * 0.25f;
 }
 
-__device__ __forceinline__ void descr_init(float4 *smp, float *gauss, int lane)
+__device__ __forceinline__ void descr_init(float *tbl, float *gauss, int lane)
 {
   if (lane < 16) gauss[lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
-  for (int i = lane; i < SMP_W * SMP_W; i += 64) smp[i] = make_float4(0.0f, 0.0f, -1.0f, 0.0f);   // border stays zero
+  for (int i = lane; i < DESCR_TBL; i += 64) tbl[i] = 0.0f;
+}
+
+// 8x8 footprint of a cell in one plane: rows are 20 floats apart, the two b128 loads of a row are adjacent
+__device__ __forceinline__ float footprint_sum(const float *base, float acc)
+{
+#pragma unroll
+  for (int my = 0; my < 8; my++) {
+    const float4 lo = *reinterpret_cast<const float4 *>(base + my * SMP_W);
+    const float4 hi = *reinterpret_cast<const float4 *>(base + my * SMP_W + 4);
+    const float wy = spatial_w(my);
+    acc = __builtin_fmaf(wy * spatial_w(0), lo.x, acc);
+    acc = __builtin_fmaf(wy * spatial_w(1), lo.y, acc);
+    acc = __builtin_fmaf(wy * spatial_w(2), lo.z, acc);
+    acc = __builtin_fmaf(wy * spatial_w(3), lo.w, acc);
+    acc = __builtin_fmaf(wy * spatial_w(4), hi.x, acc);
+    acc = __builtin_fmaf(wy * spatial_w(5), hi.y, acc);
+    acc = __builtin_fmaf(wy * spatial_w(6), hi.z, acc);
+    acc = __builtin_fmaf(wy * spatial_w(7), hi.w, acc);
+  }
+  return acc;
 }
 
 // Normalised descriptor bins (8*cell + (lane&3)) and (+4) of one keypoint, cell = lane >> 2.
 __device__ __forceinline__ void descr_core(const float *img, int w, int h, int pitch, bool q8, float px, float py,
-                                           float pscale, float orientation, float4 *smp, const float *gauss,
+                                           float pscale, float orientation, float *tbl, const float *gauss,
                                            int lane, float &out0, float &out1)
 {
   const int cell = lane >> 2, cx = cell & 3, cy = cell >> 2;
-  const float a0 = (float)(lane & 3), a1 = a0 + 4.0f;
-  const float am0 = (lane & 3) == 0 ? 7.0f : a0 - 1.0f;      // angi whose angp lands on a0 (7 and 8 both wrap to 0)
-  const float am1 = a1 - 1.0f;
-  const bool a0_is0 = (lane & 3) == 0;
-  const float4 *cellbase = smp + (4 * cy) * SMP_W + 4 * cx;   // table slot of sample (tx,y) is (y+2)*20 + tx+2
-  wave_sync();
+  // this lane's plane (bin lane&3, then bin (lane&3)+4) and the top-left slot of its cell's footprint:
+  // table slot of sample (tx,y) is (y+2)*20 + tx+2, the footprint of cell (cx,cy) starts at sample (4cx-2, 4cy-2)
+  const float *mine = tbl + (lane & 3) * SMP_PLANE + (4 * cy) * SMP_W + 4 * cx;
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
   const float sina = sinf(theta);
   const float cosa = cosf(theta);
   const float scale = 12.0f / 16.0f * pscale;
   const float ssina = scale * sina;
   const float scosa = scale * cosa;
+  float vx[4], vy[4];
+  int slotx[4], sloty[4];         // plane-relative slot (bin * SMP_PLANE + position) of the two votes, bins 0..7 (8: special)
   bool has8 = false;
 #pragma unroll
   for (int rep = 0; rep < 4; rep++) {
@@ -228,35 +255,46 @@ __device__ __forceinline__ void descr_core(const float *img, int w, int h, int p
     angf -= angi;
     const float iangf = 1.0f - angf;
     has8 |= angi >= 8;
-    smp[(y + 2) * SMP_W + tx + 2] = make_float4(iangf * grad, angf * grad, (float)angi, 0.0f);
+    vx[rep] = iangf * grad;
+    vy[rep] = angf * grad;
+    const int pos = (y + 2) * SMP_W + tx + 2;
+    slotx[rep] = angi * SMP_PLANE + pos;                       // angi == 8: the special fifth plane (handled below)
+    sloty[rep] = (angi >= 7 ? 0 : angi + 1) * SMP_PLANE + pos; // angi+1 wraps to bin 0 (7 and 8 alike)
+  }
+  // ---- bins 0..3
+#pragma unroll
+  for (int rep = 0; rep < 4; rep++) {
+    if (slotx[rep] < 4 * SMP_PLANE) tbl[slotx[rep]] = vx[rep];
+    if (sloty[rep] < 4 * SMP_PLANE) tbl[sloty[rep]] = vy[rep];
   }
   wave_sync();
-  float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll 2
-  for (int my = 0; my < 8; my++) {
-    const float wy = spatial_w(my);
+  float acc0 = footprint_sum(mine, 0.0f);
+  wave_sync();
+  // ---- bins 4..7 re-use planes 0..3 (a lane's pass-A and pass-B slots never coincide: different plane or
+  // position).  The rare angi == 8 votes land in the fifth plane here (slot - 4 planes = plane 4).
 #pragma unroll
-    for (int mx = 0; mx < 8; mx++) {
-      const float4 e = cellbase[my * SMP_W + mx];
-      const float wgt = wy * spatial_w(mx);
-      const float t0 = (e.z == a0) ? e.x : ((e.z == am0 || (a0_is0 && e.z == 8.0f)) ? e.y : 0.0f);
-      const float t1 = (e.z == a1) ? e.x : ((e.z == am1) ? e.y : 0.0f);
-      acc0 = __builtin_fmaf(wgt, t0, acc0);
-      acc1 = __builtin_fmaf(wgt, t1, acc1);
+  for (int rep = 0; rep < 4; rep++) {
+    if (slotx[rep] < 4 * SMP_PLANE) tbl[slotx[rep]] = 0.0f;
+    if (sloty[rep] < 4 * SMP_PLANE) tbl[sloty[rep]] = 0.0f;
+    if (slotx[rep] >= 4 * SMP_PLANE) tbl[slotx[rep] - 4 * SMP_PLANE] = vx[rep];
+    if (sloty[rep] >= 4 * SMP_PLANE) tbl[sloty[rep] - 4 * SMP_PLANE] = vy[rep];
+  }
+  wave_sync();
+  float acc1 = footprint_sum(mine, 0.0f);
+  if (__any(has8)) {
+    // rare (dy == +0 and dx < 0): angi == 8 makes the iangf vote land in bin 0 of the
+    // NEXT cell of the flattened 4x4 grid, with the spatial weights of the cell it was computed for; cell 16
+    // does not exist (dropped).  Sum plane 4 over the PREVIOUS cell's footprint.
+    if ((lane & 3) == 0 && cell >= 1) {
+      const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
+      acc0 = footprint_sum(tbl + 4 * SMP_PLANE + (4 * pcy) * SMP_W + 4 * pcx, acc0);
     }
   }
-  if (__any(has8)) {
-    // rare (dy == +0 and dx < 0): angi == 8 makes the iangf vote land in
-    // bin 0 of the NEXT cell of the flattened 4x4 grid; cell 16 does not exist (dropped)
-    if (a0_is0 && cell >= 1) {
-      const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
-      const float4 *pb = smp + (4 * pcy) * SMP_W + 4 * pcx;
-      for (int my = 0; my < 8; my++)
-        for (int mx = 0; mx < 8; mx++) {
-          const float4 e = pb[my * SMP_W + mx];
-          if (e.z == 8.0f) acc0 = __builtin_fmaf(spatial_w(my) * spatial_w(mx), e.x, acc0);
-        }
-    }
+  wave_sync();
+#pragma unroll
+  for (int rep = 0; rep < 4; rep++) {
+    if (slotx[rep] >= 4 * SMP_PLANE) tbl[slotx[rep] - 4 * SMP_PLANE] = 0.0f;
+    if (sloty[rep] >= 4 * SMP_PLANE) tbl[sloty[rep] - 4 * SMP_PLANE] = 0.0f;
   }
   // normalise, clamp at 0.2, normalise again (reference cudaSiftD.cu:390-409)
   const float tsum1 = wave_sum(acc0 * acc0 + acc1 * acc1);
@@ -273,7 +311,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ ba
                                                     const unsigned *__restrict__ counters,
                                                     SiftPointD *__restrict__ pts, int max_pts, int frac8)
 {
-  __shared__ float4 s_smp[WAVES_PER_BLOCK][SMP_W * SMP_W];
+  __shared__ __attribute__((aligned(16))) float s_smp[WAVES_PER_BLOCK][DESCR_TBL];
   __shared__ float s_gauss[WAVES_PER_BLOCK][16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.y;
@@ -345,12 +383,12 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
   }
 }
 
-__global__ __launch_bounds__(256) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+__global__ __launch_bounds__(256, 4) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                         unsigned *__restrict__ counters,
                                                         const Detection *__restrict__ det,
                                                         SiftPointD *__restrict__ pts, int max_pts, int frac8)
 {
-  __shared__ float4 s_smp[WAVES_PER_BLOCK][SMP_W * SMP_W];
+  __shared__ __attribute__((aligned(16))) float s_smp[WAVES_PER_BLOCK][DESCR_TBL];
   __shared__ float s_gauss[WAVES_PER_BLOCK][16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.y;
