@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmisift.so")
+# MISIFT_LIB: developer override to A/B-test another build of the same library (tools/variants.sh)
+LIB_PATH = os.environ.get("MISIFT_LIB") or os.path.join(HERE, "libmisift.so")
 
 POINT_DTYPE = np.dtype([
     ("xpos", "<f4"), ("ypos", "<f4"), ("scale", "<f4"), ("sharpness", "<f4"),

@@ -708,22 +708,42 @@ struct RefineAllParams {
   int max_pts;
   unsigned cand_stride;
 };
-__global__ __launch_bounds__(64) void refine_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
-                                                        AllTaps taps, RefineAllParams R,
-                                                        unsigned *__restrict__ counters,
-                                                        const unsigned *__restrict__ cand,
-                                                        Detection *__restrict__ det)
+// Work decomposition (rocprof: the one-lane-per-candidate version needed 326 VGPRs -> 1 wave/SIMD, and each
+// of its 121 gathers touched 64 different cache lines): SIXTEEN lanes share one candidate, four candidates
+// per wavefront.  Lane c of a group owns column x-5+c of the 11x11 patch (11 row loads per lane, each load
+// instruction covers 4 x 11 contiguous pixels), blurs it vertically for the 4 scales and 3 rows, fetches the
+// horizontal neighbours with DPP row shifts inside its 16-lane row, and lanes 4..6 end up with the DoG values
+// of columns x-1..x+1; lane 5 collects the 27 values and runs the tests/refinement.  ~60 VGPRs, every value
+// computed with the same expression as dog_patch() (bit-identical).
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+#define ROW_SHR(n) (0x110 + (n))      // lane i reads lane i-n of its 16-lane row
+#define ROW_SHL(n) (0x100 + (n))      // lane i reads lane i+n of its 16-lane row
+
+__global__ __launch_bounds__(256) void refine_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                         AllTaps taps, RefineAllParams R,
+                                                         unsigned *__restrict__ counters,
+                                                         const unsigned *__restrict__ cand,
+                                                         Detection *__restrict__ det)
 {
   const int frame = blockIdx.y;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * R.max_pts;
-  // candidates of all octaves are flattened (finest first): every lane takes ONE candidate per pass,
-  // whatever its octave, so a wavefront never idles through the octaves it has no work in
+  const int lane = threadIdx.x & 63, c = lane & 15;
+  const unsigned group = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + (unsigned)(lane >> 4);
+  const unsigned ngroups = gridDim.x * 16u;
+  // candidates of all octaves are flattened (finest first) so no group idles through octaves it has no work in
   unsigned total = 0;
   for (int o = P.noct; o >= 1; o--) total += min(cnt[CNT_CAND + o], P.o[o].cand_cap);
-  for (unsigned fi = blockIdx.x * blockDim.x + threadIdx.x; fi < total; fi += gridDim.x * blockDim.x) {
+  const unsigned rounds = (total + ngroups - 1) / ngroups;       // wave-uniform trip count (DPP needs all lanes)
+  for (unsigned it = 0; it < rounds; it++) {
+    const unsigned fi = it * ngroups + group;
+    const bool live = fi < total;
     int o = P.noct;
-    unsigned ci = fi;
+    unsigned ci = live ? fi : 0u;
     for (int k = P.noct; k >= 1; k--) {
       const unsigned n = min(cnt[CNT_CAND + k], P.o[k].cand_cap);
       if (ci < n) { o = k; break; }
@@ -731,25 +751,58 @@ __global__ __launch_bounds__(64) void refine_all_kernel(const float *__restrict_
     }
     const int lw = P.o[o].w, lh = P.o[o].h, lp = P.o[o].p;
     const float *img = scratch + (long long)frame * P.frame_stride + P.o[o].img_off;
-    const unsigned code = cand[(size_t)frame * R.cand_stride + P.o[o].cand_off + ci];
+    const unsigned code = live ? cand[(size_t)frame * R.cand_stride + P.o[o].cand_off + ci] : 0u;
     const int x = code & 0x3fff, y = (code >> 14) & 0x3fff, s = code >> 28;
-    float tk[4][5];                                   // taps of blur scales s .. s+3 of this lane's octave
+    // ---- this lane's column of the patch: rows y-5 .. y+5 (clamped), column x-5+c (clamped; lanes 11..15 idle along)
+    const float *col = img + clampi(x + min(c, 10) - 5, 0, lw - 1);
+    float r[11];
 #pragma unroll
-    for (int bs = 0; bs < 4; bs++)
+    for (int j = 0; j < 11; j++) r[j] = col[(size_t)clampi(y + j - 5, 0, lh - 1) * lp];
+    // pair sums of the vertical taps are shared by the four scales
+    float ps[3][4];
 #pragma unroll
-      for (int j = 0; j < 5; j++) tk[bs][j] = taps.t[o].k[s + bs][j];
-    float d[3][3][3];
-    dog_patch(img, lw, lh, lp, tk, x, y, d);
-    Refined r;
-    if (!refine_math(d, x, y, s, R.thresh, R.edge_limit, R.factor, P.o[o].lowest_scale, R.scmul, r)) continue;
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int k = 1; k <= 4; k++) ps[dy][k - 1] = r[dy + 4 - k] + r[dy + 4 + k];
+    float d[3][3];                     // [plane s..s+2][dy] at this lane's column (meaningful for c = 4, 5, 6)
+    float prev[3];
+#pragma unroll
+    for (int bs = 0; bs < 4; bs++) {
+      const float *tk = taps.t[o].k[s + bs];
+      const float k0 = tk[0], k1 = tk[1], k2 = tk[2], k3 = tk[3], k4 = tk[4];
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++) {
+        const float v = conv9(k0, k1, k2, k3, k4, r[dy + 4], ps[dy][0], ps[dy][1], ps[dy][2], ps[dy][3]);
+        const float cur = conv9(k0, k1, k2, k3, k4, v,
+                                row_dpp<ROW_SHR(1)>(v) + row_dpp<ROW_SHL(1)>(v),
+                                row_dpp<ROW_SHR(2)>(v) + row_dpp<ROW_SHL(2)>(v),
+                                row_dpp<ROW_SHR(3)>(v) + row_dpp<ROW_SHL(3)>(v),
+                                row_dpp<ROW_SHR(4)>(v) + row_dpp<ROW_SHL(4)>(v));
+        if (bs > 0) d[bs - 1][dy] = cur - prev[dy];
+        prev[dy] = cur;
+      }
+    }
+    // ---- lane 5 of the group collects columns x-1 (lane 4) and x+1 (lane 6)
+    float dd[3][3][3];
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++) {
+        dd[p][dy][0] = row_dpp<ROW_SHR(1)>(d[p][dy]);
+        dd[p][dy][1] = d[p][dy];
+        dd[p][dy][2] = row_dpp<ROW_SHL(1)>(d[p][dy]);
+      }
+    if (!(live && c == 5)) continue;
+    Refined rr;
+    if (!refine_math(dd, x, y, s, R.thresh, R.edge_limit, R.factor, P.o[o].lowest_scale, R.scmul, rr)) continue;
     const unsigned idx = atomicAdd(&cnt[CNT_DET + o], 1u);
     if (idx >= (unsigned)R.max_pts) { atomicAdd(&cnt[CNT_PTOVF], 1u); continue; }
-    Detection *p = &fdet[(size_t)(o - 1) * R.max_pts + idx];
-    p->xpos = r.xpos;
-    p->ypos = r.ypos;
-    p->scale = r.scale;
-    p->sharpness = r.sharpness;
-    p->edgeness = r.edgeness;
+    Detection *pd = &fdet[(size_t)(o - 1) * R.max_pts + idx];
+    pd->xpos = rr.xpos;
+    pd->ypos = rr.ypos;
+    pd->scale = rr.scale;
+    pd->sharpness = rr.sharpness;
+    pd->edgeness = rr.edgeness;
   }
 }
 
@@ -893,7 +946,7 @@ int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
   R.cand_stride = cand_stride;
   const AllTaps at = pack_taps(taps, P.noct);
   LaunchScope ls(ctx, "refine");
-  hipLaunchKernelGGL(refine_all_kernel, dim3(128, P.nframes), dim3(64), 0, ctx->stream, scratch, P, at, R,
+  hipLaunchKernelGGL(refine_all_kernel, dim3(64, P.nframes), dim3(256), 0, ctx->stream, scratch, P, at, R,
                      ctx->d_counters, ctx->d_cand, ctx->d_det);
   return ls.finish();
 }
