@@ -34,30 +34,73 @@ __device__ __forceinline__ float wave_sum(float v)
 struct OrientResult { float ori1, ori2; bool has2; };      // meaningful in lane 0 only
 
 // Orientation of one keypoint by one wavefront (reference cudaSiftD.cu:984-1037).  hist[64], gauss[16] and
-// smp[128] are wave-private LDS slices; smp[121..127] must hold bin -1 (never matches).
+// smp[128], tgrid[169] are wave-private LDS slices; smp[121..127] must hold bin -1 (never matches).
 __device__ __forceinline__ OrientResult orient_core(const float *img, int w, int h, int pitch, bool q8, float xpos,
                                                     float ypos, float scale, float *hist, float *gauss,
-                                                    float2 *smp, int lane)
+                                                    float2 *smp, float *tgrid, int lane)
 {
   const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
   if (lane < 11) gauss[lane] = expf(i2sigma2 * (lane - 5) * (lane - 5));
   wave_sync();
   const float xp = xpos - 4.5f;
   const float yp = ypos - 4.5f;
+  // The 121 samples sit on an integer grid and take central differences of bilinear fetches one pixel to
+  // either side (cudaSiftD.cu:1003-1010): all 484 fetches are values of ONE 13x13 grid T[gy][gx] =
+  // tex(xp + gx, yp + gy), gx, gy = -1..11.  Evaluate the 169 grid values once (3 fetches per lane instead of
+  // 8) and difference them out of LDS.  The reference computes the coordinates as (xp + xd) +- 1, which
+  // differs from xp + (xd +- 1) in the last bit when a sum crosses a binade; that is checked here (20 + 20
+  // float comparisons) and such keypoints take the literal per-sample path, so results stay bit-identical.
+  bool same = true;
+  if (lane < 40) {
+    const float base = lane < 20 ? xp : yp;
+    const int k = lane < 20 ? lane : lane - 20;
+    if (k < 10) same = ((base + (float)k) + 1.0f) == (base + (float)(k + 1));          // xd = 0..9, "+1"
+    else same = ((base + (float)(k - 9)) - 1.0f) == (base + (float)(k - 10));           // xd = 1..10, "-1"
+  }
+  if (__all(same)) {
 #pragma unroll
-  for (int rep = 0; rep < 2; rep++) {
-    const int tx = lane + 64 * rep;
-    if (tx < 121) {
-      const int yd = tx / 11;
-      const int xd = tx - yd * 11;
-      const float xf = xp + xd;
-      const float yf = yp + yd;
-      const float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q8) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q8);
-      const float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q8) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q8);
-      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
-      if (bin > 31) bin = 0;
-      const float grad = sqrtf(dx * dx + dy * dy);
-      smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
+    for (int rep = 0; rep < 3; rep++) {
+      const int id = lane + 64 * rep;
+      if (id < 169) {
+        const int gy = id / 13, gx = id - gy * 13;          // grid index + 1
+        // the outermost ring is reached only as (xp + 10) + 1 resp. (xp + 0) - 1
+        const float xf = gx == 0 ? (xp + 0.0f) - 1.0f : (gx == 12 ? (xp + 10.0f) + 1.0f : xp + (float)(gx - 1));
+        const float yf = gy == 0 ? (yp + 0.0f) - 1.0f : (gy == 12 ? (yp + 10.0f) + 1.0f : yp + (float)(gy - 1));
+        tgrid[id] = tex2d(img, w, h, pitch, xf, yf, q8);
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+      const int tx = lane + 64 * rep;
+      if (tx < 121) {
+        const int yd = tx / 11;
+        const int xd = tx - yd * 11;
+        const float *t = tgrid + (yd + 1) * 13 + (xd + 1);
+        const float dx = t[1] - t[-1];
+        const float dy = t[13] - t[-13];
+        int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+        if (bin > 31) bin = 0;
+        const float grad = sqrtf(dx * dx + dy * dy);
+        smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int rep = 0; rep < 2; rep++) {
+      const int tx = lane + 64 * rep;
+      if (tx < 121) {
+        const int yd = tx / 11;
+        const int xd = tx - yd * 11;
+        const float xf = xp + xd;
+        const float yf = yp + yd;
+        const float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q8) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q8);
+        const float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q8) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q8);
+        int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+        if (bin > 31) bin = 0;
+        const float grad = sqrtf(dx * dx + dy * dy);
+        smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
+      }
     }
   }
   wave_sync();
@@ -80,24 +123,29 @@ __device__ __forceinline__ OrientResult orient_core(const float *img, int w, int
   const int x2m = (t >= 2 ? t - 2 : t + 30), x2p = (t <= 29 ? t + 2 : t - 30);
   if (lane < 32) hist[t + 32] = 6.0f * hist[t] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
   wave_sync();
+  // non-maximum suppression, then the two largest peaks by wave reductions (the reference scans the 32 bins
+  // serially, cudaSiftD.cu:1020-1033: first index of the maximum, first index of the runner-up)
+  float pk = 0.0f;
   if (lane < 32) {
     const float v = hist[32 + t];
-    hist[t] = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
+    pk = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
   }
-  wave_sync();
+  float maxval1 = pk;
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) maxval1 = fmaxf(maxval1, __shfl_xor(maxval1, m, 64));
+  maxval1 = __shfl(maxval1, 0, 64);
+  const unsigned long long b1 = __ballot(lane < 32 && pk == maxval1 && maxval1 > 0.0f);
+  const int i1 = b1 ? __ffsll((long long)b1) - 1 : -1;
+  const float pk2 = lane == i1 ? 0.0f : pk;
+  float maxval2 = pk2;
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) maxval2 = fmaxf(maxval2, __shfl_xor(maxval2, m, 64));
+  maxval2 = __shfl(maxval2, 0, 64);
+  const unsigned long long b2 = __ballot(lane < 32 && pk2 == maxval2 && maxval2 > 0.0f);
+  const int i2 = b2 ? __ffsll((long long)b2) - 1 : -1;
   OrientResult r;
   r.ori1 = 0.0f; r.ori2 = 0.0f; r.has2 = false;
   if (lane == 0) {
-    float maxval1 = 0.0f, maxval2 = 0.0f;
-    int i1 = -1, i2 = -1;
-    for (int i = 0; i < 32; i++) {
-      const float v = hist[i];
-      if (v > maxval1) {
-        maxval2 = maxval1; maxval1 = v; i2 = i1; i1 = i;
-      } else if (v > maxval2) {
-        maxval2 = v; i2 = i;
-      }
-    }
     if (i1 >= 0) {                                      // empty histogram -> orientation 0
       const float val1 = hist[32 + ((i1 + 1) & 31)];
       const float val2 = hist[32 + ((i1 + 31) & 31)];
@@ -124,6 +172,7 @@ __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ b
   __shared__ float s_hist[WAVES_PER_BLOCK][64];
   __shared__ float s_gauss[WAVES_PER_BLOCK][16];
   __shared__ float2 s_smp[WAVES_PER_BLOCK][128];     // (bin, weight) of the 121 samples
+  __shared__ float s_tgrid[WAVES_PER_BLOCK][176];   // 13x13 grid of bilinear fetches
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.y;
   const float *img = base + (long long)frame * base_frame_stride;
@@ -138,7 +187,7 @@ __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ b
 
   for (int bx = fstPts + blockIdx.x * WAVES_PER_BLOCK + wave; bx < totPts; bx += gridDim.x * WAVES_PER_BLOCK) {
     const OrientResult r = orient_core(img, w, h, pitch, q8, sift[bx].xpos, sift[bx].ypos, sift[bx].scale,
-                                       s_hist[wave], s_gauss[wave], s_smp[wave], lane);
+                                       s_hist[wave], s_gauss[wave], s_smp[wave], s_tgrid[wave], lane);
     if (lane == 0) {
       sift[bx].orientation = r.ori1;
       if (r.has2) {                                     // duplicate with the second orientation (cudaSiftD.cu:1038-1052)
@@ -361,6 +410,7 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
   __shared__ float s_hist[WAVES_PER_BLOCK][64];
   __shared__ float s_gauss[WAVES_PER_BLOCK][16];
   __shared__ float2 s_smp[WAVES_PER_BLOCK][128];
+  __shared__ float s_tgrid[WAVES_PER_BLOCK][176];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.y;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
@@ -374,7 +424,7 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
     const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
     Detection *d = &fdet[(size_t)(o - 1) * max_pts + i];
     const OrientResult r = orient_core(img, L.w, L.h, L.p, q8, d->xpos, d->ypos, d->scale, s_hist[wave],
-                                       s_gauss[wave], s_smp[wave], lane);
+                                       s_gauss[wave], s_smp[wave], s_tgrid[wave], lane);
     if (lane == 0) {
       d->ori1 = r.ori1;
       d->ori2 = r.ori2;
