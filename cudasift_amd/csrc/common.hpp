@@ -183,6 +183,9 @@ struct __attribute__((packed, aligned(4))) Pair2 { float a, b; };
 // tex2D<float>() of a pitch2D texture with clamp addressing and linear filtering
 // (cudaSiftH.cu:196-205).  frac8: round the weights to 8 fractional bits like the
 // CUDA texture unit.  Same operation sequence as oracle tex2d().
+// INTERIOR: the caller guarantees 1 <= x - 0.5 and x + 0.5 <= w - 2 (same for y), i.e. all four texels lie
+// inside the image: no clamping, no edge selects (same values, ~20 VALU instructions less per fetch).
+template <bool INTERIOR = false>
 __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch, float x, float y, bool frac8)
 {
   float xb = x - 0.5f, yb = y - 0.5f;
@@ -192,21 +195,29 @@ __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch
     a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
     b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
   }
-  fx = fminf(fmaxf(fx, -2.0f), (float)w);
-  fy = fminf(fmaxf(fy, -2.0f), (float)h);
-  const int ix = (int)fx, iy = (int)fy;
-  const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
-  const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
-  // The two texels of a row are adjacent except at the clamped image edges: fetch them with ONE 8-byte load at
-  // column xl (4-byte aligned is enough on gfx950) and pick.  rocprof: the per-keypoint kernels are bound by the
-  // L1's one-cache-line-per-clock lookup rate on these scattered gathers, so halving the load instructions
-  // (64 -> 32 per lane and descriptor) matters more than the extra selects.
-  const int xl = clampi(ix, 0, w - 2);
-  const Pair2 r0 = *reinterpret_cast<const Pair2 *>(img + (size_t)y0 * pitch + xl);
-  const Pair2 r1 = *reinterpret_cast<const Pair2 *>(img + (size_t)y1 * pitch + xl);
-  const bool lo0 = x0 == xl, hi1 = x1 == xl + 1;
-  const float t00 = lo0 ? r0.a : r0.b, t10 = hi1 ? r0.b : r0.a;
-  const float t01 = lo0 ? r1.a : r1.b, t11 = hi1 ? r1.b : r1.a;
+  float t00, t10, t01, t11;
+  if (INTERIOR) {
+    const int ix = (int)fx, iy = (int)fy;
+    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(img + (size_t)iy * pitch + ix);
+    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(img + (size_t)(iy + 1) * pitch + ix);
+    t00 = r0.a; t10 = r0.b; t01 = r1.a; t11 = r1.b;
+  } else {
+    fx = fminf(fmaxf(fx, -2.0f), (float)w);
+    fy = fminf(fmaxf(fy, -2.0f), (float)h);
+    const int ix = (int)fx, iy = (int)fy;
+    const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
+    const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+    // The two texels of a row are adjacent except at the clamped image edges: fetch them with ONE 8-byte load at
+    // column xl (4-byte aligned is enough on gfx950) and pick.  rocprof: the per-keypoint kernels are bound by the
+    // L1's one-cache-line-per-clock lookup rate on these scattered gathers, so halving the load instructions
+    // (64 -> 32 per lane and descriptor) matters more than the extra selects.
+    const int xl = clampi(ix, 0, w - 2);
+    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(img + (size_t)y0 * pitch + xl);
+    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(img + (size_t)y1 * pitch + xl);
+    const bool lo0 = x0 == xl, hi1 = x1 == xl + 1;
+    t00 = lo0 ? r0.a : r0.b; t10 = hi1 ? r0.b : r0.a;
+    t01 = lo0 ? r1.a : r1.b; t11 = hi1 ? r1.b : r1.a;
+  }
   const float ia = 1.0f - a, ib = 1.0f - b;
   float v = (ia * ib) * t00;
   v = __builtin_fmaf(a * ib, t10, v);

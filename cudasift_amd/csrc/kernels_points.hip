@@ -58,6 +58,9 @@ __device__ __forceinline__ OrientResult orient_core(const float *img, int w, int
     else same = ((base + (float)(k - 9)) - 1.0f) == (base + (float)(k - 10));           // xd = 1..10, "-1"
   }
   if (__all(same)) {
+    // grid spans xpos-5.5 .. xpos+6.5: fetches need no clamping when that (plus the bilinear footprint) is inside
+    const bool inside = xpos - 7.0f >= 1.0f && xpos + 8.0f <= (float)(w - 2) && ypos - 7.0f >= 1.0f &&
+                        ypos + 8.0f <= (float)(h - 2);
 #pragma unroll
     for (int rep = 0; rep < 3; rep++) {
       const int id = lane + 64 * rep;
@@ -66,7 +69,7 @@ __device__ __forceinline__ OrientResult orient_core(const float *img, int w, int
         // the outermost ring is reached only as (xp + 10) + 1 resp. (xp + 0) - 1
         const float xf = gx == 0 ? (xp + 0.0f) - 1.0f : (gx == 12 ? (xp + 10.0f) + 1.0f : xp + (float)(gx - 1));
         const float yf = gy == 0 ? (yp + 0.0f) - 1.0f : (gy == 12 ? (yp + 10.0f) + 1.0f : yp + (float)(gy - 1));
-        tgrid[id] = tex2d(img, w, h, pitch, xf, yf, q8);
+        tgrid[id] = inside ? tex2d<true>(img, w, h, pitch, xf, yf, q8) : tex2d<false>(img, w, h, pitch, xf, yf, q8);
       }
     }
     wave_sync();
@@ -270,6 +273,37 @@ __device__ __forceinline__ float footprint_sum(const float *base, float acc)
   return acc;
 }
 
+// Phase 1 of the descriptor: this lane's 4 of the 256 rotated samples -> votes and their table slots.
+template <bool INTERIOR>
+__device__ __forceinline__ void descr_samples(const float *img, int w, int h, int pitch, bool q8, float px, float py,
+                                              float sina, float cosa, float ssina, float scosa, const float *gauss,
+                                              int lane, float (&vx)[4], float (&vy)[4], int (&slotx)[4],
+                                              int (&sloty)[4], bool &has8)
+{
+#pragma unroll
+  for (int rep = 0; rep < 4; rep++) {
+    const int id = lane + 64 * rep;
+    const int tx = id & 15, y = id >> 4;
+    const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
+    const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+    const float dx = tex2d<INTERIOR>(img, w, h, pitch, xpos + cosa, ypos + sina, q8) -
+                     tex2d<INTERIOR>(img, w, h, pitch, xpos - cosa, ypos - sina, q8);
+    const float dy = tex2d<INTERIOR>(img, w, h, pitch, xpos - sina, ypos + cosa, q8) -
+                     tex2d<INTERIOR>(img, w, h, pitch, xpos + sina, ypos - cosa, q8);
+    const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+    float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+    const int angi = (int)angf;
+    angf -= angi;
+    const float iangf = 1.0f - angf;
+    has8 |= angi >= 8;
+    vx[rep] = iangf * grad;
+    vy[rep] = angf * grad;
+    const int pos = (y + 2) * SMP_W + tx + 2;
+    slotx[rep] = angi * SMP_PLANE + pos;                       // angi == 8: the special fifth plane
+    sloty[rep] = (angi >= 7 ? 0 : angi + 1) * SMP_PLANE + pos; // angi+1 wraps to bin 0 (7 and 8 alike)
+  }
+}
+
 // Normalised descriptor bins (8*cell + (lane&3)) and (+4) of one keypoint, cell = lane >> 2.
 __device__ __forceinline__ void descr_core(const float *img, int w, int h, int pitch, bool q8, float px, float py,
                                            float pscale, float orientation, float *tbl, const float *gauss,
@@ -288,28 +322,12 @@ __device__ __forceinline__ void descr_core(const float *img, int w, int h, int p
   float vx[4], vy[4];
   int slotx[4], sloty[4];         // plane-relative slot (bin * SMP_PLANE + position) of the two votes, bins 0..7 (8: special)
   bool has8 = false;
-#pragma unroll
-  for (int rep = 0; rep < 4; rep++) {
-    const int id = lane + 64 * rep;
-    const int tx = id & 15, y = id >> 4;
-    const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
-    const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
-    const float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q8) -
-                     tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, q8);
-    const float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, q8) -
-                     tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q8);
-    const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
-    float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
-    const int angi = (int)angf;
-    angf -= angi;
-    const float iangf = 1.0f - angf;
-    has8 |= angi >= 8;
-    vx[rep] = iangf * grad;
-    vy[rep] = angf * grad;
-    const int pos = (y + 2) * SMP_W + tx + 2;
-    slotx[rep] = angi * SMP_PLANE + pos;                       // angi == 8: the special fifth plane (handled below)
-    sloty[rep] = (angi >= 7 ? 0 : angi + 1) * SMP_PLANE + pos; // angi+1 wraps to bin 0 (7 and 8 alike)
-  }
+  // all 1024 texels of the patch inside the image (the usual case): fetches without clamping or edge selects
+  const float reach = 10.6067f * scale + 2.5f;
+  const bool interior = px - reach >= 1.0f && px + reach <= (float)(w - 2) && py - reach >= 1.0f &&
+                        py + reach <= (float)(h - 2);
+  if (interior) descr_samples<true>(img, w, h, pitch, q8, px, py, sina, cosa, ssina, scosa, gauss, lane, vx, vy, slotx, sloty, has8);
+  else descr_samples<false>(img, w, h, pitch, q8, px, py, sina, cosa, ssina, scosa, gauss, lane, vx, vy, slotx, sloty, has8);
   // ---- bins 0..3
 #pragma unroll
   for (int rep = 0; rep < 4; rep++) {
