@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
   }
 }
 
+#ifndef SCAN_UNROLL3
+#define SCAN_UNROLL3 1
+#endif
 // ------------------------------------------------------- fused DoG + scan
 // dog_scan_kernel: blur -> DoG in registers (nothing but the base image is read, nothing but
 // a short candidate list is written) and a cheap NECESSARY test per pixel and scale:
@@ -367,8 +370,10 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
   };
   float4 r0 = ld(y0 - 4), r1 = ld(y0 - 3), r2 = ld(y0 - 2), r3 = ld(y0 - 1), r4 = ld(y0);
   float4 r5 = ld(y0 + 1), r6 = ld(y0 + 2), r7 = ld(y0 + 3), r8 = ld(y0 + 4);
-  for (int y = y0; y < y1; y++) {
-    const float4 rnext = ld(y + 5);              // prefetch for the next row: its latency hides under this row's math
+  // One row of the scan; the 9-row window is passed by name so that the unrolled loop below can rotate the
+  // names instead of the registers (the rotation was 36 moves per row, 6 % of the loop's VALU issue slots).
+  auto row = [&](const float4 &r0, const float4 &r1, const float4 &r2, const float4 &r3, const float4 &r4,
+                 const float4 &r5, const float4 &r6, const float4 &r7, const float4 &r8, const int y) {
     // re-read the taps from LDS every row instead of pinning 80 VGPRs across the loop
     asm volatile("" ::: "memory");
     const Quad2 c = q2(r4), p1 = add_q2(q2(r3), q2(r5)), p2 = add_q2(q2(r2), q2(r6)), p3 = add_q2(q2(r1), q2(r7)),
@@ -396,7 +401,9 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
     for (int p = 0; p < NUM_SCALES; p++)
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(d[p].x), fabsf(d[p].y)), fmaxf(fabsf(d[p].z), fabsf(d[p].w))));
     // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
-    if (y >= 1 && y <= g.height - 2 && __any(amax > thresh)) {
+    // (tester lanes only: the halo lanes' blurs see zeros beyond the wavefront and would trip the test in every row —
+    //  with them masked, 99 % of the finest level's rows of a typical frame skip the extremum tests)
+    if (y >= 1 && y <= g.height - 2 && __any(tester && amax > thresh)) {
       unsigned mask = 0;
 #pragma unroll
       for (int s = 0; s < NUM_SCALES; s++) {
@@ -445,6 +452,22 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
         }
       }
     }
+  };
+  int y = y0;
+#if SCAN_UNROLL3
+  for (; y + 2 < y1; y += 3) {
+    const float4 n0 = ld(y + 5);                 // prefetch: latency hides under the row's math
+    row(r0, r1, r2, r3, r4, r5, r6, r7, r8, y);
+    const float4 n1 = ld(y + 6);
+    row(r1, r2, r3, r4, r5, r6, r7, r8, n0, y + 1);
+    const float4 n2 = ld(y + 7);
+    row(r2, r3, r4, r5, r6, r7, r8, n0, n1, y + 2);
+    r0 = r3; r1 = r4; r2 = r5; r3 = r6; r4 = r7; r5 = r8; r6 = n0; r7 = n1; r8 = n2;
+  }
+#endif
+  for (; y < y1; y++) {
+    const float4 rnext = ld(y + 5);
+    row(r0, r1, r2, r3, r4, r5, r6, r7, r8, y);
     r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = r8; r8 = rnext;
   }
 }
