@@ -139,10 +139,57 @@ __device__ __forceinline__ Quad2 blur_quad2(const Taps2 &t, Quad2 c, Quad2 p1, Q
 }
 __device__ __forceinline__ Quad2 q2(float4 v) { Quad2 r; r.lo = mk2(v.x, v.y); r.hi = mk2(v.z, v.w); return r; }
 __device__ __forceinline__ Quad2 add_q2(Quad2 a, Quad2 b) { Quad2 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; }
+__device__ __forceinline__ float4 add4p(float4 a, float4 b)      // two v_pk_add_f32
+{
+  const v2f l = mk2(a.x, a.y) + mk2(b.x, b.y), h = mk2(a.z, a.w) + mk2(b.z, b.w);
+  return make_float4(l.x, l.y, h.x, h.y);
+}
 __device__ __forceinline__ float4 sub_q2(Quad2 a, Quad2 b)
 {
   const v2f l = a.lo - b.lo, h = a.hi - b.hi;
   return make_float4(l.x, l.y, h.x, h.y);
+}
+
+// Scale-paired variant for the fused scan: the two halves of every packed operand are the SAME pixel at two
+// consecutive blur scales (taps {k_s[j], k_s+1[j]}), not two pixels of one scale.  Every operand of the
+// horizontal pass is then a register pair as it stands — the pixel-paired form needs pairs such as (y,z) or
+// (w, right.x) that straddle the quad's pairs and cost ~50 v_mov/v_pk_mov per row to assemble.  Same fmaf
+// chain per value as blur_quad().
+struct Pair4 { v2f x, y, z, w; };
+__device__ __forceinline__ v2f lane_from_left2(v2f v) { return mk2(lane_from_left(v.x), lane_from_left(v.y)); }
+__device__ __forceinline__ v2f lane_from_right2(v2f v) { return mk2(lane_from_right(v.x), lane_from_right(v.y)); }
+__device__ __forceinline__ v2f conv9p(const Taps2 &t, v2f c, v2f p1, v2f p2, v2f p3, v2f p4)
+{
+  v2f s = t.k0 * c;
+  s = pk_fma(t.k1, p1, s);
+  s = pk_fma(t.k2, p2, s);
+  s = pk_fma(t.k3, p3, s);
+  s = pk_fma(t.k4, p4, s);
+  return s;
+}
+__device__ __forceinline__ Pair4 blur_pair(const Taps2 &t, float4 c, float4 p1, float4 p2, float4 p3, float4 p4)
+{
+  Pair4 v;
+  v.x = conv9p(t, mk2(c.x, c.x), mk2(p1.x, p1.x), mk2(p2.x, p2.x), mk2(p3.x, p3.x), mk2(p4.x, p4.x));
+  v.y = conv9p(t, mk2(c.y, c.y), mk2(p1.y, p1.y), mk2(p2.y, p2.y), mk2(p3.y, p3.y), mk2(p4.y, p4.y));
+  v.z = conv9p(t, mk2(c.z, c.z), mk2(p1.z, p1.z), mk2(p2.z, p2.z), mk2(p3.z, p3.z), mk2(p4.z, p4.z));
+  v.w = conv9p(t, mk2(c.w, c.w), mk2(p1.w, p1.w), mk2(p2.w, p2.w), mk2(p3.w, p3.w), mk2(p4.w, p4.w));
+  const v2f lx = lane_from_left2(v.x), ly = lane_from_left2(v.y), lz = lane_from_left2(v.z), lw = lane_from_left2(v.w);
+  const v2f rx = lane_from_right2(v.x), ry = lane_from_right2(v.y), rz = lane_from_right2(v.z),
+            rw = lane_from_right2(v.w);
+  Pair4 h;
+  h.x = conv9p(t, v.x, lw + v.y, lz + v.z, ly + v.w, lx + rx);
+  h.y = conv9p(t, v.y, v.x + v.z, lw + v.w, lz + rx, ly + ry);
+  h.z = conv9p(t, v.z, v.y + v.w, v.x + rx, lw + ry, lz + rz);
+  h.w = conv9p(t, v.w, v.z + rx, v.y + ry, v.x + rz, lw + rw);
+  return h;
+}
+// tap pairs of the three scale pairs (1,2), (3,4), (5,6) the scan needs: dst[5*p + j] = {k[1+2p][j], k[2+2p][j]}
+#define NUM_SCAN_PAIRS 3
+__device__ __forceinline__ v2f scan_pair_tap(const LaplaceTaps &taps, int i)
+{
+  const int p = i / 5, j = i - 5 * p;
+  return mk2(taps.k[1 + 2 * p][j], taps.k[2 + 2 * p][j]);
 }
 
 // ------------------------------------------------------------------ Laplace
@@ -376,26 +423,29 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
                  const float4 &r5, const float4 &r6, const float4 &r7, const float4 &r8, const int y) {
     // re-read the taps from LDS every row instead of pinning 80 VGPRs across the loop
     asm volatile("" ::: "memory");
-    const Quad2 c = q2(r4), p1 = add_q2(q2(r3), q2(r5)), p2 = add_q2(q2(r2), q2(r6)), p3 = add_q2(q2(r1), q2(r7)),
-                p4 = add_q2(q2(r0), q2(r8));
+    const float4 c = r4, p1 = add4p(r3, r5), p2 = add4p(r2, r6), p3 = add4p(r1, r7), p4 = add4p(r0, r8);
     // Only blurs 1..6 are computed here: they give the five centre DoG planes d[0..4] (= reference planes
     // 1..5), which is all the necessary condition below needs; the outermost planes 0 and 6 (blurs 0 and 7)
     // are evaluated only for the survivors, by refine.  A quarter of the blur work of the dense path is saved.
+    // The six blurs are computed as three scale pairs (see blur_pair); the tap pairs of the next scale pair
+    // are fetched from LDS while the current one is computed.
     float4 d[NUM_SCALES];
-    // tap pairs of scale s+1 are fetched from LDS while scale s is computed
-    Taps2 tcur = load_taps2(tk + 5), tnext = load_taps2(tk + 10);
+    Taps2 tcur = load_taps2(tk), tnext = load_taps2(tk + 5);
     __builtin_amdgcn_sched_barrier(0);
-    Quad2 old = blur_quad2(tcur, c, p1, p2, p3, p4);
-#pragma unroll
-    for (int s = 2; s < NUM_BLURS - 1; s++) {
-      tcur = tnext;
-      asm volatile("" ::: "memory");            // re-read from LDS: do not pin the tap pairs across the row loop
-      if (s + 1 < NUM_BLURS - 1) tnext = load_taps2(tk + 5 * (s + 1));
-      __builtin_amdgcn_sched_barrier(0);        // prefetch stays ahead of the math that hides it
-      const Quad2 res = blur_quad2(tcur, c, p1, p2, p3, p4);
-      d[s - 2] = sub_q2(res, old);
-      old = res;
-    }
+    const Pair4 b0 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 1, 2
+    tcur = tnext;
+    asm volatile("" ::: "memory");                                 // re-read from LDS: do not pin tap pairs across the row loop
+    tnext = load_taps2(tk + 10);
+    __builtin_amdgcn_sched_barrier(0);
+    d[0] = make_float4(b0.x.y - b0.x.x, b0.y.y - b0.y.x, b0.z.y - b0.z.x, b0.w.y - b0.w.x);
+    const Pair4 b1 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 3, 4
+    tcur = tnext;
+    __builtin_amdgcn_sched_barrier(0);
+    d[1] = make_float4(b1.x.x - b0.x.y, b1.y.x - b0.y.y, b1.z.x - b0.z.y, b1.w.x - b0.w.y);
+    d[2] = make_float4(b1.x.y - b1.x.x, b1.y.y - b1.y.x, b1.z.y - b1.z.x, b1.w.y - b1.w.x);
+    const Pair4 b2 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 5, 6
+    d[3] = make_float4(b2.x.x - b1.x.y, b2.y.x - b1.y.y, b2.z.x - b1.z.y, b2.w.x - b1.w.y);
+    d[4] = make_float4(b2.x.y - b2.x.x, b2.y.y - b2.y.x, b2.z.y - b2.z.x, b2.w.y - b2.w.x);
     float amax = 0.0f;
 #pragma unroll
     for (int p = 0; p < NUM_SCALES; p++)
@@ -478,8 +528,9 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
                                                             unsigned *__restrict__ counters,
                                                             unsigned *__restrict__ cand, unsigned cand_cap, int aligned)
 {
-  __shared__ v2f s_taps[NUM_BLURS * 5];
-  fill_lds_taps(s_taps, taps);
+  __shared__ v2f s_taps[NUM_SCAN_PAIRS * 5];
+  if (threadIdx.x < NUM_SCAN_PAIRS * 5) s_taps[threadIdx.x] = scan_pair_tap(taps, threadIdx.x);
+  __syncthreads();
   const ItemCoord it = decode_item(g);
   if (!it.valid) return;
   const int lane = threadIdx.x & 63;
@@ -511,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void dog_scan_all_kernel(const float *__res
                                                               unsigned *__restrict__ counters,
                                                               unsigned *__restrict__ cand)
 {
-  __shared__ v2f s_taps[WAVES_PER_BLOCK][NUM_BLURS * 5];
+  __shared__ v2f s_taps[WAVES_PER_BLOCK][NUM_SCAN_PAIRS * 5];
   // no XCD remap here: items of different levels cost differently, and the hardware's round-robin
   // block -> XCD placement is what keeps the eight XCDs evenly loaded across the level boundaries
   const unsigned lb = blockIdx.x;
@@ -530,10 +581,7 @@ __global__ __launch_bounds__(256, 2) void dog_scan_all_kernel(const float *__res
   const int strip = (int)(r % L.nstrips);
   const int frame = (int)(r / L.nstrips);
   // this wavefront's private copy of its octave's tap pairs
-  if (lane < NUM_BLURS * 5) {
-    const float k = taps.t[L.octave].k[lane / 5][lane % 5];
-    s_taps[wave][lane] = mk2(k, k);
-  }
+  if (lane < NUM_SCAN_PAIRS * 5) s_taps[wave][lane] = scan_pair_tap(taps.t[L.octave], lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
