@@ -557,7 +557,10 @@ struct ScanAllGeom {
 };
 
 template <bool FAST>
-__global__ __launch_bounds__(256, 2) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
+#ifndef SCAN_OCC
+#define SCAN_OCC 3
+#endif
+__global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
                                                               AllTaps taps, float thresh,
                                                               unsigned *__restrict__ counters,
                                                               unsigned *__restrict__ cand)
