@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--unfused", action="store_true", help="separate laplace/detect kernels (DoG planes in HBM)")
+    ap.add_argument("--selftest-dist", action="store_true", help="single GPU: run the RCCL count all-gather / barrier path with world_size 1")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (H2D + extract + D2H) side measurement")
     args = ap.parse_args()
 
@@ -101,6 +102,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    elif args.selftest_dist:                                  # single GPU: exercise the RCCL path with one rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1)
 
     B = args.frames_per_gpu
     stream = torch.cuda.current_stream()
@@ -115,30 +120,59 @@ def main():
     counts = (C.c_int * B)()
     torch.cuda.synchronize()
 
-    from cudasift_amd.dist import gather_sift_records
+    from cudasift_amd.dist import RecordGather
 
-    def step():
-        capi.check(capi.lib().misift_extract_batch(ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
-                                                   INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
-                                                   MAX_PTS, counts), "misift_extract_batch")
-        n = np.frombuffer(counts, dtype=np.int32)
-        if world > 1:
-            gather_sift_records(dist, torch, pts.view(B, MAX_PTS * 576), n, rank, world, device)
-        return n
+    # Software-pipelined step loop, the same for every N: batch k is extracted AND packed on the device
+    # (misift_extract_batch_packed_async, nothing synchronises), then the host completes batch k-1: reads its
+    # per-frame counts back and — with more than one GPU — gathers the packed SiftPoint records of all ranks on
+    # rank 0 over RCCL/xGMI on a communication stream (BASELINE config 4), overlapping batch k's extraction.
+    # Every batch's read-back/gather completes before the closing barrier: nothing is skipped, only overlapped.
+    NSLOT, LAG = 3, 2          # batch k-2 is completed after batch k was queued: the GPU never waits for the host
+    packed = [torch.empty((B * MAX_PTS * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
+    cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(NSLOT)]
+    gather = RecordGather(dist, torch, rank, world, device, dst=0, nslots=NSLOT,
+                          force_collectives=args.selftest_dist)
+    torch.cuda.synchronize()
+
+    def enqueue(k):
+        slot = k % NSLOT
+        fe = gather.free_event(slot)
+        if fe is not None:
+            torch.cuda.current_stream().wait_event(fe)          # slot's previous transfer has left the buffers
+        capi.check(capi.lib().misift_extract_batch_packed_async(
+            ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(),
+            pts.data_ptr(), MAX_PTS, cnts[slot].data_ptr(), cnts[slot][B:].data_ptr(), packed[slot].data_ptr()),
+            "misift_extract_batch_packed_async")
+        ev = torch.cuda.Event()
+        ev.record()
+        gather.post(slot, cnts[slot][:B], packed[slot], ev)
+
+    def run(nsteps):
+        res = None
+        for k in range(nsteps):
+            enqueue(k)
+            if k >= LAG:
+                res = gather.complete((k - LAG) % NSLOT)
+        for k in range(max(0, nsteps - LAG), nsteps):
+            res = gather.complete(k % NSLOT)
+        all_counts = res[0]
+        if (all_counts < 0).any():
+            raise RuntimeError("candidate list overflow in the bench workload")
+        return all_counts
 
     def barrier():
-        if world > 1:
+        if world > 1 or args.selftest_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        n = step()
+    if args.warmup > 0:
+        run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n = step()
+    all_counts = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    n = all_counts[rank if world > 1 else 0]
     kp_per_frame = float(np.mean(n))
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -196,10 +230,18 @@ def main():
                         "reach HBM (see traffic), so achieved > peak is possible; the kernel itself is fp32-VALU-bound"}
     # the genuinely HBM-bound kernels, same definition (algorithmic bytes / summed launch time)
     hbm_kernels = {}
+    tbytes = {}
+    if os.path.exists(tj):
+        try:
+            tbytes = json.load(open(tj)).get("bytes_per_frame", {})
+        except Exception:
+            tbytes = {}
     for k in ("lowpass", "lowpass_down", "scaledown"):
         if k in kernels:
             a = alg[k] * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
             hbm_kernels[k] = {"achieved": round(a, 1), "frac": round(a / HBM_PEAK_GBS, 4)}
+            if k in tbytes:          # bytes actually moved (PMC): the fused prefilter never re-reads the finest level
+                hbm_kernels[k]["traffic_GBps"] = round(tbytes[k] * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e9, 1)
     roofline["hbm_bound_kernels"] = hbm_kernels
     # achievable-copy ceiling: device-to-device copy of 1 GiB, read + write bytes counted
     if rank == 0:
@@ -217,7 +259,8 @@ def main():
         del a, b
         roofline["copy_ceiling_GBps"] = round(copy_gbs, 1)
         for k in hbm_kernels:
-            hbm_kernels[k]["frac_of_copy_ceiling"] = round(hbm_kernels[k]["achieved"] / copy_gbs, 4)
+            if "traffic_GBps" in hbm_kernels[k]:
+                hbm_kernels[k]["traffic_frac_of_copy_ceiling"] = round(hbm_kernels[k]["traffic_GBps"] / copy_gbs, 4)
 
     # ---------------- PCIe-inclusive side measurement (never `value`): pinned host frames -> H2D -> extract -> D2H
     pcie = None
@@ -332,6 +375,24 @@ def main():
                          "(OpenCV cv::SIFT is not installed on this image)" % args.cpu_frames,
                "keypoints_per_frame": round(tot / args.cpu_frames, 1)}
 
+        # matcher CPU baseline: the reference's OWN AVX2/OpenMP routine MatchC3 (match.cu:102-130, built from the
+        # reference tree into oracle/_ref by oracle/build_ref.sh) on its own 16384 x 16384 problem
+        L = orc.ref_lib(16384)
+        if L is not None and match is not None:
+            a = orc.aligned_f32(16384 * 128); b = orc.aligned_f32(16384 * 128)
+            sc = orc.aligned_f32(16384); ix = np.zeros(16384, np.int32)
+            L.ref_generate(a.ctypes.data, b.ctypes.data, 1)
+            L.ref_match_c3(a.ctypes.data, b.ctypes.data, sc.ctypes.data, ix.ctypes.data)     # warm-up
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                L.ref_match_c3(a.ctypes.data, b.ctypes.data, sc.ctypes.data, ix.ctypes.data)
+            mdt = (time.perf_counter() - t0) / reps
+            match["cpu_baseline"] = {"value": round(16384.0 * 16384.0 / mdt / 1e6, 1), "unit": "Mpairs/s",
+                                     "cores": os.cpu_count(), "kind": "reference",
+                                     "sample": "reference MatchC3 (AVX2+FMA, OpenMP; argmax only, no runner-up) on "
+                                               "16384 x 16384 x 128, its own generator"}
+
     if rank == 0:
         out = {"metric": "1920x1080 SIFT frames/sec", "value": round(fps, 1), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -345,7 +406,7 @@ def main():
                           "keypoints_per_frame": round(kp_per_frame, 1)},
                "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu, "pcie_inclusive": pcie}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.selftest_dist:
         dist.destroy_process_group()
     ctx.close()
 

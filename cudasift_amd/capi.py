@@ -74,6 +74,7 @@ SIGNATURES = {
     "misift_match": (_i, [_vp, _vp, _i, _vp, _i]),
     "misift_match_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
     "misift_find_homography": (_i, [_vp, _vp, _i, _fp, _ip, _i, _f, _f, _f]),
+    "misift_extract_batch_packed_async": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "misift_lowpass_scaledown": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f, _vp, _i]),
     "misift_extract_batch_u8": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _ip]),
     "misift_pipe_create": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, C.POINTER(_vp)]),

@@ -761,6 +761,23 @@ extern "C" int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, 
   return MISIFT_OK;
 }
 
+extern "C" int misift_extract_batch_packed_async(misift_ctx *ctx, const float *d_imgs, int nframes,
+                                                 size_t frame_stride, int width, int height, int pitch,
+                                                 int num_octaves, float init_blur, float thresh, float lowest_scale,
+                                                 float *d_scratch, void *d_pts, int max_pts, int *d_counts_out,
+                                                 int *d_offsets_out, void *d_packed_out)
+{
+  ARG_CHECK(d_counts_out && d_offsets_out && d_packed_out);
+  int rc = misift_extract_enqueue(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch,
+                                  num_octaves, init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts,
+                                  max_pts);
+  if (rc) return rc;
+  rc = launch_export_counts(ctx, nframes, num_octaves, max_pts, d_counts_out, d_offsets_out);
+  if (rc) return rc;
+  return launch_pack_records(ctx, (const SiftPointD *)d_pts, max_pts, nframes, d_offsets_out,
+                             (SiftPointD *)d_packed_out);
+}
+
 extern "C" int misift_get_counters(misift_ctx *ctx, int frame, unsigned int *counters17)
 {
   ARG_CHECK(ctx && counters17 && frame >= 0 && frame < ctx->cap_frames);

@@ -136,6 +136,20 @@ int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, int nframes
                                float lowest_scale, float *d_scratch, void *d_pts,
                                int max_pts, int *d_counts_out);
 
+/* As misift_extract_batch_async, and additionally packs the valid records of all
+ * frames contiguously (frame after frame) into d_packed_out, ready for ONE
+ * device-to-device / xGMI / PCIe transfer: d_counts_out[f] = numPts of frame f
+ * (-1: that frame's candidate list overflowed), d_offsets_out[0..nframes] =
+ * exclusive prefix sum of the non-negative counts (records).  Nothing
+ * synchronises; this is what the multi-GPU gather of SiftData (BASELINE
+ * config 4) and the host pipeline send. */
+int misift_extract_batch_packed_async(misift_ctx *ctx, const float *d_imgs, int nframes,
+                                      size_t frame_stride, int width, int height, int pitch,
+                                      int num_octaves, float init_blur, float thresh,
+                                      float lowest_scale, float *d_scratch, void *d_pts,
+                                      int max_pts, int *d_counts_out, int *d_offsets_out,
+                                      void *d_packed_out);
+
 /* As misift_extract_batch, but the frames are 8-bit (pitch and frame_stride in
  * bytes): the prefilter converts in registers, so the result is bit-identical
  * to an fp32 upload of the same pixel values (what mainSift.cpp:41-42 does on

@@ -89,3 +89,57 @@ def test_gather_and_row_block_match_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "ok0").read() == "1" and open(tmp_path / "ok1").read() == "1"
+
+
+def _pipe_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from cudasift_amd.dist import RECORD_BYTES, RecordGather, unpack_records
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    B, cap, steps = 4, 12, 5
+    g = RecordGather(dist, torch, rank, world, dev, nslots=2)
+
+    def batch(r, k):
+        rng = np.random.default_rng(1000 * r + k)
+        c = rng.integers(0, cap + 1, size=B).astype(np.int32)
+        if k == 2:
+            c[r] = -1                                      # an overflowed frame: counted as 0 records
+        n = int(np.clip(c, 0, None).sum())
+        body = rng.integers(0, 255, size=n * RECORD_BYTES, dtype=np.uint8)
+        packed = np.zeros(B * cap * RECORD_BYTES, np.uint8)
+        packed[: body.size] = body
+        return c, body, packed
+
+    ok = True
+
+    def check(k, res):
+        nonlocal ok
+        all_counts, bufs = res
+        for r in range(world):
+            c, body, _ = batch(r, k)
+            ok &= bool(np.array_equal(all_counts[r], c))
+            if rank == 0:
+                ok &= bool(np.array_equal(bufs[r].numpy(), body))
+                frames = unpack_records(bufs[r], np.clip(all_counts[r], 0, None))
+                ok &= len(frames) == B
+        if rank != 0:
+            ok &= bufs is None
+
+    for k in range(steps):                                  # software pipeline: complete(k-1) after post(k)
+        c, _, packed = batch(rank, k)
+        g.post(k % 2, torch.from_numpy(c), torch.from_numpy(packed))
+        if k > 0:
+            check(k - 1, g.complete((k - 1) % 2))
+    check(steps - 1, g.complete((steps - 1) % 2))
+    open(os.path.join(out_dir, "pok%d" % rank), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_pipelined_record_gather_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "pok0").read() == "1" and open(tmp_path / "pok1").read() == "1"
