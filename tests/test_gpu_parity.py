@@ -513,3 +513,29 @@ def test_fused_lowpass_scaledown_bit_exact(ctx, h, w):
            down_equal=bool(np.array_equal(dn, ref_dn)))
     assert np.array_equal(lp, ref_lp)
     assert dn.shape == ref_dn.shape and np.array_equal(dn, ref_dn)
+
+
+def test_extract_batch_packed_async_equals_batch(ctx):
+    """misift_extract_batch_packed_async (what the multi-GPU gather ships): counts, offsets and the packed
+    records equal the synchronous batch call's, frame after frame."""
+    import ctypes as C
+    from cudasift_amd import capi
+    h, w, B, mp = 272, 480, 3, 4096
+    frames = np.stack([synth_frame(500 + i, width=w, height=h) for i in range(B)]).astype(np.float32)
+    rp, rn = ctx.extract_batch(frames, thresh=2.0, max_pts=mp)
+    d = ctx.upload(frames)
+    sc = capi.DevBuf(4 * capi.scratch_floats(w, h, 5, False) * B)
+    pts = ctx.zeros(576 * mp * B)
+    packed = ctx.zeros(576 * mp * B)
+    cnt = ctx.zeros(4 * (2 * B + 1))
+    capi.check(capi.lib().misift_extract_batch_packed_async(ctx.h, d.ptr, B, h * w, w, h, w, 5, 1.0, 2.0, 0.0, sc.ptr,
+                                                            pts.ptr, mp, cnt.ptr, cnt.ptr + 4 * B, packed.ptr),
+               "misift_extract_batch_packed_async")
+    ctx.sync()
+    ci = ctx.download(cnt, (2 * B + 1,), np.int32)
+    counts, offs = ci[:B], ci[B:]
+    assert np.array_equal(counts, rn) and counts.min() > 20
+    assert offs[0] == 0 and np.array_equal(np.diff(offs), counts)
+    recs = ctx.download(packed, (int(offs[B]),), capi.POINT_DTYPE)
+    for f in range(B):
+        assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(rp[f, :rn[f]])
