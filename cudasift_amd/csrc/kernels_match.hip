@@ -38,10 +38,12 @@ struct MatchGeom {
 
 __device__ __forceinline__ void top2_update(float sc, int p2, float &mx, float &sec, int &ix)
 {
-  // reference update rule (matching.cu:352-360): strict '>' so the earliest column wins ties.
-  // Branch-free (selects only): `if (sc > mx) {sec = mx; mx = sc; ix = p2;} else if (sc > sec) sec = sc;`
+  // reference update rule (matching.cu:352-360): `if (sc > mx) {sec = mx; mx = sc; ix = p2;} else if (sc > sec)
+  // sec = sc;` — strict '>' so the earliest column wins ties.  With sec <= mx always, the new (sec, mx) is the
+  // top two of {sec, mx, sc}: sec' = median of the three (one v_med3_f32), mx' = sc or mx.  4 VALU per score
+  // (compare, median, two selects) instead of 8 with fmaxf (which also costs canonicalising v_max x,x pairs).
   const bool gt = sc > mx;
-  sec = gt ? mx : fmaxf(sec, sc);       // sc <= mx here in the else case, so max(sec, sc) == the reference's update
+  sec = __builtin_amdgcn_fmed3f(sec, mx, sc);
   ix = gt ? p2 : ix;
   mx = gt ? sc : mx;
 }
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
   __syncthreads();
   for (int st = st0; st < st1; st++) {
     const int buf = (st - st0) & 1;
-    if (st + 1 < st1) gload(st + 1);
+    gload(min(st + 1, st1 - 1));     // unconditional (the last iteration re-fetches its own tile): no phi copies of the 32 staging registers
     const float4 *b0 = reinterpret_cast<const float4 *>(&Bs[buf][col * MT_BSTRIDE + half * 64]);
     const float4 *b1 = reinterpret_cast<const float4 *>(&Bs[buf][(col + 32) * MT_BSTRIDE + half * 64]);
     floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
 #pragma unroll
       for (int r = 0; r < 16; r++) top2_update(acc1[r], c1, mx[r], sec[r], ix[r]);
     }
-    if (st + 1 < st1) lstore(buf ^ 1);
+    lstore(buf ^ 1);
     __syncthreads();
   }
 
