@@ -265,6 +265,10 @@ int misift_ensure_tmp(misift_ctx *ctx, size_t bytes);
 int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride,
                            int width, int height, int pitch, int num_octaves, float init_blur, float thresh,
                            float lowest_scale, int scale_up, float *d_scratch, SiftPointD *pts, int max_pts);
+// synchronous extraction of a batch incl. the exact dense re-run when a candidate list overflowed
+int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride, int width,
+                        int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
+                        int scale_up, float *d_scratch, SiftPointD *pts, int max_pts, int *num_pts_out);
 // counts_out[f] = numPts of frame f (clamped to max_pts), or -1 when a candidate list of that frame overflowed;
 // offsets_out (optional, nframes+1 entries): exclusive prefix sum of the non-negative counts
 int launch_export_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *counts_out,

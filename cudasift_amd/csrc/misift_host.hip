@@ -684,7 +684,7 @@ static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pt
 // path (possible only for extreme thresh/contrast), redo the batch with the dense unfused kernels,
 // whose list holds true 3x3x3 extrema only; an overflow there is reported as an error, never dropped
 // silently (the reference silently caps at 32 candidates per 30x8 tile, cudaSiftD.cu:1371).
-static int extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride, int width,
+int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride, int width,
                         int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
                         int scale_up, float *d_scratch, SiftPointD *pts, int max_pts, int *num_pts_out)
 {
@@ -714,7 +714,7 @@ extern "C" int misift_extract(misift_ctx *ctx, const float *d_img, int width, in
                               void *d_pts, int max_pts, int *num_pts_out)
 {
   ARG_CHECK(num_pts_out != nullptr);
-  int rc = extract_sync(ctx, d_img, 0, 1, 0, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
+  int rc = misift_extract_sync(ctx, d_img, 0, 1, 0, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
                         scale_up, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
   if (scale_up) {                                    // cudaSiftH.cu:130
@@ -730,7 +730,7 @@ extern "C" int misift_extract_batch(misift_ctx *ctx, const float *d_imgs, int nf
                                     int *num_pts_out)
 {
   ARG_CHECK(num_pts_out != nullptr);
-  int rc = extract_sync(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
+  int rc = misift_extract_sync(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
                         init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
   return resolve_profile(ctx);
@@ -742,7 +742,7 @@ extern "C" int misift_extract_batch_u8(misift_ctx *ctx, const unsigned char *d_i
                                        int *num_pts_out)
 {
   ARG_CHECK(num_pts_out != nullptr);
-  int rc = extract_sync(ctx, d_imgs, 1, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
+  int rc = misift_extract_sync(ctx, d_imgs, 1, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
                         init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
   return resolve_profile(ctx);

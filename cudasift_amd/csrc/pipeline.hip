@@ -14,7 +14,8 @@
 //     for their extraction — measured 9.4 k instead of 16 k frames/s),
 //   * the valid records of all frames of a batch are packed contiguously on the device
 //     (pack kernels below) so the read-back is ONE sized copy instead of one per frame,
-//   * nothing is silently dropped: a frame whose candidate list overflowed is reported.
+//   * nothing is silently dropped: a batch in which a candidate list overflowed is redone with the
+//     exact dense kernels when it is collected.
 #include <string.h>
 #include <vector>
 #include "common.hpp"
@@ -251,33 +252,48 @@ extern "C" int misift_pipe_collect(misift_pipe *p, int *nframes_out, int *counts
   PipeSlot &s = p->slots[p->collected % p->depth];
   HIP_TRY(hipEventSynchronize(s.ev_counts));
   const int n = s.nframes;
-  const int *offs = s.h_counts + p->batch;
-  const size_t total = (size_t)offs[n];
   *nframes_out = n;
-  *nrecords_out = total;
+  *nrecords_out = 0;
   bool overflow = false;
-  for (int f = 0; f < n; f++) {
-    counts_out[f] = s.h_counts[f];
+  for (int f = 0; f < n; f++)
     if (s.h_counts[f] < 0) overflow = true;
-  }
   int rc = MISIFT_OK;
-  if (host_records && total) {
-    if (total > capacity_records) {
-      misift_set_error("misift_pipe_collect: %zu records but room for %zu", total, capacity_records);
+  if (overflow) {
+    // a candidate list of the fused scan overflowed (extreme contrast / tiny thresh): redo THIS batch from its
+    // frames (still in the slot) with the synchronous call, which falls back to the exact dense kernels; the
+    // batches queued behind it have already packed their results into their own slots
+    misift_ctx *ctx = p->ctx;
+    HIP_TRY(hipStreamSynchronize(p->s_compute));
+    hipStream_t saved = ctx->stream;
+    ctx->stream = p->s_compute;
+    std::vector<int> tmp((size_t)n);
+    rc = misift_extract_sync(ctx, s.d_frames, p->src_u8, n, (long long)p->frame_elems, p->width, p->height, p->width,
+                             p->num_octaves, p->init_blur, p->thresh, p->lowest_scale, 0, p->d_scratch, p->d_pts,
+                             p->max_pts, tmp.data());
+    if (!rc) rc = launch_export_counts(ctx, n, p->num_octaves, p->max_pts, s.d_counts, s.d_counts + p->batch);
+    if (!rc) rc = launch_pack_records(ctx, p->d_pts, p->max_pts, n, s.d_counts + p->batch, s.d_packed);
+    ctx->stream = saved;
+    if (rc) { s.nframes = 0; p->collected++; return rc; }
+    HIP_TRY(hipMemcpyAsync(s.h_counts, s.d_counts, sizeof(int) * (2 * (size_t)p->batch + 1), hipMemcpyDeviceToHost,
+                           p->s_compute));
+    HIP_TRY(hipStreamSynchronize(p->s_compute));
+  }
+  const int *offs2 = s.h_counts + p->batch;
+  const size_t total2 = (size_t)offs2[n];
+  *nrecords_out = total2;
+  for (int f = 0; f < n; f++) counts_out[f] = s.h_counts[f];
+  if (host_records && total2) {
+    if (total2 > capacity_records) {
+      misift_set_error("misift_pipe_collect: %zu records but room for %zu", total2, capacity_records);
       rc = MISIFT_ENOMEM;
     } else {
       // ev_counts implies the packing of this slot is complete; the copy must not queue behind later batches
-      HIP_TRY(hipMemcpyAsync(host_records, s.d_packed, sizeof(SiftPointD) * total, hipMemcpyDeviceToHost, p->s_rec));
+      HIP_TRY(hipMemcpyAsync(host_records, s.d_packed, sizeof(SiftPointD) * total2, hipMemcpyDeviceToHost, p->s_rec));
       HIP_TRY(hipStreamSynchronize(p->s_rec));
     }
   }
   s.nframes = 0;
   p->collected++;
-  if (!rc && overflow) {
-    misift_set_error("candidate list overflow in at least one frame of the batch (count -1): re-run those frames "
-                     "with misift_extract_batch (exact dense fallback) or raise thresh");
-    rc = MISIFT_ENOMEM;
-  }
   return rc;
 }
 

@@ -169,10 +169,11 @@ int misift_extract_batch_u8(misift_ctx *ctx, const unsigned char *d_imgs, int nf
  *   misift_pipe_submit   enqueues upload + extraction of `nframes` (<= batch_frames) frames and
  *                        returns at once; host_frames must stay valid until the batch is
  *                        collected (pinned memory from misift_host_alloc makes the upload async).
- *   misift_pipe_collect  waits for the oldest batch: counts_out[f] = numPts of frame f (or -1 if
- *                        that frame's candidate list overflowed -> MISIFT_ENOMEM, nothing is
- *                        dropped silently); the valid records of all frames, frame after frame,
- *                        are copied to host_records (capacity in records; may be NULL to skip). */
+ *   misift_pipe_collect  waits for the oldest batch: counts_out[f] = numPts of frame f; the valid
+ *                        records of all frames, frame after frame, are copied to host_records
+ *                        (capacity in records; may be NULL to skip).  If a candidate list of the
+ *                        fused scan overflowed, the batch is redone here with the exact dense
+ *                        kernels (as misift_extract_batch does): nothing is dropped silently. */
 typedef struct misift_pipe misift_pipe;
 int misift_pipe_create(misift_ctx *ctx, int width, int height, int batch_frames, int src_u8,
                        int num_octaves, float init_blur, float thresh, float lowest_scale,

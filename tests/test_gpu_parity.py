@@ -539,3 +539,57 @@ def test_extract_batch_packed_async_equals_batch(ctx):
     recs = ctx.download(packed, (int(offs[B]),), capi.POINT_DTYPE)
     for f in range(B):
         assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(rp[f, :rn[f]])
+
+
+def _noise_u8(h, w, seed):
+    return np.random.default_rng(seed).integers(0, 256, size=(h, w), dtype=np.uint8)
+
+
+def test_candidate_overflow_falls_back_to_dense_kernels(ctx):
+    """White noise at a tiny threshold floods the fused scan's pre-candidate list (cap = max(16384, w*h/4) per
+    octave); extract must notice and redo the frame with the dense kernels — same keypoints as the oracle,
+    nothing dropped silently (the reference caps silently at 32 candidates per tile, cudaSiftD.cu:1371)."""
+    img = _noise_u8(256, 256, 11).astype(np.float32)
+    ref, nref, cref = orc().extract(img, num_octaves=3, thresh=0.05, max_pts=32768)
+    got, ngot, cgot = ctx.extract(img, num_octaves=3, thresh=0.05, max_pts=32768)
+    record("overflow_fallback", n_oracle=int(nref), n_hip=int(ngot))
+    assert nref > 2000 and ngot == nref and np.array_equal(cref, cgot)
+    compare_points(ref[:nref], got[:ngot], "overflow_fallback_points", record)
+    # the premise: the fused path alone does overflow on this frame (the async entry reports it as count -1)
+    from cudasift_amd import capi
+    d = ctx.upload(img)
+    sc = capi.DevBuf(4 * capi.scratch_floats(256, 256, 3, False))
+    pts = ctx.zeros(576 * 32768)
+    cnt = ctx.zeros(4)
+    capi.check(capi.lib().misift_extract_batch_async(ctx.h, d.ptr, 1, 256 * 256, 256, 256, 256, 3, 1.0, 0.05, 0.0,
+                                                     sc.ptr, pts.ptr, 32768, cnt.ptr), "misift_extract_batch_async")
+    ctx.sync()
+    assert ctx.download(cnt, (1,), np.int32)[0] == -1
+
+
+def test_pipe_overflow_falls_back(ctx):
+    """The same inside the pipeline: the overflowed batch is redone when it is collected; the batches around
+    it are untouched."""
+    from cudasift_amd import capi
+    h, w, B = 256, 256, 2
+    frames = np.stack([_u8_frames(1, h, w, seed0=700)[0], _noise_u8(h, w, 11),      # batch 0: normal, noise
+                       _u8_frames(1, h, w, seed0=701)[0], _u8_frames(1, h, w, seed0=702)[0]])   # batch 1: normal
+    pin = capi.PinnedArray(frames.shape, np.uint8)
+    pin.array[...] = frames
+    out = capi.PinnedArray((B * 32768,), capi.POINT_DTYPE)
+    pipe = capi.Pipe(ctx, w, h, B, src_u8=True, num_octaves=3, thresh=0.05, max_pts=32768, depth=2)
+    pipe.submit(pin.ptr, B)
+    pipe.submit(pin.ptr + B * h * w, B)
+    got = []
+    for _ in range(2):
+        counts, nrec = pipe.collect(out.ptr, B * 32768)
+        got.append((counts, out.array[:nrec].copy()))
+    pipe.close()
+    for k, (counts, recs) in enumerate(got):
+        rp, rn = ctx.extract_batch_u8(frames[k * B:(k + 1) * B], num_octaves=3, thresh=0.05, max_pts=32768)
+        assert np.array_equal(counts, rn) and counts.min() >= 0
+        off = 0
+        for f in range(B):
+            assert _canon(recs[off:off + rn[f]]) == _canon(rp[f, :rn[f]])
+            off += rn[f]
+    assert got[0][0][1] > 2000
