@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--unfused", action="store_true", help="separate laplace/detect kernels (DoG planes in HBM)")
     ap.add_argument("--selftest-dist", action="store_true", help="single GPU: run the RCCL count all-gather / barrier path with world_size 1")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency side measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (H2D + extract + D2H) side measurement")
     args = ap.parse_args()
 
@@ -262,6 +263,34 @@ def main():
             if "traffic_GBps" in hbm_kernels[k]:
                 hbm_kernels[k]["traffic_frac_of_copy_ceiling"] = round(hbm_kernels[k]["traffic_GBps"] / copy_gbs, 4)
 
+    # ---------------- single-frame latencies (BASELINE configs 2 and 3; reported, never `value`)
+    latency = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        latency = {"note": "median wall time of one synchronous call, frame / records resident in HBM "
+                           "(misift_extract incl. its count read-back; misift_match of 2 x ~2000 features)"}
+        one = C.c_int(0)
+        for (lw, lh), key in (((1920, 1080), "extract_1920x1080_ms"), ((1280, 960), "extract_1280x960_ms")):
+            img = frames[0, :lh, :lw].contiguous()
+            ts = []
+            for i in range(60):
+                t1 = time.perf_counter()
+                capi.check(capi.lib().misift_extract(ctx.h, img.data_ptr(), lw, lh, lw, NUM_OCTAVES, INIT_BLUR, THRESH,
+                                                     0.0, 0, scratch.data_ptr(), pts.data_ptr(), MAX_PTS, C.byref(one)),
+                           "misift_extract")
+                ts.append(time.perf_counter() - t1)
+            latency[key] = round(1e3 * float(np.median(ts[10:])), 4)
+            latency[key.replace("_ms", "_keypoints")] = int(one.value)
+        npts = int(one.value) // 32 * 32
+        if npts >= 64:
+            a = pts[: npts * 576].clone()
+            ts = []
+            for i in range(40):
+                t1 = time.perf_counter()
+                capi.check(capi.lib().misift_match(ctx.h, a.data_ptr(), npts, pts.data_ptr(), npts), "misift_match")
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            latency["match_%dx%d_ms" % (npts, npts)] = round(1e3 * float(np.median(ts[10:])), 4)
+
     # ---------------- PCIe-inclusive side measurement (never `value`): pinned host frames -> H2D -> extract -> D2H
     pcie = None
     if rank == 0 and world == 1 and not args.no_pcie:
@@ -404,7 +433,7 @@ def main():
                                       (B, " + RCCL gather of SiftData to rank 0" if world > 1 else ""),
                           "frames_per_gpu": B, "path": "unfused" if args.unfused else "fused dog+detect",
                           "keypoints_per_frame": round(kp_per_frame, 1)},
-               "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu, "pcie_inclusive": pcie}
+               "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu, "pcie_inclusive": pcie, "single_frame": latency}
         print(json.dumps(out))
     if world > 1 or args.selftest_dist:
         dist.destroy_process_group()
