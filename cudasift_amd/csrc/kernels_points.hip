@@ -280,27 +280,41 @@ __device__ __forceinline__ void descr_samples(const float *img, int w, int h, in
                                               int lane, float (&vx)[4], float (&vy)[4], int (&slotx)[4],
                                               int (&sloty)[4], bool &has8)
 {
+  // two samples per trip of a rolled loop: 16 gathers in flight per lane instead of 32 keeps the kernel at
+  // 128 VGPRs (4 waves/SIMD); the results are moved into the named slots of the trip
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    float tvx[2], tvy[2];
+    int tsx[2], tsy[2];
 #pragma unroll
-  for (int rep = 0; rep < 4; rep++) {
-    const int id = lane + 64 * rep;
-    const int tx = id & 15, y = id >> 4;
-    const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
-    const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
-    const float dx = tex2d<INTERIOR>(img, w, h, pitch, xpos + cosa, ypos + sina, q8) -
-                     tex2d<INTERIOR>(img, w, h, pitch, xpos - cosa, ypos - sina, q8);
-    const float dy = tex2d<INTERIOR>(img, w, h, pitch, xpos - sina, ypos + cosa, q8) -
-                     tex2d<INTERIOR>(img, w, h, pitch, xpos + sina, ypos - cosa, q8);
-    const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
-    float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
-    const int angi = (int)angf;
-    angf -= angi;
-    const float iangf = 1.0f - angf;
-    has8 |= angi >= 8;
-    vx[rep] = iangf * grad;
-    vy[rep] = angf * grad;
-    const int pos = (y + 2) * SMP_W + tx + 2;
-    slotx[rep] = angi * SMP_PLANE + pos;                       // angi == 8: the special fifth plane
-    sloty[rep] = (angi >= 7 ? 0 : angi + 1) * SMP_PLANE + pos; // angi+1 wraps to bin 0 (7 and 8 alike)
+    for (int j = 0; j < 2; j++) {
+      const int id = lane + 64 * (2 * half + j);
+      const int tx = id & 15, y = id >> 4;
+      const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
+      const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+      const float dx = tex2d<INTERIOR>(img, w, h, pitch, xpos + cosa, ypos + sina, q8) -
+                       tex2d<INTERIOR>(img, w, h, pitch, xpos - cosa, ypos - sina, q8);
+      const float dy = tex2d<INTERIOR>(img, w, h, pitch, xpos - sina, ypos + cosa, q8) -
+                       tex2d<INTERIOR>(img, w, h, pitch, xpos + sina, ypos - cosa, q8);
+      const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+      float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+      const int angi = (int)angf;
+      angf -= angi;
+      const float iangf = 1.0f - angf;
+      has8 |= angi >= 8;
+      tvx[j] = iangf * grad;
+      tvy[j] = angf * grad;
+      const int pos = (y + 2) * SMP_W + tx + 2;
+      tsx[j] = angi * SMP_PLANE + pos;                       // angi == 8: the special fifth plane
+      tsy[j] = (angi >= 7 ? 0 : angi + 1) * SMP_PLANE + pos; // angi+1 wraps to bin 0 (7 and 8 alike)
+    }
+    if (half == 0) {
+      vx[0] = tvx[0]; vy[0] = tvy[0]; slotx[0] = tsx[0]; sloty[0] = tsy[0];
+      vx[1] = tvx[1]; vy[1] = tvy[1]; slotx[1] = tsx[1]; sloty[1] = tsy[1];
+    } else {
+      vx[2] = tvx[0]; vy[2] = tvy[0]; slotx[2] = tsx[0]; sloty[2] = tsy[0];
+      vx[3] = tvx[1]; vy[3] = tvy[1]; slotx[3] = tsx[1]; sloty[3] = tsy[1];
+    }
   }
 }
 
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
 }
 
 #ifndef DESCR_OCC
-#define DESCR_OCC 3
+#define DESCR_OCC 4
 #endif
 #ifndef DESCR_UNROLL
 #define DESCR_UNROLL 4
