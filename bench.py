@@ -182,6 +182,23 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     fps = world * B * args.steps / dt
 
+    # ---------------- distribution of the synchronous step (median + p10/p90), same workload, one
+    # misift_extract_batch call incl. its count read-back per sample
+    dist_ms = None
+    if rank == 0:
+        ts = []
+        for _ in range(40):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            capi.check(capi.lib().misift_extract_batch(ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
+                                                       INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
+                                                       MAX_PTS, counts), "misift_extract_batch")
+            ts.append(1e3 * (time.perf_counter() - t1))
+        ts = np.sort(np.array(ts[8:]))
+        dist_ms = {"p10": round(float(np.percentile(ts, 10)), 4), "p50": round(float(np.percentile(ts, 50)), 4),
+                   "p90": round(float(np.percentile(ts, 90)), 4), "samples": int(len(ts)),
+                   "note": "synchronous misift_extract_batch of the same 64-frame batch (no pipelining)"}
+
     # ---------------- per-kernel durations (HIP events on the launch stream) for the roofline
     ctx.profile_reset()
     ctx.profile_enable(True)
@@ -433,7 +450,8 @@ def main():
                                       (B, " + RCCL gather of SiftData to rank 0" if world > 1 else ""),
                           "frames_per_gpu": B, "path": "unfused" if args.unfused else "fused dog+detect",
                           "keypoints_per_frame": round(kp_per_frame, 1)},
-               "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu, "pcie_inclusive": pcie, "single_frame": latency}
+               "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu, "pcie_inclusive": pcie, "single_frame": latency,
+               "sync_step_ms": dist_ms}
         print(json.dumps(out))
     if world > 1 or args.selftest_dist:
         dist.destroy_process_group()

@@ -468,9 +468,6 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
 #ifndef DESCR_OCC
 #define DESCR_OCC 4
 #endif
-#ifndef DESCR_UNROLL
-#define DESCR_UNROLL 4
-#endif
 __global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                         unsigned *__restrict__ counters,
                                                         const Detection *__restrict__ det,
