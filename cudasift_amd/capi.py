@@ -40,6 +40,7 @@ SIGNATURES = {
     "misift_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "misift_ctx_destroy": (None, [_vp]),
     "misift_ctx_set_stream": (_i, [_vp, _vp]),
+    "misift_ctx_set_graph_replay": (_i, [_vp, _i]),
     "misift_ctx_sync": (_i, [_vp]),
     "misift_last_error": (C.c_char_p, []),
     "misift_default_options": (None, [C.POINTER(Options)]),

@@ -38,9 +38,25 @@ extern "C" const char *misift_last_error(void) { return g_err; }
 
 // --------------------------------------------------------------- profiling
 struct PendingProf { int slot; hipEvent_t a, b; };
+// Identity of one synchronous extraction call; a repeated call (the reference demo extracts the same image
+// 1000 times, mainSift.cpp:64-69; a tracker calls with the same buffers every frame) replays a captured hipGraph.
+struct CallKey {
+  const void *imgs; float *scratch; void *pts;
+  int src_u8, nframes, width, height, pitch, num_octaves, scale_up, max_pts, fused, texfrac, fixnum, alloc_gen;
+  long long frame_stride;
+  float init_blur, thresh, lowest_scale;
+  bool operator==(const CallKey &o) const { return memcmp(this, &o, sizeof(CallKey)) == 0; }
+};
 struct CtxExtra {
   std::vector<PendingProf> pending;
   std::vector<hipEvent_t> pool;
+  // hipGraph replay of the launch sequence of misift_extract_enqueue (launch-latency bound for a single frame)
+  int graph_mode = 0;                 // off by default (measured slower, see misift.h); MISIFT_GRAPH=1 / misift_ctx_set_graph_replay
+  bool have_last = false, have_graph = false;
+  CallKey last_key, graph_key;
+  hipGraphExec_t gexec = nullptr;
+  hipStream_t gstream = nullptr;      // capture / replay stream (capture is not allowed on the null stream)
+  hipEvent_t gev_in = nullptr, gev_out = nullptr;
 };
 static CtxExtra *extra(misift_ctx *ctx);
 
@@ -171,6 +187,7 @@ extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char *e = getenv("MISIFT_GRAPH")) f->x.graph_mode = atoi(e) != 0;
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
   int rc = misift_ensure_frames(ctx, 1, 65536);
@@ -187,6 +204,10 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   CtxExtra *x = extra(ctx);
+  if (x->gexec) hipGraphExecDestroy(x->gexec);
+  if (x->gstream) { hipStreamSynchronize(x->gstream); hipStreamDestroy(x->gstream); }
+  if (x->gev_in) hipEventDestroy(x->gev_in);
+  if (x->gev_out) hipEventDestroy(x->gev_out);
   for (auto &p : x->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : x->pool) hipEventDestroy(e);
   if (ctx->d_counters) hipFree(ctx->d_counters);
@@ -198,6 +219,13 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   hipEventDestroy(ctx->ev0);
   hipEventDestroy(ctx->ev1);
   delete reinterpret_cast<CtxFull *>(ctx);
+}
+
+extern "C" int misift_ctx_set_graph_replay(misift_ctx *ctx, int on)
+{
+  ARG_CHECK(ctx != nullptr);
+  extra(ctx)->graph_mode = on ? 1 : 0;
+  return MISIFT_OK;
 }
 
 extern "C" int misift_ctx_set_stream(misift_ctx *ctx, void *stream)
@@ -236,6 +264,7 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
     if (ctx->h_counters) HIP_TRY(hipHostFree(ctx->h_counters));
     ctx->d_counters = nullptr; ctx->h_counters = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes));
+    ctx->alloc_gen++;
     HIP_TRY(hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, hipHostMallocDefault));
     HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, ctx->stream));
     memset(ctx->h_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes);
@@ -246,6 +275,7 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
     if (ctx->d_cand) HIP_TRY(hipFree(ctx->d_cand));
     ctx->d_cand = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->d_cand, sizeof(unsigned) * cc * nf));
+    ctx->alloc_gen++;
     ctx->cand_cap = cc;
     ctx->cap_frames = nf;
   }
@@ -275,6 +305,7 @@ static int ensure_det(misift_ctx *ctx, int nframes, int max_pts)
     if (ctx->d_det) HIP_TRY(hipFree(ctx->d_det));
     ctx->d_det = nullptr; ctx->cap_det_frames = 0; ctx->det_max_pts = 0;
     HIP_TRY(hipMalloc((void **)&ctx->d_det, sizeof(Detection) * (size_t)nf * MISIFT_MAX_OCTAVES * mp));
+    ctx->alloc_gen++;
     ctx->cap_det_frames = nf;
     ctx->det_max_pts = mp;
   }
@@ -684,14 +715,87 @@ static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pt
 // path (possible only for extreme thresh/contrast), redo the batch with the dense unfused kernels,
 // whose list holds true 3x3x3 extrema only; an overflow there is reported as an error, never dropped
 // silently (the reference silently caps at 32 candidates per 30x8 tile, cudaSiftD.cu:1371).
+// Enqueue through a captured hipGraph when this exact call was seen before: the first call runs normally (and
+// allocates whatever the context needs), the second is captured while it is enqueued, later ones are one
+// hipGraphLaunch instead of ~10 launches.  Returns 1 if the work was queued here, 0 if the caller must enqueue it
+// the ordinary way (graphs disabled, profiling on, unsuitable call, or any capture problem — which turns graphs off).
+static int enqueue_via_graph(misift_ctx *ctx, const CallKey &key, const void *d_imgs, long long frame_stride,
+                             float *d_scratch, SiftPointD *pts)
+{
+  CtxExtra *x = extra(ctx);
+  if (!x->graph_mode || ctx->profile || !d_scratch || key.scale_up || !key.fused) return 0;
+  if (x->have_graph && x->graph_key == key) {
+    if (hipEventRecord(x->gev_in, ctx->stream) != hipSuccess || hipStreamWaitEvent(x->gstream, x->gev_in, 0) != hipSuccess ||
+        hipGraphLaunch(x->gexec, x->gstream) != hipSuccess || hipEventRecord(x->gev_out, x->gstream) != hipSuccess ||
+        hipStreamWaitEvent(ctx->stream, x->gev_out, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      x->graph_mode = 0;
+      return 0;
+    }
+    return 1;
+  }
+  const bool repeat = x->have_last && x->last_key == key;
+  x->last_key = key;
+  x->have_last = true;
+  if (!repeat) return 0;
+  // second identical call: capture it
+  if (!x->gstream) {
+    if (hipStreamCreateWithFlags(&x->gstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&x->gev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x->gev_out, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      x->graph_mode = 0;
+      return 0;
+    }
+  }
+  if (x->have_graph) { hipGraphExecDestroy(x->gexec); x->gexec = nullptr; x->have_graph = false; }
+  hipStream_t saved = ctx->stream;
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(x->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    x->graph_mode = 0;
+    return 0;
+  }
+  ctx->stream = x->gstream;
+  const int rc = misift_extract_enqueue(ctx, d_imgs, key.src_u8, key.nframes, frame_stride, key.width, key.height,
+                                        key.pitch, key.num_octaves, key.init_blur, key.thresh, key.lowest_scale, 0,
+                                        d_scratch, pts, key.max_pts);
+  ctx->stream = saved;
+  const hipError_t e = hipStreamEndCapture(x->gstream, &graph);
+  if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&x->gexec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    if (graph) hipGraphDestroy(graph);
+    x->gexec = nullptr;
+    x->graph_mode = 0;                 // never try again on this context; the caller enqueues the ordinary way
+    return 0;
+  }
+  hipGraphDestroy(graph);
+  x->graph_key = key;
+  x->have_graph = true;
+  return enqueue_via_graph(ctx, key, d_imgs, frame_stride, d_scratch, pts);      // replay what was just captured
+}
+
 int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride, int width,
                         int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
                         int scale_up, float *d_scratch, SiftPointD *pts, int max_pts, int *num_pts_out)
 {
   const int fused_saved = ctx->opt.fused;
   for (int attempt = 0; attempt < 2; attempt++) {
-    int rc = misift_extract_enqueue(ctx, d_imgs, src_u8, nframes, frame_stride, width, height, pitch, num_octaves,
-                                    init_blur, thresh, lowest_scale, scale_up, d_scratch, pts, max_pts);
+    int rc = MISIFT_OK;
+    int queued = 0;
+    if (attempt == 0 && ctx && d_imgs && pts) {
+      CallKey key;
+      memset(&key, 0, sizeof(key));
+      key.imgs = d_imgs; key.scratch = d_scratch; key.pts = pts;
+      key.src_u8 = src_u8; key.nframes = nframes; key.width = width; key.height = height; key.pitch = pitch;
+      key.num_octaves = num_octaves; key.scale_up = scale_up; key.max_pts = max_pts; key.fused = ctx->opt.fused;
+      key.texfrac = ctx->opt.texfrac_bits; key.fixnum = ctx->opt.fix_numpts; key.alloc_gen = ctx->alloc_gen;
+      key.frame_stride = frame_stride; key.init_blur = init_blur; key.thresh = thresh; key.lowest_scale = lowest_scale;
+      queued = enqueue_via_graph(ctx, key, d_imgs, frame_stride, d_scratch, pts);
+    }
+    if (!queued)
+      rc = misift_extract_enqueue(ctx, d_imgs, src_u8, nframes, frame_stride, width, height, pitch, num_octaves,
+                                  init_blur, thresh, lowest_scale, scale_up, d_scratch, pts, max_pts);
     bool ovf = false;
     if (!rc) rc = read_counts(ctx, nframes, num_octaves, max_pts, num_pts_out, &ovf);
     if (rc) { ctx->opt.fused = fused_saved; return rc; }

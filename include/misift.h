@@ -67,6 +67,13 @@ int misift_device_info(int device, char *name, int name_len, int *mem_clock_khz,
                        int *bus_width_bits, size_t *total_mem_bytes,
                        int *num_cus, int *lds_bytes_per_block);
 
+/* hipGraph replay of repeated synchronous calls: when misift_extract / misift_extract_batch is called again
+ * with exactly the same arguments and buffers (the reference demo does, mainSift.cpp:64-69), the launch
+ * sequence is captured on the 2nd occurrence and replayed afterwards as one hipGraphLaunch.  OFF by default:
+ * on ROCm 7.2 / MI355X the replay measured SLOWER than the ~10 direct launches (single 1080p frame 0.199 ms vs
+ * 0.170 ms; 64-frame batch 1.508 vs 1.502 ms).  Also MISIFT_GRAPH=1 in the environment at context creation. */
+int misift_ctx_set_graph_replay(misift_ctx *ctx, int on);
+
 /* One context per device; `stream` is a hipStream_t (NULL = the null stream).
  * The context owns the per-frame point counters (cudaSiftD.cu:13-14), a
  * pinned read-back buffer and the filter tap tables (cudaSiftD.cu:15-17). */

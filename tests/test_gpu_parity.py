@@ -593,3 +593,35 @@ def test_pipe_overflow_falls_back(ctx):
             assert _canon(recs[off:off + rn[f]]) == _canon(rp[f, :rn[f]])
             off += rn[f]
     assert got[0][0][1] > 2000
+
+
+def test_repeated_call_replays_graph_with_identical_results(ctx, stereo):
+    """A synchronous call repeated with the same buffers (what mainSift.cpp:64-69 does 1000 times) is captured
+    into a hipGraph on its 2nd occurrence and replayed from the 3rd: every repetition must return the same
+    keypoint set as the first, ordinary run — also after an interleaved different call and a re-allocation."""
+    import ctypes as C
+    from cudasift_amd import capi
+    img = stereo[0]
+    h, w = img.shape
+    src, p = ctx.upload_image(img)
+    sc = capi.DevBuf(4 * capi.scratch_floats(w, h, 5, False))
+    pts = ctx.zeros(576 * 8192)
+    n = C.c_int(0)
+
+    def run():
+        capi.check(capi.lib().misift_extract(ctx.h, src.ptr, w, h, p, 5, 1.0, 3.5, 0.0, 0, sc.ptr, pts.ptr, 8192,
+                                             C.byref(n)), "misift_extract")
+        return _canon(ctx.download(pts, (n.value,), capi.POINT_DTYPE))
+    first = run()                                           # ordinary launches (replay is off by default)
+    assert n.value > 500
+    capi.check(capi.lib().misift_ctx_set_graph_replay(ctx.h, 1), "misift_ctx_set_graph_replay")
+    for _ in range(5):
+        assert run() == first
+    ctx.extract(stereo[1], thresh=3.5)                      # a different call in between (new buffers)
+    assert run() == first
+    big = np.stack([synth_frame(900 + i, width=640, height=480) for i in range(3)]).astype(np.float32)
+    ctx.extract_batch(big, thresh=3.0, max_pts=2048)         # forces the per-frame buffers to grow (re-allocation)
+    for _ in range(3):
+        assert run() == first
+    capi.check(capi.lib().misift_ctx_set_graph_replay(ctx.h, 0), "misift_ctx_set_graph_replay")
+    assert run() == first
