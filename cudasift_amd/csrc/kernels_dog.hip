@@ -983,7 +983,7 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
     const int nquads = (L.w + 3) / 4;
     S.nstrips = (nquads + (OUT_LANES - 2) - 1) / (OUT_LANES - 2);
     if (S.nstrips < 1) S.nstrips = 1;
-    const long long target = (long long)ctx->num_cus * 16;
+    const long long target = (long long)ctx->num_cus * ctx->scan_waves_per_cu;
     long long want = (target + (long long)P.nframes * S.nstrips - 1) / ((long long)P.nframes * S.nstrips);
     if (want < 1) want = 1;
     int seg = (int)((L.h + want - 1) / want);
