@@ -251,6 +251,8 @@ struct misift_ctx {
   void *d_match_tmp;            // matcher partial results
   size_t match_tmp_bytes;
   int num_cus;
+  int orient_blocks_per_cu;
+  int point_blocks_per_cu;                     // grid sizing of the per-keypoint kernels
   int strip_waves_per_cu, scan_waves_per_cu;   // segment sizing targets of the streaming kernels
   int alloc_gen;                // bumped whenever a context-owned device buffer is reallocated (invalidates captured graphs)
   hipEvent_t ev0, ev1;

@@ -541,11 +541,12 @@ __global__ void rescale_kernel(SiftPointD *pts, int npts, float scale)
 }
 
 // ------------------------------------------------------------- host wrappers
-static inline int points_grid_x(misift_ctx *ctx, int nframes)
+static inline int points_grid_x(misift_ctx *ctx, int nframes, int blocks_per_cu = 0)
 {
+  if (blocks_per_cu <= 0) blocks_per_cu = ctx->point_blocks_per_cu;
   // enough wavefronts to cover a few thousand keypoints per frame while keeping
   // the total near a few waves per SIMD when many frames are batched
-  int per_frame = (ctx->num_cus * 8 + nframes - 1) / nframes;
+  int per_frame = (ctx->num_cus * blocks_per_cu + nframes - 1) / nframes;
   if (per_frame < 8) per_frame = 8;
   if (per_frame > 512) per_frame = 512;
   return per_frame;
@@ -575,7 +576,7 @@ int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
 {
   (void)pts;
   LaunchScope ls(ctx, "orient_all");
-  hipLaunchKernelGGL(orient_all_kernel, dim3(points_grid_x(ctx, P.nframes), P.nframes), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(orient_all_kernel, dim3(points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu), P.nframes), dim3(256), 0, ctx->stream,
                      scratch, P, ctx->d_counters, ctx->d_det, max_pts, ctx->opt.texfrac_bits == 8 ? 1 : 0);
   return ls.finish();
 }

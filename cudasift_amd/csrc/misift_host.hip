@@ -191,6 +191,10 @@ extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
   // work decomposition of the streaming kernels: wavefronts aimed at per CU and launch (developer knobs)
   ctx->strip_waves_per_cu = 32;   // measured: lowpass_down 0.247 -> 0.220 ms vs 16 (better balance over the CUs, 64-row segments)
   ctx->scan_waves_per_cu = 32;
+  ctx->orient_blocks_per_cu = 4;
+  if (const char *e = getenv("MISIFT_ORIENT_BLOCKS")) ctx->orient_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 4;
+  ctx->point_blocks_per_cu = 8;
+  if (const char *e = getenv("MISIFT_POINT_BLOCKS")) ctx->point_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 8;
   if (const char *e = getenv("MISIFT_STRIP_WAVES")) ctx->strip_waves_per_cu = atoi(e) > 0 ? atoi(e) : 16;
   if (const char *e = getenv("MISIFT_SCAN_WAVES")) ctx->scan_waves_per_cu = atoi(e) > 0 ? atoi(e) : 16;
   HIP_TRY(hipEventCreate(&ctx->ev0));
