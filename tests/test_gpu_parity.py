@@ -625,3 +625,15 @@ def test_repeated_call_replays_graph_with_identical_results(ctx, stereo):
         assert run() == first
     capi.check(capi.lib().misift_ctx_set_graph_replay(ctx.h, 0), "misift_ctx_set_graph_replay")
     assert run() == first
+
+
+def test_extract_large_frame_4096x3072(ctx):
+    """A 12.6 Mpx frame (17 strips, many segments per level, candidate words with 12-bit coordinates): same
+    keypoint set and counters as the oracle."""
+    img = synth_frame(4242, width=4096, height=3072)
+    ref, nref, cref = orc().extract(img, num_octaves=5, thresh=3.0, max_pts=32768)
+    got, ngot, cgot = ctx.extract(img, num_octaves=5, thresh=3.0, max_pts=32768)
+    record("extract_4096x3072", n_oracle=int(nref), n_hip=int(ngot))
+    assert nref > 5000 and ngot == nref and np.array_equal(cref, cgot)
+    tot = int(cref[11])
+    compare_points(ref[:tot], got[:tot], "extract_4096x3072_points", record)
