@@ -1,23 +1,24 @@
 // kernels_dog.hip — difference-of-Gaussians and scale-space extrema for gfx950.
 //
-//   laplace_kernel     replaces LaplaceMultiMem   (reference cudaSiftD.cu:1753-1793, host cudaSiftH.cu:460-487)
-//   detect_kernel      replaces the 3x3x3 extremum search of FindPointsMultiNew (cudaSiftD.cu:1292-1366)
-//   dog_detect_kernel  = laplace + detect fused: the 7 DoG planes never touch HBM
-//   refine_kernel      replaces the edge test / sub-pixel refinement / append of
-//                      FindPointsMultiNew (cudaSiftD.cu:1379-1430); in the fused path it
-//                      recomputes the 3x3x3 DoG neighbourhood of each candidate from the
-//                      octave base image with the same fmaf chains (bit-identical values)
+//   laplace_kernel        replaces LaplaceMultiMem   (reference cudaSiftD.cu:1753-1793, host cudaSiftH.cu:460-487)
+//   detect_kernel         replaces the 3x3x3 extremum search of FindPointsMultiNew (cudaSiftD.cu:1292-1366)
+//   dog_scan_kernel       = laplace + a cheap NECESSARY extremum test fused: DoG values exist only in registers,
+//   dog_scan_all_kernel     the < 0.1 % survivors go to a candidate list (..._all: every octave of every frame in
+//                           one launch — the default path)
+//   refine_kernel         replaces the edge test / sub-pixel refinement / append of FindPointsMultiNew
+//   refine_all_kernel       (cudaSiftD.cu:1379-1430); after a scan it recomputes the 3x3x3 DoG neighbourhood of
+//                           each candidate from the octave base image with the same fmaf chains (bit-identical
+//                           values) and applies the reference's full 26-neighbour test first (..._all: 16 lanes
+//                           per candidate, DPP row shifts)
 //
-// Streaming design (see common.hpp): a wavefront walks down a 256-px strip; the
-// 9-row raw window, the 8 vertical blur results and (fused path) a 3-row window
-// of all 7 DoG planes live in VGPRs; horizontal neighbours come from adjacent
-// lanes by DPP.  Unfused laplace is HBM-write-bound (4 B read + 28 B written per
-// px); unfused detect is HBM-read-bound (28 B/px); the fused kernel reads 4 B/px
-// and is VALU-bound.
+// Streaming design (see common.hpp): a wavefront walks down a 256-px strip; the 9-row raw window lives in VGPRs
+// (rotating names in a 3x unrolled loop), horizontal neighbours come from adjacent lanes by DPP, blurs are
+// packed v_pk_fma_f32 over PAIRS OF SCALES with the tap pairs read from LDS.  Unfused laplace is HBM-write-bound
+// (4 B read + 28 B written per px); unfused detect is HBM-read-bound (28 B/px); the scan reads ~5 B/px and is
+// fp32-VALU-bound (DESIGN.md section 4 has the measurements behind each of these choices).
 //
 // Compiled with -ffp-contract=off: every multiply-add below that is meant to be
 // fused is an explicit __builtin_fmaf, exactly as in oracle/sift_oracle.c.
-#include <stdlib.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>

@@ -5,8 +5,9 @@
 //
 // The only dense contraction of the pipeline: S = D1 (n1 x 128) * D2^T (128 x n2), then a
 // per-row (max, second max, argmax).  Each wavefront keeps its 32 rows of D1 for the whole
-// K = 128 in VGPRs (64 registers) and sweeps 32-column tiles of D2 staged through
-// double-buffered LDS, one v_mfma_f32_32x32x2_f32 per k-pair with k ascending — so every
+// K = 128 in VGPRs (64 registers) and sweeps 64-column super-tiles of D2 staged through
+// double-buffered LDS as TWO interleaved accumulator chains, one v_mfma_f32_32x32x2_f32 per k-pair and chain with
+// k ascending — so every
 // score is bit-identical to the reference's sequential fp32 FMA chain (matching.cu:343-346;
 // MI355X f32 MFMA == k-ordered fmaf chain).  The running top-2 is kept per lane, i.e. per
 // column residue (p2 mod 32); residues 4c..4c+3 form the reference's "class" c = (p2 mod 32)/4

@@ -1,17 +1,20 @@
 // kernels_points.hip — per-keypoint kernels for gfx950 (one wavefront per keypoint).
 //
-//   orient_kernel   replaces ComputeOrientationsCONST       (reference cudaSiftD.cu:972-1057, host cudaSiftH.cu:353-369)
-//   descr_kernel    replaces ExtractSiftDescriptorsCONSTNew (reference cudaSiftD.cu:308-417 + FastAtan2 :295-306,
-//                                                            host cudaSiftH.cu:371-382)
-//   rescale_kernel  replaces RescalePositions               (reference cudaSiftD.cu:753-761)
+//   orient_kernel / orient_all_kernel  replace ComputeOrientationsCONST (reference cudaSiftD.cu:972-1057,
+//                                      host cudaSiftH.cu:353-369)
+//   descr_kernel / descr_all_kernel    replace ExtractSiftDescriptorsCONSTNew (reference cudaSiftD.cu:308-417 +
+//                                      FastAtan2 :295-306, host cudaSiftH.cu:371-382)
+//   rescale_kernel                     replaces RescalePositions (reference cudaSiftD.cu:753-761)
+//   (the ..._all kernels take every octave of every frame in one launch from the Detection staging area and
+//    lay the final SiftPoint array out in the reference's segment order)
 //
-// The reference uses 121- and 128-thread blocks (32-lane warps, texture unit
-// fetches).  Here a 64-lane wavefront owns a keypoint: 121 orientation samples
-// = 2 per lane, 256 descriptor samples = 4 per lane; bilinear "texture" fetches
-// are manual (tex2d in common.hpp, optional 8-bit weight quantisation like the
-// CUDA texture unit); histograms live in a wave-private LDS slice updated with
-// native ds_add_f32; the norms are 64-lane butterfly reductions.  Four
-// wavefronts share a workgroup only to fill the CU — they never synchronise.
+// The reference uses 121- and 128-thread blocks (32-lane warps, texture unit fetches, shared-memory float
+// atomics).  Here a 64-lane wavefront owns a keypoint: bilinear "texture" fetches are manual (tex2d in
+// common.hpp: one 8-byte load per texel pair, optional 8-bit weight quantisation like the CUDA texture unit,
+// clamp-free path for interior patches); orientation differences come out of ONE shared 13x13 grid of
+// fetches; both histograms are accumulated WITHOUT atomics from wave-private LDS tables (descriptor: per-bin
+// planes, 16 b128 loads + 64 literal-weight FMAs per lane); the norms are 64-lane butterfly reductions.
+// Four wavefronts share a workgroup only to fill the CU — they never synchronise.
 #include "common.hpp"
 
 #define WAVES_PER_BLOCK 4
