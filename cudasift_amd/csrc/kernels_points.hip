@@ -428,14 +428,43 @@ __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ ba
 // orientation(s) and hands out duplicate slots; descr_all_kernel lays the final SiftPoint array out in
 // the reference's segment order  [oct 1 detections | oct 1 duplicates | oct 2 detections | ...]
 // (cudaSiftD.cu:1297-1300, :1038-1044) and writes the reference's 17 counters.
-__device__ __forceinline__ bool flat_to_octave(const unsigned *cnt, int noct, int idx, int &o, int &i, int max_pts)
+
+// The per-octave detection counts of a frame are final when these kernels run: read them ONCE per wavefront
+// into (scalar) registers instead of chasing 5-10 dependent global loads per keypoint, and keep the keypoint
+// index wave-uniform (readfirstlane) so that the level lookup in the kernel arguments is a scalar load.
+struct FrameCounts {
+  int ndet[MISIFT_MAX_OCTAVES + 1];           // min(count, max_pts)
+  unsigned bdet[MISIFT_MAX_OCTAVES + 1];      // segment base of the octave's detections in the reference layout
+  unsigned bdup[MISIFT_MAX_OCTAVES + 1];      // ... and of its duplicates
+};
+__device__ __forceinline__ FrameCounts load_frame_counts(const unsigned *cnt, int noct, int max_pts, bool with_dups)
 {
-  for (int k = 1; k <= noct; k++) {
-    const int n = (int)min(cnt[CNT_DET + k], (unsigned)max_pts);
-    if (idx < n) { o = k; i = idx; return true; }
-    idx -= n;
+  FrameCounts c;
+  unsigned b = 0;
+#pragma unroll
+  for (int k = 1; k <= MISIFT_MAX_OCTAVES; k++) {
+    const unsigned nd = k <= noct ? __builtin_amdgcn_readfirstlane(cnt[CNT_DET + k]) : 0u;
+    const unsigned nu = (with_dups && k <= noct) ? __builtin_amdgcn_readfirstlane(cnt[CNT_DUP + k]) : 0u;
+    c.ndet[k] = (int)min(nd, (unsigned)max_pts);
+    c.bdet[k] = b;
+    c.bdup[k] = b + nd;
+    b += nd + nu;
   }
-  return false;
+  c.ndet[0] = 0; c.bdet[0] = 0; c.bdup[0] = 0;
+  return c;
+}
+__device__ __forceinline__ bool flat_to_octave(const FrameCounts &c, int noct, int idx, int &o, int &i)
+{
+  bool found = false;
+  o = 0; i = idx;
+#pragma unroll
+  for (int k = 1; k <= MISIFT_MAX_OCTAVES; k++) {
+    if (!found && k <= noct) {
+      if (i < c.ndet[k]) { o = k; found = true; }
+      else i -= c.ndet[k];
+    }
+  }
+  return found;
 }
 
 __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
@@ -452,9 +481,11 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
   Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
   const bool q8 = frac8 != 0;
   if (lane >= 57) s_smp[wave][64 + lane] = make_float2(-1.0f, 0.0f);
-  for (int idx = blockIdx.x * WAVES_PER_BLOCK + wave;; idx += gridDim.x * WAVES_PER_BLOCK) {
+  const FrameCounts fc = load_frame_counts(cnt, P.noct, max_pts, false);
+  for (int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave);;
+       idx += gridDim.x * WAVES_PER_BLOCK) {
     int o, i;
-    if (!flat_to_octave(cnt, P.noct, idx, o, i, max_pts)) break;
+    if (!flat_to_octave(fc, P.noct, idx, o, i)) break;
     const OctaveInfo &L = P.o[o];
     const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
     Detection *d = &fdet[(size_t)(o - 1) * max_pts + i];
@@ -497,17 +528,18 @@ __global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *
       cnt[2 * k + 1] = b;
     }
   }
-  for (int idx = blockIdx.x * WAVES_PER_BLOCK + wave;; idx += gridDim.x * WAVES_PER_BLOCK) {
+  const FrameCounts fc = load_frame_counts(cnt, P.noct, max_pts, true);
+  for (int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave);;
+       idx += gridDim.x * WAVES_PER_BLOCK) {
     int o, i;
-    if (!flat_to_octave(cnt, P.noct, idx, o, i, max_pts)) break;
+    if (!flat_to_octave(fc, P.noct, idx, o, i)) break;
     const OctaveInfo &L = P.o[o];
     const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
     const Detection d = fdet[(size_t)(o - 1) * max_pts + i];
     unsigned bdet = 0, bdup = 0;                          // segment bases of octave o
-    for (int k = 1; k <= o; k++) {
-      bdet = bdup + (k > 1 ? cnt[CNT_DUP + k - 1] : 0u);
-      bdup = bdet + cnt[CNT_DET + k];
-    }
+#pragma unroll
+    for (int k = 1; k <= MISIFT_MAX_OCTAVES; k++)
+      if (k == o) { bdet = fc.bdet[k]; bdup = fc.bdup[k]; }
 #pragma unroll 1
     for (int which = 0; which < 2; which++) {
       if (which == 1 && d.dupslot < 0) break;
