@@ -482,19 +482,28 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
   const bool q8 = frac8 != 0;
   if (lane >= 57) s_smp[wave][64 + lane] = make_float2(-1.0f, 0.0f);
   const FrameCounts fc = load_frame_counts(cnt, P.noct, max_pts, false);
-  for (int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave);;
-       idx += gridDim.x * WAVES_PER_BLOCK) {
-    int o, i;
-    if (!flat_to_octave(fc, P.noct, idx, o, i)) break;
+  const int stride = gridDim.x * WAVES_PER_BLOCK;
+  int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave);
+  int o, i;
+  bool more = flat_to_octave(fc, P.noct, idx, o, i);
+  // the next keypoint's record is fetched while the current one is processed (its ~1 us load latency was exposed
+  // at the top of every iteration)
+  float4 nxt = more ? *reinterpret_cast<const float4 *>(&fdet[(size_t)(o - 1) * max_pts + i]) : make_float4(0, 0, 0, 0);
+  while (more) {
+    const float4 cur = nxt;
     const OctaveInfo &L = P.o[o];
     const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
     Detection *d = &fdet[(size_t)(o - 1) * max_pts + i];
-    const OrientResult r = orient_core(img, L.w, L.h, L.p, q8, d->xpos, d->ypos, d->scale, s_hist[wave],
+    const int co = o;
+    idx += stride;
+    more = flat_to_octave(fc, P.noct, idx, o, i);
+    if (more) nxt = *reinterpret_cast<const float4 *>(&fdet[(size_t)(o - 1) * max_pts + i]);
+    const OrientResult r = orient_core(img, L.w, L.h, L.p, q8, cur.x, cur.y, cur.z, s_hist[wave],
                                        s_gauss[wave], s_smp[wave], s_tgrid[wave], lane);
     if (lane == 0) {
       d->ori1 = r.ori1;
       d->ori2 = r.ori2;
-      d->dupslot = r.has2 ? (int)atomicAdd(&cnt[CNT_DUP + o], 1u) : -1;
+      d->dupslot = r.has2 ? (int)atomicAdd(&cnt[CNT_DUP + co], 1u) : -1;
     }
   }
 }
@@ -540,10 +549,11 @@ __global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *
 #pragma unroll
     for (int k = 1; k <= MISIFT_MAX_OCTAVES; k++)
       if (k == o) { bdet = fc.bdet[k]; bdup = fc.bdup[k]; }
+    const unsigned ci = (unsigned)i;
 #pragma unroll 1
     for (int which = 0; which < 2; which++) {
       if (which == 1 && d.dupslot < 0) break;
-      const unsigned dst = which == 0 ? bdet + (unsigned)i : bdup + (unsigned)d.dupslot;
+      const unsigned dst = which == 0 ? bdet + ci : bdup + (unsigned)d.dupslot;
       if (dst >= (unsigned)max_pts) continue;             // capacity: dropped, still counted
       float o0, o1;
       descr_core(img, L.w, L.h, L.p, q8, d.xpos, d.ypos, d.scale, which == 0 ? d.ori1 : d.ori2, s_smp[wave],
