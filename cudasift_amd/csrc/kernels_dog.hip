@@ -811,18 +811,27 @@ __global__ __launch_bounds__(256) void refine_all_kernel(const float *__restrict
   const unsigned group = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + (unsigned)(lane >> 4);
   const unsigned ngroups = gridDim.x * 16u;
   // candidates of all octaves are flattened (finest first) so no group idles through octaves it has no work in
+  // the per-octave candidate counts are final (the scan is done): read them once, into scalar registers
+  unsigned ncand[MISIFT_MAX_OCTAVES + 1];
   unsigned total = 0;
-  for (int o = P.noct; o >= 1; o--) total += min(cnt[CNT_CAND + o], P.o[o].cand_cap);
+#pragma unroll
+  for (int k = 1; k <= MISIFT_MAX_OCTAVES; k++) {
+    ncand[k] = k <= P.noct ? __builtin_amdgcn_readfirstlane(min(cnt[CNT_CAND + k], P.o[k].cand_cap)) : 0u;
+    total += ncand[k];
+  }
   const unsigned rounds = (total + ngroups - 1) / ngroups;       // wave-uniform trip count (DPP needs all lanes)
   for (unsigned it = 0; it < rounds; it++) {
     const unsigned fi = it * ngroups + group;
     const bool live = fi < total;
     int o = P.noct;
     unsigned ci = live ? fi : 0u;
-    for (int k = P.noct; k >= 1; k--) {
-      const unsigned n = min(cnt[CNT_CAND + k], P.o[k].cand_cap);
-      if (ci < n) { o = k; break; }
-      ci -= n;
+    bool found = false;
+#pragma unroll
+    for (int k = MISIFT_MAX_OCTAVES; k >= 1; k--) {
+      if (!found && k <= P.noct) {
+        if (ci < ncand[k]) { o = k; found = true; }
+        else ci -= ncand[k];
+      }
     }
     const int lw = P.o[o].w, lh = P.o[o].h, lp = P.o[o].p;
     const float *img = scratch + (long long)frame * P.frame_stride + P.o[o].img_off;
