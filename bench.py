@@ -148,14 +148,22 @@ def main():
         ev.record()
         gather.post(slot, cnts[slot][:B], packed[slot], ev)
 
+    trace = [] if os.environ.get("BENCH_TRACE") else None
+
     def run(nsteps):
         res = None
         for k in range(nsteps):
             enqueue(k)
+            if trace is not None:
+                trace.append(("enq", k, time.perf_counter()))
             if k >= LAG:
                 res = gather.complete((k - LAG) % NSLOT)
+                if trace is not None:
+                    trace.append(("done", k - LAG, time.perf_counter()))
         for k in range(max(0, nsteps - LAG), nsteps):
             res = gather.complete(k % NSLOT)
+            if trace is not None:
+                trace.append(("done", k, time.perf_counter()))
         all_counts = res[0]
         if (all_counts < 0).any():
             raise RuntimeError("candidate list overflow in the bench workload")
@@ -173,6 +181,11 @@ def main():
     all_counts = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if trace is not None and rank == 0:
+        for kind, k, t in trace[-(3 * args.steps):]:
+            if t >= t0:
+                print("trace %-4s %3d %8.3f ms" % (kind, k, 1e3 * (t - t0)), file=sys.stderr)
+        print("trace end %8.3f ms" % (1e3 * dt), file=sys.stderr)
     n = all_counts[rank if world > 1 else 0]
     kp_per_frame = float(np.mean(n))
     if world > 1:
