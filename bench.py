@@ -142,7 +142,8 @@ def main():
             torch.cuda.current_stream().wait_event(fe)          # slot's previous transfer has left the buffers
         capi.check(capi.lib().misift_extract_batch_packed_async(
             ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(),
-            pts.data_ptr(), MAX_PTS, cnts[slot].data_ptr(), cnts[slot][B:].data_ptr(), packed[slot].data_ptr()),
+            pts.data_ptr() if args.unfused else None,      # merged-octave path writes the packed array directly
+            MAX_PTS, cnts[slot].data_ptr(), cnts[slot][B:].data_ptr(), packed[slot].data_ptr()),
             "misift_extract_batch_packed_async")
         ev = torch.cuda.Event()
         ev.record()

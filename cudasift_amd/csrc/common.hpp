@@ -251,6 +251,10 @@ struct misift_ctx {
   void *d_match_tmp;            // matcher partial results
   size_t match_tmp_bytes;
   int num_cus;
+  // packed-output mode (misift_extract_batch_packed_async): descr_all writes the valid records of all frames
+  // straight into one contiguous array; set only around that entry point's enqueue
+  int *pack_counts, *pack_offsets;
+  SiftPointD *pack_dst;
   int orient_blocks_per_cu;
   int point_blocks_per_cu;                     // grid sizing of the per-keypoint kernels
   int strip_waves_per_cu, scan_waves_per_cu;   // segment sizing targets of the streaming kernels
@@ -322,7 +326,11 @@ int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride
                  int nframes, float subsampling, int octave, SiftPointD *pts, int max_pts);
 int launch_rescale(misift_ctx *ctx, SiftPointD *pts, int npts, float scale);
 int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts);
-int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts);
+int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts,
+                     const int *pack_offsets, SiftPointD *pack_dst);
+// counts / offsets from the STAGED per-octave counters (valid once orient_all has run, before descr_all)
+int launch_export_counts_staged(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *counts_out,
+                                int *offsets_out);
 struct ScanAll;
 int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
                         float thresh);

@@ -514,7 +514,9 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
 __global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                         unsigned *__restrict__ counters,
                                                         const Detection *__restrict__ det,
-                                                        SiftPointD *__restrict__ pts, int max_pts, int frac8)
+                                                        SiftPointD *__restrict__ pts, int max_pts, int frac8,
+                                                        const int *__restrict__ pack_offsets,
+                                                        SiftPointD *__restrict__ pack_dst)
 {
   __shared__ __attribute__((aligned(16))) float s_smp[WAVES_PER_BLOCK][DESCR_TBL];
   __shared__ float s_gauss[WAVES_PER_BLOCK][16];
@@ -522,7 +524,10 @@ __global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *
   const int frame = blockIdx.y;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   const Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
-  SiftPointD *sift = pts + (size_t)frame * max_pts;
+  SiftPointD *sift = pts ? pts + (size_t)frame * max_pts : nullptr;
+  // packed output: this frame's first numPts records go to pack_dst[pack_offsets[frame] ...] (what a gather ships)
+  const int pack_off = pack_dst ? __builtin_amdgcn_readfirstlane(pack_offsets[frame]) : 0;
+  const unsigned pack_cnt = pack_dst ? (unsigned)(__builtin_amdgcn_readfirstlane(pack_offsets[frame + 1]) - pack_off) : 0u;
   const bool q8 = frac8 != 0;
   descr_init(s_smp[wave], s_gauss[wave], lane);
   const int cell = lane >> 2;
@@ -558,17 +563,26 @@ __global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *
       float o0, o1;
       descr_core(img, L.w, L.h, L.p, q8, d.xpos, d.ypos, d.scale, which == 0 ? d.ori1 : d.ori2, s_smp[wave],
                  s_gauss[wave], lane, o0, o1);
-      SiftPointD *p = &sift[dst];
-      p->data[8 * cell + (lane & 3)] = o0;
-      p->data[8 * cell + (lane & 3) + 4] = o1;
-      if (lane == 0) {
-        p->xpos = d.xpos * L.subsampling;
-        p->ypos = d.ypos * L.subsampling;
-        p->scale = d.scale * L.subsampling;
-        p->sharpness = d.sharpness;
-        p->edgeness = d.edgeness;
-        p->orientation = which == 0 ? d.ori1 : d.ori2;
-        p->subsampling = L.subsampling;
+#pragma unroll
+      for (int tgt = 0; tgt < 2; tgt++) {
+        SiftPointD *p = tgt == 0 ? (sift ? &sift[dst] : nullptr)
+                                 : (pack_dst && dst < pack_cnt ? pack_dst + pack_off + dst : nullptr);
+        if (!p) continue;
+        p->data[8 * cell + (lane & 3)] = o0;
+        p->data[8 * cell + (lane & 3) + 4] = o1;
+        if (lane == 0) {
+          p->xpos = d.xpos * L.subsampling;
+          p->ypos = d.ypos * L.subsampling;
+          p->scale = d.scale * L.subsampling;
+          p->sharpness = d.sharpness;
+          p->edgeness = d.edgeness;
+          p->orientation = which == 0 ? d.ori1 : d.ori2;
+          p->subsampling = L.subsampling;
+          if (tgt == 1) {                       // a packed record is complete: the match fields start out cleared
+            p->score = 0.0f; p->ambiguity = 0.0f; p->match = 0; p->match_xpos = 0.0f; p->match_ypos = 0.0f;
+            p->match_error = 0.0f; p->empty[0] = 0.0f; p->empty[1] = 0.0f; p->empty[2] = 0.0f;
+          }
+        }
       }
     }
   }
@@ -626,11 +640,13 @@ int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
   return ls.finish();
 }
 
-int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts)
+int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts,
+                     const int *pack_offsets, SiftPointD *pack_dst)
 {
   LaunchScope ls(ctx, "descr_all");
   hipLaunchKernelGGL(descr_all_kernel, dim3(points_grid_x(ctx, P.nframes), P.nframes), dim3(256), 0, ctx->stream,
-                     scratch, P, ctx->d_counters, ctx->d_det, pts, max_pts, ctx->opt.texfrac_bits == 8 ? 1 : 0);
+                     scratch, P, ctx->d_counters, ctx->d_det, pts, max_pts, ctx->opt.texfrac_bits == 8 ? 1 : 0,
+                     pack_offsets, pack_dst);
   return ls.finish();
 }
 

@@ -564,7 +564,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
                            int width, int height, int pitch, int num_octaves, float init_blur, float thresh,
                            float lowest_scale, int scale_up, float *d_scratch, SiftPointD *pts, int max_pts)
 {
-  ARG_CHECK(ctx && d_imgs && pts);
+  ARG_CHECK(ctx && d_imgs && (pts || (ctx->pack_dst && ctx->opt.fused)));
   ARG_CHECK(nframes >= 1 && width >= 16 && height >= 16 && pitch >= width);
   ARG_CHECK((width >> (num_octaves - 1)) >= 8 && (height >> (num_octaves - 1)) >= 8);
   ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);
@@ -680,7 +680,11 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     if (rc) return rc;
     rc = launch_orient_all(ctx, d_scratch, P, pts, max_pts);
     if (rc) return rc;
-    return launch_descr_all(ctx, d_scratch, P, pts, max_pts);
+    if (ctx->pack_dst) {                // counts and offsets are known as soon as the orientations are: pack while writing
+      rc = launch_export_counts_staged(ctx, nframes, num_octaves, max_pts, ctx->pack_counts, ctx->pack_offsets);
+      if (rc) return rc;
+    }
+    return launch_descr_all(ctx, d_scratch, P, pts, max_pts, ctx->pack_offsets, ctx->pack_dst);
   }
   // --- octaves, coarsest first (cudaSiftH.cu:161 after the recursion)
   for (int o = 1; o <= num_octaves; o++) {
@@ -880,7 +884,17 @@ extern "C" int misift_extract_batch_packed_async(misift_ctx *ctx, const float *d
                                                  float *d_scratch, void *d_pts, int max_pts, int *d_counts_out,
                                                  int *d_offsets_out, void *d_packed_out)
 {
-  ARG_CHECK(d_counts_out && d_offsets_out && d_packed_out);
+  ARG_CHECK(ctx && d_counts_out && d_offsets_out && d_packed_out);
+  if (ctx->opt.fused) {
+    // merged-octave path: descr_all writes the packed array itself (no separate packing pass); d_pts may be NULL
+    ctx->pack_counts = d_counts_out; ctx->pack_offsets = d_offsets_out; ctx->pack_dst = (SiftPointD *)d_packed_out;
+    const int rc = misift_extract_enqueue(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch,
+                                          num_octaves, init_blur, thresh, lowest_scale, 0, d_scratch,
+                                          (SiftPointD *)d_pts, max_pts);
+    ctx->pack_counts = nullptr; ctx->pack_offsets = nullptr; ctx->pack_dst = nullptr;
+    return rc;
+  }
+  ARG_CHECK(d_pts != nullptr);
   int rc = misift_extract_enqueue(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch,
                                   num_octaves, init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts,
                                   max_pts);

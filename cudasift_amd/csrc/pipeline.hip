@@ -21,9 +21,12 @@
 #include "common.hpp"
 
 // ------------------------------------------------------------------ counts / offsets / packing
+// staged_noct > 0: the reference counters are not published yet (descr_all does that) — derive numPts from the
+// staged per-octave detection / duplicate counts exactly as descr_all will (cudaSiftD.cu:1297-1300 protocol;
+// `slot` odd = fix_numpts, the finest octave's duplicates are counted too).
 __global__ __launch_bounds__(1024) void export_counts_kernel(const unsigned *__restrict__ counters, int nframes, int slot,
                                                               int max_pts, int *__restrict__ counts,
-                                                              int *__restrict__ offsets)
+                                                              int *__restrict__ offsets, int staged_noct)
 {
   __shared__ int wave_tot[16];
   __shared__ int carry_s;
@@ -35,7 +38,14 @@ __global__ __launch_bounds__(1024) void export_counts_kernel(const unsigned *__r
     int c = 0;
     if (f < nframes) {
       const unsigned *cnt = counters + (size_t)f * CNT_STRIDE;
-      const unsigned n = cnt[slot];
+      unsigned n = cnt[slot];
+      if (staged_noct > 0) {
+        n = 0;
+        for (int k = 1; k <= staged_noct; k++) {
+          n += cnt[CNT_DET + k];
+          if (k < staged_noct || (slot & 1)) n += cnt[CNT_DUP + k];
+        }
+      }
       c = (int)(n < (unsigned)max_pts ? n : (unsigned)max_pts);      // cudaSiftH.cu:116
       counts[f] = cnt[CNT_CANDOVF] ? -1 : c;
       if (cnt[CNT_CANDOVF]) c = 0;
@@ -80,7 +90,17 @@ int launch_export_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_
   const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
   LaunchScope ls(ctx, "export_counts");
   hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_counters, nframes, slot, max_pts,
-                     counts_out, offsets_out);
+                     counts_out, offsets_out, 0);
+  return ls.finish();
+}
+
+int launch_export_counts_staged(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *counts_out,
+                                int *offsets_out)
+{
+  const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
+  LaunchScope ls(ctx, "export_counts");
+  hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_counters, nframes, slot, max_pts,
+                     counts_out, offsets_out, num_octaves);
   return ls.finish();
 }
 

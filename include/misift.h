@@ -147,7 +147,9 @@ int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, int nframes
  * frames contiguously (frame after frame) into d_packed_out, ready for ONE
  * device-to-device / xGMI / PCIe transfer: d_counts_out[f] = numPts of frame f
  * (-1: that frame's candidate list overflowed), d_offsets_out[0..nframes] =
- * exclusive prefix sum of the non-negative counts (records).  Nothing
+ * exclusive prefix sum of the non-negative counts (records).  In the default
+ * (fused) mode the descriptor kernel writes the packed array itself — no extra
+ * packing pass — and d_pts may be NULL (if given it is filled as well).  Nothing
  * synchronises; this is what the multi-GPU gather of SiftData (BASELINE
  * config 4) and the host pipeline send. */
 int misift_extract_batch_packed_async(misift_ctx *ctx, const float *d_imgs, int nframes,

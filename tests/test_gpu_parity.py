@@ -539,6 +539,18 @@ def test_extract_batch_packed_async_equals_batch(ctx):
     recs = ctx.download(packed, (int(offs[B]),), capi.POINT_DTYPE)
     for f in range(B):
         assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(rp[f, :rn[f]])
+    unp = ctx.download(pts, (B, mp), capi.POINT_DTYPE)                      # d_pts was given: filled as well
+    for f in range(B):
+        assert _canon(unp[f, :rn[f]]) == _canon(rp[f, :rn[f]])
+    # packed-only (d_pts = NULL), into a dirty buffer: every byte of every record must be written
+    packed2 = ctx.upload(np.full(576 * mp * B, 0xA5, np.uint8))
+    capi.check(capi.lib().misift_extract_batch_packed_async(ctx.h, d.ptr, B, h * w, w, h, w, 5, 1.0, 2.0, 0.0, sc.ptr,
+                                                            None, mp, cnt.ptr, cnt.ptr + 4 * B, packed2.ptr),
+               "misift_extract_batch_packed_async")
+    ctx.sync()
+    recs2 = ctx.download(packed2, (int(offs[B]),), capi.POINT_DTYPE)
+    for f in range(B):
+        assert _canon(recs2[offs[f]:offs[f + 1]]) == _canon(rp[f, :rn[f]])
 
 
 def _noise_u8(h, w, seed):
