@@ -253,6 +253,10 @@ struct misift_ctx {
   int num_cus;
   // packed-output mode (misift_extract_batch_packed_async): descr_all writes the valid records of all frames
   // straight into one contiguous array; set only around that entry point's enqueue
+  // pyramid tail (coarse ScaleDowns + their scan) on a second, high-priority stream beside the scan of the fine levels
+  int split_tail, in_capture;
+  hipStream_t stream2;
+  hipEvent_t ev_fork, ev_join;
   int *pack_counts, *pack_offsets;
   SiftPointD *pack_dst;
   int orient_blocks_per_cu;
@@ -333,7 +337,7 @@ int launch_export_counts_staged(misift_ctx *ctx, int nframes, int num_octaves, i
                                 int *offsets_out);
 struct ScanAll;
 int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
-                        float thresh);
+                        float thresh, int lev_begin, int lev_end);
 int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
                       float thresh, float edge_limit, float factor, int max_pts);
 int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2);

@@ -972,22 +972,23 @@ static AllTaps pack_taps(const LaplaceTaps *taps, int noct)
   return a;
 }
 
+// lev_begin..lev_end: pyramid levels to scan, 0 = finest (all levels: 0, P.noct)
 int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
-                        float thresh)
+                        float thresh, int lev_begin, int lev_end)
 {
   ScanAllGeom G;
   memset(&G, 0, sizeof(G));
-  G.nlev = P.noct; G.nframes = P.nframes; G.frame_stride = P.frame_stride;
+  G.nlev = lev_end - lev_begin; G.nframes = P.nframes; G.frame_stride = P.frame_stride;
   bool fast = (is_aligned16(scratch, 4) && (P.frame_stride & 3) == 0);
   long long items = 0;
   unsigned cand_stride = 0;
   for (int o = 1; o <= P.noct; o++) cand_stride += P.o[o].cand_cap;
   G.cand_stride = cand_stride;
   // total wavefronts aimed at: ~16 per CU; every level gets segments sized for its share
-  for (int lev = 0; lev < P.noct; lev++) {
+  for (int lev = lev_begin; lev < lev_end; lev++) {
     const int o = P.noct - lev;                           // finest first
     const OctaveInfo &L = P.o[o];
-    ScanOct &S = G.o[lev];
+    ScanOct &S = G.o[lev - lev_begin];
     S.w = L.w; S.h = L.h; S.p = L.p; S.octave = o; S.img_off = L.img_off;
     S.cand_off = L.cand_off; S.cand_cap = L.cand_cap;
     const int nquads = (L.w + 3) / 4;
