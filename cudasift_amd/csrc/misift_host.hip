@@ -191,7 +191,8 @@ extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
   // work decomposition of the streaming kernels: wavefronts aimed at per CU and launch (developer knobs)
   ctx->strip_waves_per_cu = 32;   // measured: lowpass_down 0.247 -> 0.220 ms vs 16 (better balance over the CUs, 64-row segments)
   ctx->scan_waves_per_cu = 32;
-  ctx->split_tail = 1;            // measured +2.8 % frames/s (MISIFT_SPLIT_TAIL=0 disables)
+  ctx->split_tail = 8;            // batches of >= 8 frames: measured +2.8 % frames/s (MISIFT_SPLIT_TAIL=0 disables,
+                                  // =N sets the smallest batch; a single frame is launch-latency bound and loses)
   if (const char *e = getenv("MISIFT_SPLIT_TAIL")) ctx->split_tail = atoi(e);
   {
     int lo = 0, hi = 0;
@@ -683,8 +684,8 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   // scan of those levels run beside it on a second, high-priority stream — their launch gaps and tails hide
   // under the big kernel.
   bool scanned = false;
-  if (ctx->opt.fused && ctx->split_tail && !ctx->in_capture && first_down_done && num_octaves >= 3 && !ctx->profile &&
-      ctx->stream2) {
+  if (ctx->opt.fused && ctx->split_tail && nframes >= ctx->split_tail && !ctx->in_capture && first_down_done &&
+      num_octaves >= 3 && !ctx->profile && ctx->stream2) {
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     rc = launch_dog_scan_all(ctx, d_scratch, P, tapsv.data(), thresh, 0, 2);
