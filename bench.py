@@ -465,7 +465,10 @@ def main():
                           "frames_per_gpu": B, "path": "unfused" if args.unfused else "fused dog+detect",
                           "keypoints_per_frame": round(kp_per_frame, 1)},
                "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu, "pcie_inclusive": pcie, "single_frame": latency,
-               "sync_step_ms": dist_ms}
+               "sync_step_ms": dist_ms,
+               "kernels_note": "dog_scan runs as two launches per step (fine levels on the context stream, the coarse "
+                               "ScaleDowns + coarse levels beside it on a second stream): their durations overlap, so "
+                               "the per-kernel times add up to more than the step"}
         print(json.dumps(out))
     if world > 1 or args.selftest_dist:
         dist.destroy_process_group()

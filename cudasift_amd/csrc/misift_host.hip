@@ -685,7 +685,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   // under the big kernel.
   bool scanned = false;
   if (ctx->opt.fused && ctx->split_tail && nframes >= ctx->split_tail && !ctx->in_capture && first_down_done &&
-      num_octaves >= 3 && !ctx->profile && ctx->stream2) {
+      num_octaves >= 3 && ctx->stream2) {
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     rc = launch_dog_scan_all(ctx, d_scratch, P, tapsv.data(), thresh, 0, 2);
