@@ -105,6 +105,8 @@ def _pipe_worker(rank, world, port, out_dir):
     def batch(r, k):
         rng = np.random.default_rng(1000 * r + k)
         c = rng.integers(0, cap + 1, size=B).astype(np.int32)
+        if r == 2 and k % 2 == 1:
+            c[:] = 0                                       # a rank with nothing to send this step (no message at all)
         if k == 2:
             c[r] = -1                                      # an overflowed frame: counted as 0 records
         n = int(np.clip(c, 0, None).sum())
@@ -143,3 +145,10 @@ def test_pipelined_record_gather_world2(tmp_path):
     port = _free_port()
     mp.spawn(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "pok0").read() == "1" and open(tmp_path / "pok1").read() == "1"
+
+
+def test_pipelined_record_gather_world3_with_silent_rank(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_pipe_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all(open(tmp_path / ("pok%d" % r)).read() == "1" for r in range(3))
