@@ -450,7 +450,7 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
     float amax = 0.0f;
 #pragma unroll
     for (int p = 0; p < NUM_SCALES; p++)
-      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(d[p].x), fabsf(d[p].y)), fmaxf(fabsf(d[p].z), fabsf(d[p].w))));
+      amax = max3f(max3f(amax, fabsf(d[p].x), fabsf(d[p].y)), fabsf(d[p].z), fabsf(d[p].w));   // two v_max3_f32 per plane
     // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
     // (tester lanes only: the halo lanes' blurs see zeros beyond the wavefront and would trip the test in every row —
     //  with them masked, 99 % of the finest level's rows of a typical frame skip the extremum tests)
