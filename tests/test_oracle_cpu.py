@@ -374,3 +374,56 @@ def test_descriptor_against_independent_numpy(stereo):
         worst = max(worst, float(np.abs(ref - got).max()))
         mincos = min(mincos, float((ref * got).sum()))
     assert worst < 1e-4 and mincos > 0.999999, (worst, mincos)        # measured: 3.5e-5, 0.9999998
+
+
+def _np_orientation(img, xpos, ypos, scale):
+    """Independent float64 restatement of ComputeOrientations (cudaSiftD.cu:984-1037): 11x11 central-difference
+    gradients of exact bilinear fetches, Gaussian weights, 32-bin histogram (np.bincount), [1 4 6 4 1] circular
+    smoothing (np.roll), non-maximum suppression, parabolic refinement of the largest peak.  Returns degrees."""
+    h, w = img.shape
+    im = img.astype(np.float64)
+
+    def tex(x, y):
+        xb, yb = x - 0.5, y - 0.5
+        fx, fy = np.floor(xb), np.floor(yb)
+        a, b = xb - fx, yb - fy
+        x0 = np.clip(fx, 0, w - 1).astype(int); x1 = np.clip(fx + 1, 0, w - 1).astype(int)
+        y0 = np.clip(fy, 0, h - 1).astype(int); y1 = np.clip(fy + 1, 0, h - 1).astype(int)
+        return (1 - a) * (1 - b) * im[y0, x0] + a * (1 - b) * im[y0, x1] + (1 - a) * b * im[y1, x0] + a * b * im[y1, x1]
+
+    yd, xd = np.meshgrid(np.arange(11), np.arange(11), indexing="ij")
+    xf, yf = xpos - 4.5 + xd, ypos - 4.5 + yd
+    dx = tex(xf + 1.0, yf) - tex(xf - 1.0, yf)
+    dy = tex(xf, yf + 1.0) - tex(xf, yf - 1.0)
+    g = np.exp(-(np.arange(11) - 5.0) ** 2 / (2.0 * 1.5 * 1.5 * scale * scale))
+    bins = np.floor(16.0 * np.arctan2(dy, dx) / 3.1416 + 16.5).astype(int)
+    bins[bins > 31] = 0
+    hist = np.bincount(bins.ravel(), weights=(np.sqrt(dx * dx + dy * dy) * g[xd] * g[yd]).ravel(), minlength=32)
+    sm = 6.0 * hist + 4.0 * (np.roll(hist, 1) + np.roll(hist, -1)) + (np.roll(hist, 2) + np.roll(hist, -2))
+    peaks = np.where((sm > np.roll(sm, 1)) & (sm >= np.roll(sm, -1)), sm, 0.0)
+    i1 = int(np.argmax(peaks))
+    v1, v2 = sm[(i1 + 1) % 32], sm[(i1 - 1) % 32]
+    peak = i1 + 0.5 * (v1 - v2) / (2.0 * peaks[i1] - v1 - v2)
+    second = np.sort(peaks)[-2]
+    return 11.25 * (peak + 32.0 if peak < 0 else peak), second / peaks[i1]
+
+
+def test_orientation_against_independent_numpy(stereo):
+    """The oracle's orientations (exact bilinear weights) against the float64 numpy restatement above; keypoints
+    whose two largest histogram peaks are within 2 % of each other are skipped (which one wins is then a matter of
+    the last float32 bit).  Circular difference below 0.001 degrees."""
+    img = stereo[0][:480, :640]
+    base = orc.lowpass(img, 1.0)
+    det, nd = orc.findpoints(orc.laplace(base, 1, 1), 3.5)
+    pts = det.copy()
+    total = orc.orientations(base, pts, 0, nd, len(pts), fracbits=23)
+    assert nd > 40 and total >= nd
+    worst, used = 0.0, 0
+    for k in range(nd):
+        ref, ratio = _np_orientation(base, float(pts[k]["xpos"]), float(pts[k]["ypos"]), float(pts[k]["scale"]))
+        if ratio > 0.98:
+            continue
+        d = abs(ref - float(pts[k]["orientation"])) % 360.0
+        worst = max(worst, min(d, 360.0 - d))
+        used += 1
+    assert used > 30 and worst < 1e-3, (used, worst)                      # measured: 71 keypoints, 2e-5 degrees
