@@ -20,8 +20,10 @@
  * PARITY PINNING.  The reference ships no golden vectors, known-answer tests or
  * fixtures for extraction and cannot be built here (CUDA), so
  * the EXTRACTION part of this oracle is "parity unpinned": it is checked only
- * against closed forms, the tap table of SURVEY Appendix C and cross
- * implementations (tests/test_oracle_*.py).  The MATCHER part is pinned against
+ * against closed forms, the tap table of SURVEY Appendix C and independent cross
+ * implementations of every stage (tests/test_oracle_cpu.py: scipy separable filters,
+ * scipy rank filters + numpy.linalg for detection/refinement, float64 numpy for
+ * orientation and descriptor).  The MATCHER part is pinned against
  * the reference's own CPU routines MatchC1/MatchC3 (match.cu:57-130), compiled
  * from the reference tree into oracle/_ref/ by oracle/build_ref.sh.
  *
