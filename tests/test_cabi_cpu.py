@@ -108,3 +108,14 @@ def test_reference_main_compiles_unchanged(tmp_path):
                            "-L", os.path.join(ROOT, "cudasift_amd"), "-lcudasift", "-lmisift",
                            "-Wl,-rpath," + os.path.join(ROOT, "cudasift_amd")])
     assert os.path.exists(exe)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/misift.h is the FFI surface: it must compile as strict C99 (no C++ constructs, no HIP types)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "misift.h"\nint main(void) { misift_options o; (void)o; return 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
