@@ -20,10 +20,10 @@ def load(d):
 ft, fn = load(fetch_dir); wt, wn = load(write_dir)
 res = {"frames_per_launch": frames, "bytes_per_frame": {}, "detail": {}}
 # launches per step differ per kernel (scaledown: 4); normalise by steps = launches of lowpass
-steps = max(1, fn.get("dog_scan", fn.get("lowpass", 1)))     # one dog_scan launch per step
+steps = max(1, fn.get("lowpass_down", fn.get("lowpass", fn.get("dog_scan", 1))))     # one prefilter launch per step
 for k in sorted(set(ft) | set(wt)):
     rd = 2.0 * ft.get(k, 0.0) * 1024.0 / steps / frames
-    wr = wt.get(k, 0.0) * 1024.0 / max(1, wn.get("dog_scan", steps)) / frames
+    wr = wt.get(k, 0.0) * 1024.0 / max(1, wn.get("lowpass_down", wn.get("lowpass", steps))) / frames
     res["bytes_per_frame"][k] = rd + wr
     res["detail"][k] = {"read_bytes_per_frame": rd, "write_bytes_per_frame": wr, "launches": fn.get(k, 0)}
 res["note"] = "read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024; separate --pmc passes of the same command"
