@@ -3,6 +3,6 @@
 The product is the C-ABI library `libmisift.so` (hand-written gfx950 HIP kernels,
 include/misift.h) plus the C++ drop-in shim `libcudasift.so` (include/cudaSift.h,
 include/cudaImage.h).  This Python package is only the ctypes binding used by the
-tests and bench.py: `capi` (raw C-ABI) and `api` (mirror of the reference's interface).
+tests and bench.py: `capi` (raw C-ABI over ctypes) and `dist` (torch.distributed plumbing for bench.py).
 """
 from . import capi  # noqa: F401

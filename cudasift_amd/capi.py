@@ -37,6 +37,7 @@ _ip, _fp, _up = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint)
 SIGNATURES = {
     "misift_device_count": (_i, []),
     "misift_device_info": (_i, [_i, C.c_char_p, _i, _ip, _ip, C.POINTER(_sz), _ip, _ip]),
+    "misift_device_arch": (_i, [_i, C.c_char_p, _i]),
     "misift_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "misift_ctx_destroy": (None, [_vp]),
     "misift_ctx_set_stream": (_i, [_vp, _vp]),

@@ -45,7 +45,15 @@ struct CallKey {
   int src_u8, nframes, width, height, pitch, num_octaves, scale_up, max_pts, fused, texfrac, fixnum, alloc_gen;
   long long frame_stride;
   float init_blur, thresh, lowest_scale;
-  bool operator==(const CallKey &o) const { return memcmp(this, &o, sizeof(CallKey)) == 0; }
+  // field by field: the struct has padding, and plain assignment need not preserve padding bytes
+  bool operator==(const CallKey &o) const
+  {
+    return imgs == o.imgs && scratch == o.scratch && pts == o.pts && src_u8 == o.src_u8 && nframes == o.nframes &&
+           width == o.width && height == o.height && pitch == o.pitch && num_octaves == o.num_octaves &&
+           scale_up == o.scale_up && max_pts == o.max_pts && fused == o.fused && texfrac == o.texfrac &&
+           fixnum == o.fixnum && alloc_gen == o.alloc_gen && frame_stride == o.frame_stride &&
+           init_blur == o.init_blur && thresh == o.thresh && lowest_scale == o.lowest_scale;
+  }
 };
 struct CtxExtra {
   std::vector<PendingProf> pending;
@@ -139,14 +147,24 @@ extern "C" int misift_device_info(int device, char *name, int name_len, int *mem
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   if (name && name_len > 0) {
-    strncpy(name, prop.name, name_len - 1);
-    name[name_len - 1] = 0;
+    // ROCm 7.2 leaves prop.name empty for some Instinct parts: fall back to the ISA name
+    if (prop.name[0]) snprintf(name, name_len, "%s", prop.name);
+    else snprintf(name, name_len, "AMD Instinct (%s)", prop.gcnArchName);
   }
   if (mem_clock_khz) *mem_clock_khz = prop.memoryClockRate;
   if (bus_width_bits) *bus_width_bits = prop.memoryBusWidth;
   if (total_mem_bytes) *total_mem_bytes = prop.totalGlobalMem;
   if (num_cus) *num_cus = prop.multiProcessorCount;
   if (lds_bytes_per_block) *lds_bytes_per_block = (int)prop.sharedMemPerBlock;
+  return MISIFT_OK;
+}
+
+extern "C" int misift_device_arch(int device, char *arch, int arch_len)
+{
+  ARG_CHECK(arch && arch_len > 0);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  snprintf(arch, arch_len, "%s", prop.gcnArchName);
   return MISIFT_OK;
 }
 
@@ -168,19 +186,11 @@ extern "C" void misift_default_options(misift_options *opt)
   if ((e = getenv("MISIFT_FUSED"))) opt->fused = atoi(e);
 }
 
-extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
+extern "C" void misift_ctx_destroy(misift_ctx *ctx);
+// Everything misift_ctx_create sets up after `new CtxFull()`; on any failure the caller destroys the
+// half-built context (misift_ctx_destroy tolerates null members), so nothing leaks.
+static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
 {
-  ARG_CHECK(out != nullptr);
-  int n = misift_device_count();
-  if (n <= 0) {
-    misift_set_error("no HIP device visible");
-    return MISIFT_ENODEV;
-  }
-  if (device < 0 || device >= n) device = n - 1;      // like InitCuda: clamp (cudaSiftH.cu:27)
-  HIP_TRY(hipSetDevice(device));
-  CtxFull *f = new CtxFull();
-  misift_ctx *ctx = &f->c;
-  memset(ctx, 0, sizeof(*ctx));
   ctx->device = device;
   ctx->stream = (hipStream_t)stream;
   misift_default_options(&ctx->opt);
@@ -211,8 +221,28 @@ extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
   HIP_TRY(hipEventCreate(&ctx->ev1));
   int rc = misift_ensure_frames(ctx, 1, 65536);
   if (rc) return rc;
-  rc = launch_selftest(ctx);
-  if (rc) return rc;
+  return launch_selftest(ctx);
+}
+
+extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
+{
+  ARG_CHECK(out != nullptr);
+  *out = nullptr;
+  int n = misift_device_count();
+  if (n <= 0) {
+    misift_set_error("no HIP device visible");
+    return MISIFT_ENODEV;
+  }
+  if (device < 0 || device >= n) device = n - 1;      // like InitCuda: clamp (cudaSiftH.cu:27)
+  HIP_TRY(hipSetDevice(device));
+  CtxFull *f = new CtxFull();
+  misift_ctx *ctx = &f->c;
+  memset(ctx, 0, sizeof(*ctx));
+  const int rc = ctx_init(ctx, f, device, stream);
+  if (rc) {
+    misift_ctx_destroy(ctx);                            // keeps the error message of the failing step
+    return rc;
+  }
   *out = ctx;
   return MISIFT_OK;
 }
@@ -235,8 +265,8 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   if (ctx->d_det) hipFree(ctx->d_det);
   if (ctx->d_own_scratch) hipFree(ctx->d_own_scratch);
   if (ctx->d_match_tmp) hipFree(ctx->d_match_tmp);
-  hipEventDestroy(ctx->ev0);
-  hipEventDestroy(ctx->ev1);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
@@ -579,8 +609,8 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
 {
   ARG_CHECK(ctx && d_imgs && (pts || (ctx->pack_dst && ctx->opt.fused)));
   ARG_CHECK(nframes >= 1 && width >= 16 && height >= 16 && pitch >= width);
+  ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);       // before the shifts below
   ARG_CHECK((width >> (num_octaves - 1)) >= 8 && (height >> (num_octaves - 1)) >= 8);
-  ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);
   ARG_CHECK(max_pts >= 1);
   ARG_CHECK(width * (scale_up ? 2 : 1) < 16384 && height * (scale_up ? 2 : 1) < 16384);
   ARG_CHECK(!scale_up || nframes == 1);
@@ -837,6 +867,7 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
                         int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
                         int scale_up, float *d_scratch, SiftPointD *pts, int max_pts, int *num_pts_out)
 {
+  ARG_CHECK(ctx != nullptr && num_pts_out != nullptr);
   const int fused_saved = ctx->opt.fused;
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = MISIFT_OK;

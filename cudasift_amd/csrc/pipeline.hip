@@ -181,6 +181,11 @@ extern "C" int misift_pipe_create(misift_ctx *ctx, int width, int height, int ba
     misift_set_error("misift_pipe_create: invalid argument");
     return MISIFT_EINVAL;
   }
+  // same size rule as misift_extract: the coarsest level must keep >= 8 pixels per side (fail here, not at the first submit)
+  if ((width >> (num_octaves - 1)) < 8 || (height >> (num_octaves - 1)) < 8 || width >= 16384 || height >= 16384) {
+    misift_set_error("misift_pipe_create: %dx%d is too small (or too large) for %d octaves", width, height, num_octaves);
+    return MISIFT_EINVAL;
+  }
   *out = nullptr;
   misift_pipe *p = new misift_pipe();
   p->ctx = ctx;
@@ -290,9 +295,14 @@ extern "C" int misift_pipe_collect(misift_pipe *p, int *nframes_out, int *counts
     hipStream_t saved = ctx->stream;
     ctx->stream = p->s_compute;
     std::vector<int> tmp((size_t)n);
+    // the fused scan is known to overflow on this batch: start at the dense kernels (no wasted fused attempt, and
+    // no graph capture/replay of a call that cannot succeed — the graph path only takes fused calls)
+    const int fused_saved = ctx->opt.fused;
+    ctx->opt.fused = 0;
     rc = misift_extract_sync(ctx, s.d_frames, p->src_u8, n, (long long)p->frame_elems, p->width, p->height, p->width,
                              p->num_octaves, p->init_blur, p->thresh, p->lowest_scale, 0, p->d_scratch, p->d_pts,
                              p->max_pts, tmp.data());
+    ctx->opt.fused = fused_saved;
     if (!rc) rc = launch_export_counts(ctx, n, p->num_octaves, p->max_pts, s.d_counts, s.d_counts + p->batch);
     if (!rc) rc = launch_pack_records(ctx, p->d_pts, p->max_pts, n, s.d_counts + p->batch, s.d_packed);
     ctx->stream = saved;

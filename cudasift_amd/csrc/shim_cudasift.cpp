@@ -171,7 +171,12 @@ void InitCuda(int devNum)
   printf("  Device name: %s\n", name);
   printf("  Memory Clock Rate (MHz): %d\n", memClockKHz / 1000);
   printf("  Memory Bus Width (bits): %d\n", busWidth);
-  printf("  Peak Memory Bandwidth (GB/s): %.1f\n\n", 2.0 * memClockKHz * (busWidth / 8) / 1.0e6);
+  // the reference assumes double data rate (cudaSiftH.cu:35-36); HBM3E on gfx950 moves 4 bits per pin and reported
+  // memory clock (8 Gb/s at 2 GHz, 8192-bit bus = 8.2 TB/s)
+  char arch[64] = "";
+  SAFE(misift_device_arch(devNum, arch, sizeof(arch)));
+  const double rate = strncmp(arch, "gfx950", 6) == 0 ? 4.0 : 2.0;
+  printf("  Peak Memory Bandwidth (GB/s): %.1f\n\n", rate * memClockKHz * (busWidth / 8) / 1.0e6);
 }
 
 float *AllocSiftTempMemory(int width, int height, int numOctaves, bool scaleUp)

@@ -66,6 +66,8 @@ int misift_device_count(void);
 int misift_device_info(int device, char *name, int name_len, int *mem_clock_khz,
                        int *bus_width_bits, size_t *total_mem_bytes,
                        int *num_cus, int *lds_bytes_per_block);
+/* ISA name of the device ("gfx950:sramecc+:xnack-"); the shim uses it to print the right HBM data rate. */
+int misift_device_arch(int device, char *arch, int arch_len);
 
 /* hipGraph replay of repeated synchronous calls: when misift_extract / misift_extract_batch is called again
  * with exactly the same arguments and buffers (the reference demo does, mainSift.cpp:64-69), the launch
