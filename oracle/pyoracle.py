@@ -66,6 +66,10 @@ def lib():
         L.orc_extract.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                   C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint)]
         L.orc_extract.restype = C.c_int
+        L.orc_extract_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp,
+                                        C.c_int, C.c_int, vp, C.c_int, C.c_int]
+        L.orc_set_contract.argtypes = [C.c_int]
+        L.orc_get_contract.restype = C.c_int
         L.orc_dot128.argtypes = [vp, vp]
         L.orc_dot128.restype = C.c_float
         L.orc_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
@@ -183,6 +187,37 @@ def extract(img, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, sca
     n = lib().orc_extract(_p(img), w, h, w, num_octaves, init_blur, thresh, lowest_scale, int(scale_up),
                           _p(pts), max_pts, fracbits, int(fix_numpts), cnt)
     return pts, n, np.array(list(cnt), dtype=np.uint32)
+
+
+def extract_batch(imgs, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, max_pts=32768, fracbits=8,
+                  outer_threads=None, inner_threads=1):
+    """orc_extract_batch: frames [B,h,w] processed one per OpenMP thread.  Returns (points[B,max_pts], numPts[B])."""
+    imgs = _f32(imgs)
+    B, h, w = imgs.shape
+    pts = np.zeros((B, max_pts), POINT_DTYPE)
+    n = np.zeros(B, np.int32)
+    if outer_threads is None:
+        outer_threads = min(B, os.cpu_count() or 1)
+    lib().orc_extract_batch(_p(imgs), B, w, h, num_octaves, init_blur, thresh, lowest_scale, _p(pts), max_pts,
+                            fracbits, _p(n), outer_threads, inner_threads)
+    return pts, n
+
+
+class contract:
+    """Context manager: run the oracle in another contraction mode (0 = plain = what the HIP kernels implement,
+    1 = nvcc-style fused multiply-adds outside the separable filters; see sift_oracle.c header)."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.saved = lib().orc_get_contract()
+        lib().orc_set_contract(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_contract(self.saved)
+        return False
 
 
 def match(pts1, n1, pts2, n2, full=False, exact=False):

@@ -32,7 +32,19 @@
  * -ffp-contract=off; the separable filters use the explicit fmaf chains written
  * below (centre tap first, then outward — the order of the reference
  * expressions with nvcc's default multiply-add contraction); everything else is
- * plain, uncontracted arithmetic.  libm calls (expf, atan2f, sinf, cosf, sqrtf,
+ * plain, uncontracted arithmetic — contract mode ORC_CONTRACT_PLAIN, the one the
+ * HIP kernels implement and all parity tests use.
+ *
+ * ERROR BAR ON THAT CHOICE.  nvcc (-fmad=true by default) would also contract the
+ * multiply-adds of the refinement, orientation and descriptor code.  Which ones
+ * exactly is a compiler decision nobody can observe here, so a second mode,
+ * ORC_CONTRACT_NVCC (orc_set_contract(1)), applies the LLVM/NVPTX DAG-combiner
+ * rules to the reference expressions as written: fadd(fmul(a,b),c) -> fma(a,b,c)
+ * taking the LEFT multiply first, fsub(fmul(a,b),c) -> fma(a,b,-c),
+ * fsub(c,fmul(a,b)) -> fma(-a,b,c), multiplies reached through a phi are not
+ * fused.  tests/test_oracle_cpu.py::test_contraction_sensitivity runs both modes
+ * and bounds what the choice can change (profiles/r02_contraction_sensitivity.json,
+ * DESIGN.md section 2).  libm calls (expf, atan2f, sinf, cosf, sqrtf,
  * powf, exp2f) differ from the device versions in the last bits; tests use the
  * tolerances of SURVEY §7.5 for anything downstream of them.
  *
@@ -67,6 +79,20 @@ typedef struct {
 } orc_stats_t;
 
 static orc_stats_t g_stats;
+
+/* contraction model for everything outside the separable filters (see header) */
+#define ORC_CONTRACT_PLAIN 0
+#define ORC_CONTRACT_NVCC  1
+static int g_contract = ORC_CONTRACT_PLAIN;
+void orc_set_contract(int mode) { g_contract = mode ? ORC_CONTRACT_NVCC : ORC_CONTRACT_PLAIN; }
+int orc_get_contract(void) { return g_contract; }
+/* a*b + c, a*b - c*d, a*b + c*d + e*f as nvcc-style contraction would evaluate them */
+static inline float mad(float a, float b, float c) { return g_contract ? fmaf(a, b, c) : a * b + c; }
+static inline float mmsub(float a, float b, float c, float d) { return g_contract ? fmaf(a, b, -(c * d)) : a * b - c * d; }
+static inline float dot3(float a, float b, float c, float d, float e, float f)
+{
+  return g_contract ? fmaf(e, f, fmaf(a, b, c * d)) : a * b + c * d + e * f;
+}
 void orc_stats_reset(void) { memset(&g_stats, 0, sizeof(g_stats)); }
 void orc_stats_get(orc_stats_t *out) { *out = g_stats; }
 int orc_sizeof_point(void) { return (int)sizeof(SiftPoint); }
@@ -258,18 +284,28 @@ void orc_laplace(const float *base, int w, int h, int pitch, const float *taps, 
 /* FindPointsMultiNew, cudaSiftD.cu:1292-1431.  Appends records starting at
  * index *count (counter protocol handled by the caller); returns the number of
  * detections (before the capacity clamp).  Scan order: scale, row, column. */
+typedef struct { float xpos, ypos, scale, sharpness, edgeness; } orc_det_t;
+typedef struct { orc_det_t *d; int n, cap; } orc_detlist_t;
+
 int orc_findpoints(const float *dog, int w, int h, int pitch, float thresh, float edgeLimit,
                    float factor, float lowestScale, float subsampling, SiftPoint *pts,
                    int start, int maxPts)
 {
   const size_t size = (size_t)pitch * h;
-  int n = 0;
   /* overflow statistics for the reference's 30x8 tiles (Appendix B #4) */
   int tilesx = (w + 29) / 30, tilesy = (h + 7) / 8;
   int *tilecnt = (int *)calloc((size_t)tilesx * tilesy * NUM_SCALES, sizeof(int));
-  for (int s = 0; s < NUM_SCALES; s++) {
+  /* Rows are scanned in parallel (8-row blocks = one tile row, so tile counters are private to a block);
+   * every block keeps its detections in scan order and the blocks are concatenated in (scale, row) order
+   * afterwards, so the output order is the serial one: scale, row, column. */
+  const int nblk = tilesy;
+  orc_detlist_t *lists = (orc_detlist_t *)calloc((size_t)nblk * NUM_SCALES, sizeof(orc_detlist_t));
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int job = 0; job < nblk * NUM_SCALES; job++) {
+    const int s = job / nblk, yb = job % nblk;
+    orc_detlist_t *L = &lists[job];
     const float *d0 = dog + size * s, *d1 = dog + size * (s + 1), *d2 = dog + size * (s + 2);
-    for (int y = 0; y < h; y++) {
+    for (int y = 8 * yb; y < 8 * yb + 8 && y < h; y++) {
       int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
       for (int x = 0; x < w; x++) {
         float v = d1[(size_t)y * pitch + x];
@@ -295,7 +331,7 @@ int orc_findpoints(const float *dog, int w, int h, int pitch, float thresh, floa
         float dyy = 2.0f * val - data1[-pitch] - data1[pitch];
         float dxy = 0.25f * (data1[+pitch + 1] + data1[-pitch - 1] - data1[-pitch + 1] - data1[+pitch - 1]);
         float tra = dxx + dyy;
-        float det = dxx * dyy - dxy * dxy;
+        float det = mmsub(dxx, dyy, dxy, dxy);
         if (!(tra * tra < edgeLimit * det)) continue;
         float edge = (tra * tra) / det;
         float dx = 0.5f * (data1[1] - data1[-1]);
@@ -306,39 +342,65 @@ int orc_findpoints(const float *dog, int w, int h, int pitch, float thresh, floa
         float dss = 2.0f * val - data2[0] - data0[0];
         float dxs = 0.25f * (data2[1] + data0[-1] - data0[1] - data2[-1]);
         float dys = 0.25f * (data2[pitch] + data0[-pitch] - data2[-pitch] - data0[pitch]);
-        float idxx = dyy * dss - dys * dys;
-        float idxy = dys * dxs - dxy * dss;
-        float idxs = dxy * dys - dyy * dxs;
-        float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
-        float idyy = dxx * dss - dxs * dxs;
-        float idys = dxy * dxs - dxx * dys;
-        float idss = dxx * dyy - dxy * dxy;
-        float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
-        float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
-        float pds = idet * (idxs * dx + idys * dy + idss * ds);
+        float idxx = mmsub(dyy, dss, dys, dys);
+        float idxy = mmsub(dys, dxs, dxy, dss);
+        float idxs = mmsub(dxy, dys, dyy, dxs);
+        float idet = 1.0f / dot3(idxx, dxx, idxy, dxy, idxs, dxs);
+        float idyy = mmsub(dxx, dss, dxs, dxs);
+        float idys = mmsub(dxy, dxs, dxx, dys);
+        float idss = mmsub(dxx, dyy, dxy, dxy);
+        float pdx = idet * dot3(idxx, dx, idxy, dy, idxs, ds);
+        float pdy = idet * dot3(idxy, dx, idyy, dy, idys, ds);
+        float pds = idet * dot3(idxs, dx, idys, dy, idss, ds);
         if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
           pdx = dx / dxx;
           pdy = dy / dyy;
           pds = ds / dss;
         }
-        float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
+        float dsum = dot3(dx, pdx, dy, pdy, ds, pds);
+        float dval = 0.5f * dsum;
         float sc = powf(2.0f, (float)s / NUM_SCALES) * exp2f(pds * factor);
         if (!(sc >= lowestScale)) continue;
-        int idx = start + n;
-        n++;
-        if (idx >= maxPts) { g_stats.capacity_drops++; continue; }
-        SiftPoint *p = &pts[idx];
-        p->xpos = x + pdx;
-        p->ypos = y + pdy;
-        p->scale = sc;
-        p->sharpness = val + dval;
-        p->edgeness = edge;
-        p->subsampling = subsampling;
+        if (L->n == L->cap) {
+          L->cap = L->cap ? 2 * L->cap : 64;
+          L->d = (orc_det_t *)realloc(L->d, sizeof(orc_det_t) * (size_t)L->cap);
+        }
+        orc_det_t *q = &L->d[L->n++];
+        q->xpos = x + pdx;
+        q->ypos = y + pdy;
+        q->scale = sc;
+        q->sharpness = g_contract ? fmaf(0.5f, dsum, val) : val + dval;
+        q->edgeness = edge;
       }
     }
   }
+  int n = 0;
+  for (int job = 0; job < nblk * NUM_SCALES; job++) {
+    for (int i = 0; i < lists[job].n; i++) {
+      int idx = start + n;
+      n++;
+      if (idx >= maxPts) {
+#pragma omp atomic
+        g_stats.capacity_drops++;
+        continue;
+      }
+      const orc_det_t *q = &lists[job].d[i];
+      SiftPoint *p = &pts[idx];
+      p->xpos = q->xpos;
+      p->ypos = q->ypos;
+      p->scale = q->scale;
+      p->sharpness = q->sharpness;
+      p->edgeness = q->edgeness;
+      p->subsampling = subsampling;
+    }
+    free(lists[job].d);
+  }
+  free(lists);
   for (size_t i = 0; i < (size_t)tilesx * tilesy * NUM_SCALES; i++)
-    if (tilecnt[i] > 32) g_stats.tile_overflows++;
+    if (tilecnt[i] > 32) {
+#pragma omp atomic
+      g_stats.tile_overflows++;
+    }
   free(tilecnt);
   return n;
 }
@@ -387,6 +449,13 @@ float orc_tex2d(const float *img, int w, int h, int pitch, float x, float y, int
 void orc_orientations(const float *img, int w, int h, int pitch, SiftPoint *pts, int first,
                       int last, unsigned int *dupCount, int maxPts, int fracbits)
 {
+  /* keypoints are independent: evaluate them in parallel, then append the second-orientation duplicates
+   * serially in keypoint order (the order a serial run of the loop below would produce) */
+  const int np = last > first ? last - first : 0;
+  float *ori2 = (float *)malloc(sizeof(float) * (size_t)(np > 0 ? np : 1));
+  unsigned char *has2 = (unsigned char *)calloc((size_t)(np > 0 ? np : 1), 1);
+  long empties = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : empties)
   for (int bx = first; bx < last; bx++) {
     SiftPoint *p = &pts[bx];
     float hist[64];
@@ -405,13 +474,13 @@ void orc_orientations(const float *img, int w, int h, int pitch, SiftPoint *pts,
       float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, fracbits) - tex2d(img, w, h, pitch, xf, yf - 1.0f, fracbits);
       int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
       if (bin > 31) bin = 0;
-      float grad = sqrtf(dx * dx + dy * dy);
+      float grad = sqrtf(mad(dx, dx, dy * dy));
       hist[bin] += grad * gauss[xd] * gauss[yd];
     }
     for (int tx = 0; tx < 32; tx++) {
       int x1m = (tx >= 1 ? tx - 1 : tx + 31), x1p = (tx <= 30 ? tx + 1 : tx - 31);
       int x2m = (tx >= 2 ? tx - 2 : tx + 30), x2p = (tx <= 29 ? tx + 2 : tx - 30);
-      hist[tx + 32] = 6.0f * hist[tx] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
+      hist[tx + 32] = mad(6.0f, hist[tx], 4.0f * (hist[x1m] + hist[x1p])) + (hist[x2m] + hist[x2p]);
     }
     for (int tx = 0; tx < 32; tx++) {
       int x1m = (tx >= 1 ? tx - 1 : tx + 31), x1p = (tx <= 30 ? tx + 1 : tx - 31);
@@ -429,7 +498,7 @@ void orc_orientations(const float *img, int w, int h, int pitch, SiftPoint *pts,
       }
     }
     if (i1 < 0) {                       /* Appendix B #8 */
-      g_stats.empty_hists++;
+      empties++;
       p->orientation = 0.0f;
       continue;
     }
@@ -443,18 +512,29 @@ void orc_orientations(const float *img, int w, int h, int pitch, SiftPoint *pts,
       float val1 = hist[32 + ((i2 + 1) & 31)];
       float val2 = hist[32 + ((i2 + 31) & 31)];
       float peak = i2 + 0.5f * (val1 - val2) / (2.0f * maxval2 - val1 - val2);
-      unsigned int idx = (*dupCount)++;
-      if (idx < (unsigned int)maxPts) {
-        SiftPoint *q = &pts[idx];
-        q->xpos = p->xpos; q->ypos = p->ypos; q->scale = p->scale;
-        q->sharpness = p->sharpness; q->edgeness = p->edgeness;
-        q->orientation = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
-        q->subsampling = p->subsampling;
-      } else {
-        g_stats.capacity_drops++;
-      }
+      has2[bx - first] = 1;
+      ori2[bx - first] = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
     }
   }
+#pragma omp atomic
+  g_stats.empty_hists += empties;
+  for (int bx = first; bx < last; bx++) {
+    if (!has2[bx - first]) continue;
+    const SiftPoint *p = &pts[bx];
+    unsigned int idx = (*dupCount)++;
+    if (idx < (unsigned int)maxPts) {
+      SiftPoint *q = &pts[idx];
+      q->xpos = p->xpos; q->ypos = p->ypos; q->scale = p->scale;
+      q->sharpness = p->sharpness; q->edgeness = p->edgeness;
+      q->orientation = ori2[bx - first];
+      q->subsampling = p->subsampling;
+    } else {
+#pragma omp atomic
+      g_stats.capacity_drops++;
+    }
+  }
+  free(ori2);
+  free(has2);
 }
 
 /* ------------------------------------------------------------ descriptors */
@@ -467,7 +547,9 @@ static inline float fast_atan2(float y, float x)
   if (mx == 0.0f) return 0.0f;
   float a = mn / mx;
   float s = a * a;
-  float r = ((-0.0464964749f * s + 0.15931422f) * s - 0.327622764f) * s * a + a;
+  float r;
+  if (g_contract) r = fmaf(fmaf(fmaf(-0.0464964749f, s, 0.15931422f), s, -0.327622764f) * s, a, a);
+  else r = ((-0.0464964749f * s + 0.15931422f) * s - 0.327622764f) * s * a + a;
   r = (absy > absx ? 1.57079637f - r : r);
   r = (x < 0 ? 3.14159274f - r : r);
   r = (y < 0 ? -r : r);
@@ -495,15 +577,21 @@ void orc_descriptors(const float *img, int w, int h, int pitch, SiftPoint *pts, 
     float scosa = scale * cosa;
     for (int y = 0; y < 16; y++) {
       for (int tx = 0; tx < 16; tx++) {
-        float xpos = p->xpos + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
-        float ypos = p->ypos + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+        float xpos, ypos;
+        if (g_contract) {
+          xpos = fmaf(-(y - 7.5f), ssina, fmaf(tx - 7.5f, scosa, p->xpos)) + 0.5f;
+          ypos = fmaf(y - 7.5f, scosa, fmaf(tx - 7.5f, ssina, p->ypos)) + 0.5f;
+        } else {
+          xpos = p->xpos + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
+          ypos = p->ypos + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+        }
         float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, fracbits) -
                    tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, fracbits);
         float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, fracbits) -
                    tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, fracbits);
-        float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+        float grad = gauss[y] * gauss[tx] * sqrtf(mad(dx, dx, dy * dy));
         if (dx == 0.0f && dy == 0.0f) guards++;
-        float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+        float angf = mad(4.0f / 3.1415f, fast_atan2(dy, dx), 4.0f);
 
         int hori = (tx + 2) / 4 - 1;
         float horf = (tx - 1.5f) / 4.0f - hori;
@@ -684,6 +772,35 @@ int orc_extract(const float *img, int width, int height, int pitch, int numOctav
   if (counters17) memcpy(counters17, job.cnt, sizeof(job.cnt));
   free(memoryTmp);
   return numPts;
+}
+
+/* Frame-parallel form for the CPU baseline of bench.py: `nframes` tightly packed frames, one per outer OpenMP
+ * thread (the stage loops inside then run on `inner_threads` threads each).  pts: nframes*maxPts records,
+ * numPts: nframes ints.  Same results as nframes calls of orc_extract. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+void orc_extract_batch(const float *imgs, int nframes, int width, int height, int numOctaves, float initBlur,
+                       float thresh, float lowestScale, SiftPoint *pts, int maxPts, int fracbits, int *numPts,
+                       int outer_threads, int inner_threads)
+{
+#ifdef _OPENMP
+  const int levels_saved = omp_get_max_active_levels();
+  omp_set_max_active_levels(2);
+  if (outer_threads < 1) outer_threads = 1;
+  if (inner_threads < 1) inner_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(outer_threads)
+#endif
+  for (int f = 0; f < nframes; f++) {
+#ifdef _OPENMP
+    omp_set_num_threads(inner_threads);       /* per-thread ICV: team size of the nested stage loops */
+#endif
+    numPts[f] = orc_extract(imgs + (size_t)f * width * height, width, height, width, numOctaves, initBlur, thresh,
+                            lowestScale, 0, pts + (size_t)f * maxPts, maxPts, fracbits, 0, NULL);
+  }
+#ifdef _OPENMP
+  omp_set_max_active_levels(levels_saved);
+#endif
 }
 
 /* ---------------------------------------------------------------- matcher */

@@ -486,3 +486,44 @@ def test_findpoints_against_independent_numpy(stereo):
         worst = np.maximum(worst, np.abs(vals[j] - np.array(g_)) / np.maximum(1.0, np.abs(vals[j])))
     assert (worst < 1e-5).all(), worst                     # measured: <= 9e-8 (float32 rounding of the outputs)
     print("findpoints cross-check worst relative differences (x, y, scale, sharpness, edgeness):", worst)
+
+
+# ------------------------------------------------------------------ error bar on the unpinned oracle
+def test_contraction_sensitivity(stereo):
+    """the extraction oracle is unpinned (no reference golden vectors, CUDA cannot be built), so
+    its one arbitrary arithmetic choice — plain vs nvcc-style contracted multiply-adds in the refinement,
+    orientation and descriptor code — is bounded here: both modes must find the SAME keypoints, and every field
+    must stay far inside the north_star tolerance.  The committed full report (7 images incl. 4096x3072,
+    32 726 keypoints, Jaccard 1.0) is profiles/r02_contraction_sensitivity.json, made by
+    tools/contraction_sensitivity.py."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from contraction_sensitivity import sensitivity
+    from synth import synth_frame
+    assert orc.lib().orc_get_contract() == 0            # parity tests run in plain mode
+    for name, img, thresh in (("left", stereo[0], 4.5), ("synth", synth_frame(0, 960, 540), 3.0)):
+        rep = sensitivity(img, num_octaves=5, init_blur=1.0, thresh=thresh)
+        assert rep["n_plain"] > 300, rep
+        assert rep["only_plain"] == 0 and rep["only_nvcc"] == 0 and rep["jaccard"] == 1.0, (name, rep)
+        assert rep["numPts_plain"] == rep["numPts_nvcc"]
+        assert rep["max_dpos_octave_px"] <= 1e-4 and rep["max_rel_dscale"] <= 1e-6, (name, rep)
+        assert rep["max_rel_dsharpness"] <= 1e-6 and rep["max_rel_dedgeness"] <= 1e-6, (name, rep)
+        assert rep["max_dorientation_deg"] <= 1e-3, (name, rep)
+        assert rep["max_ddescriptor"] <= 1e-3 and rep["min_descriptor_cos"] >= 1.0 - 1e-6, (name, rep)
+    assert orc.lib().orc_get_contract() == 0
+    # the contract switch itself is observable: at least one refined position differs in its last bits
+    a, na, _ = orc.extract(stereo[0], thresh=4.5)
+    with orc.contract(1):
+        b, nb, _ = orc.extract(stereo[0], thresh=4.5)
+    assert na == nb and not np.array_equal(a["xpos"][:na], b["xpos"][:nb])
+
+
+def test_extract_batch_equals_single_calls():
+    """orc_extract_batch (frame-parallel CPU baseline of bench.py) returns what per-frame orc_extract returns."""
+    from synth import synth_frame
+    imgs = np.stack([synth_frame(40 + f, 320, 240) for f in range(5)])
+    pts, n = orc.extract_batch(imgs, num_octaves=4, thresh=2.0, max_pts=4096, outer_threads=3, inner_threads=2)
+    for f in range(5):
+        ref, nref, _ = orc.extract(imgs[f], num_octaves=4, thresh=2.0, max_pts=4096)
+        assert nref == n[f] and nref > 50
+        assert ref[:nref].tobytes() == pts[f, :nref].tobytes()
