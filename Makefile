@@ -9,7 +9,8 @@ BUILD    := build
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) \
             -Wno-unused-result -Wno-unused-value
 HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_points.hip \
-            $(CSRC)/kernels_match.hip $(CSRC)/misift_host.hip $(CSRC)/homography.hip $(CSRC)/pipeline.hip
+            $(CSRC)/kernels_match.hip $(CSRC)/misift_host.hip $(CSRC)/homography.hip $(CSRC)/pipeline.hip \
+            $(CSRC)/multigpu.hip
 HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
 all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle dropin
@@ -19,7 +20,7 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 cudasift_amd/libmisift.so: $(HIPOBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIPOBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIPOBJS) -ldl
 
 cudasift_amd/libcudasift.so: $(CSRC)/shim_cudasift.cpp include/cudaSift.h include/cudaImage.h include/misift.h cudasift_amd/libmisift.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -o $@ $(CSRC)/shim_cudasift.cpp -Lcudasift_amd -lmisift -Wl,-rpath,'$$ORIGIN'

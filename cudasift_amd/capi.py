@@ -75,6 +75,16 @@ SIGNATURES = {
     "misift_rescale_positions": (_i, [_vp, _vp, _i, _f]),
     "misift_match": (_i, [_vp, _vp, _i, _vp, _i]),
     "misift_match_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
+    "misift_comm_unique_id": (_i, [_vp]),
+    "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "misift_comm_adopt": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "misift_comm_destroy": (None, [_vp]),
+    "misift_comm_rank": (_i, [_vp]),
+    "misift_comm_size": (_i, [_vp]),
+    "misift_comm_barrier": (_i, [_vp]),
+    "misift_gather_post": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "misift_gather_complete": (_i, [_vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "misift_match_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "misift_find_homography": (_i, [_vp, _vp, _i, _fp, _ip, _i, _f, _f, _f]),
     "misift_extract_batch_packed_async": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "misift_lowpass_scaledown": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f, _vp, _i]),
@@ -408,6 +418,59 @@ class Context:
             nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
             out[nm] = {"total_ms": float(ms[i]), "calls": int(calls[i])}
         return out
+
+
+COMM_ID_BYTES = 128
+RESULT_DTYPE = np.dtype([("score", "<f4"), ("ambiguity", "<f4"), ("match", "<i4")])      # 12 B/row (misift_match_sharded)
+
+
+def comm_unique_id():
+    """128 opaque bytes made by rank 0 (ncclGetUniqueId); ship them to the other ranks, then Comm(ctx, n, r, id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib().misift_comm_unique_id(C.cast(buf, C.c_void_p)), "misift_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """One RCCL communicator per context (misift_comm_*): the multi-GPU entry points of the C-ABI."""
+
+    def __init__(self, ctx, nranks, rank, id_bytes):
+        assert len(id_bytes) == COMM_ID_BYTES
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
+        check(lib().misift_comm_create(ctx.h, nranks, rank, C.cast(buf, C.c_void_p), C.byref(h)), "misift_comm_create")
+        self.h = h
+        self.ctx = ctx
+        self.rank, self.size = lib().misift_comm_rank(h), lib().misift_comm_size(h)
+
+    def barrier(self):
+        check(lib().misift_comm_barrier(self.h), "misift_comm_barrier")
+
+    def gather_post(self, slot, d_counts, nframes, d_packed):
+        check(lib().misift_gather_post(self.ctx.h, self.h, slot, d_counts, nframes, d_packed), "misift_gather_post")
+
+    def gather_complete(self, slot, nframes, root=0, d_recv=None, capacity_records=0):
+        """Returns (all_counts [size, nframes] int32, rank offsets [size+1] in records)."""
+        counts = np.zeros((self.size, nframes), np.int32)
+        offs = (C.c_size_t * (self.size + 1))()
+        check(lib().misift_gather_complete(self.h, slot, root, counts.ctypes.data, d_recv, capacity_records, offs),
+              "misift_gather_complete")
+        return counts, np.array(list(offs), np.int64)
+
+    def match_sharded(self, d_rows1, row_count, d_shard2, shard_count, d_set2_all, d_results_all=None):
+        check(lib().misift_match_sharded(self.ctx.h, self.h, d_rows1, row_count, d_shard2, shard_count, d_set2_all,
+                                         d_results_all), "misift_match_sharded")
+
+    def close(self):
+        if self.h:
+            lib().misift_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PinnedArray:

@@ -1,0 +1,334 @@
+// multigpu.hip — the multi-GPU entry points of the C-ABI (BASELINE configs 4 and 5) on RCCL over xGMI.
+//
+// The reference is single-GPU (one global device chosen by InitCuda, cudaSiftH.cu:19-37); north_star adds
+//   config 4: a batch of frames sharded over the GPUs of a node, SiftData gathered on one rank;
+//   config 5: 100k x 100k matching, row blocks of set 1 per GPU, set 2 all-gathered, results all-gathered.
+// Both live BEHIND the boundary so that a C++ caller of cudaSift.h (the only kind the reference has,
+// mainSift.cpp:25-93) can use 8 GPUs: one misift_ctx per device (one host thread or process each), one
+// misift_comm per context.  No collective touches the extraction data path; the matcher has exactly the one
+// exchange step it needs before the sweep and one after.
+//
+// RCCL is bound at run time (dlopen): libmisift.so carries no link dependency on it, a single-GPU user never
+// loads it, and inside a process that already holds an RCCL (PyTorch ships its own librccl.so) that copy is
+// reused instead of loading a second one.  xGMI is point to point (7 links per GPU): the variable-length
+// gather is ONE message per sender (7 senders -> 7 distinct links into the root), never a ring of padded blocks.
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <rccl/rccl.h>      // types and prototypes only; every call goes through the table below
+#include "common.hpp"
+
+// ------------------------------------------------------------------ RCCL binding
+struct RcclApi {
+  void *handle;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommCount)(const ncclComm_t, int *);
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*GroupStart)(void);
+  ncclResult_t (*GroupEnd)(void);
+  const char *(*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl;
+static int g_rccl_state = 0;      // 0 = untried, 1 = bound, -1 = unavailable
+
+static int rccl_bind(void)
+{
+  if (g_rccl_state) return g_rccl_state > 0 ? MISIFT_OK : MISIFT_ENODEV;
+  void *h = nullptr;
+  // an RCCL already mapped into the process wins (PyTorch's own copy has the soname librccl.so)
+  const char *names[] = {"librccl.so", "librccl.so.1"};
+  for (const char *n : names)
+    if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  if (const char *e = getenv("MISIFT_RCCL_LIB"))
+    if (!h) h = dlopen(e, RTLD_NOW);
+  const char *paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : paths)
+    if (!h) h = dlopen(n, RTLD_NOW);
+  if (!h) {
+    g_rccl_state = -1;
+    misift_set_error("RCCL not found (librccl.so.1): %s", dlerror());
+    return MISIFT_ENODEV;
+  }
+  g_rccl.handle = h;
+  bool ok = true;
+#define BIND(field, sym)                                                          \
+  do {                                                                            \
+    *(void **)(&g_rccl.field) = dlsym(h, sym);                                    \
+    if (!g_rccl.field) { ok = false; misift_set_error("RCCL symbol %s missing", sym); } \
+  } while (0)
+  BIND(GetUniqueId, "ncclGetUniqueId");
+  BIND(CommInitRank, "ncclCommInitRank");
+  BIND(CommDestroy, "ncclCommDestroy");
+  BIND(CommCount, "ncclCommCount");
+  BIND(CommUserRank, "ncclCommUserRank");
+  BIND(AllGather, "ncclAllGather");
+  BIND(Send, "ncclSend");
+  BIND(Recv, "ncclRecv");
+  BIND(GroupStart, "ncclGroupStart");
+  BIND(GroupEnd, "ncclGroupEnd");
+  BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+  g_rccl_state = ok ? 1 : -1;
+  return ok ? MISIFT_OK : MISIFT_ENODEV;
+}
+
+#define NCCL_TRY(expr)                                                                         \
+  do {                                                                                         \
+    ncclResult_t r_ = (expr);                                                                  \
+    if (r_ != ncclSuccess) {                                                                   \
+      misift_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+      return MISIFT_EHIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+#define MG_CHECK(cond)                                                        \
+  do {                                                                        \
+    if (!(cond)) {                                                            \
+      misift_set_error("%s: invalid argument: %s", __func__, #cond);          \
+      return MISIFT_EINVAL;                                                   \
+    }                                                                         \
+  } while (0)
+
+// ------------------------------------------------------------------ communicator
+struct GatherSlot {
+  const int *d_counts;
+  const void *d_packed;
+  int nframes;
+  hipEvent_t ready;      // recorded on the context stream when the batch was posted
+  bool posted;
+};
+
+struct misift_comm {
+  misift_ctx *ctx;
+  ncclComm_t nccl;
+  bool owns_nccl;
+  int rank, nranks;
+  hipStream_t stream;           // communication stream: high priority, beside the extraction on the context stream
+  int *d_all_counts;            // [nranks][cap_frames] staging of the count all-gather
+  int *h_all_counts;            // pinned mirror
+  int cap_frames;
+  std::vector<GatherSlot> slots;
+};
+
+extern "C" int misift_comm_unique_id(void *id128)
+{
+  MG_CHECK(id128 != nullptr);
+  int rc = rccl_bind();
+  if (rc) return rc;
+  static_assert(MISIFT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  ncclUniqueId id;
+  NCCL_TRY(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return MISIFT_OK;
+}
+
+static int comm_finish_create(misift_ctx *ctx, ncclComm_t nc, bool owns, misift_comm **out)
+{
+  misift_comm *c = new misift_comm();
+  c->ctx = ctx; c->nccl = nc; c->owns_nccl = owns;
+  c->rank = 0; c->nranks = 1; c->stream = nullptr;
+  c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0;
+  c->slots.resize(4);
+  for (GatherSlot &s : c->slots) { memset(&s, 0, sizeof(s)); }
+  *out = c;                                           // from here on misift_comm_destroy cleans up after a failure
+  NCCL_TRY(g_rccl.CommCount(nc, &c->nranks));
+  NCCL_TRY(g_rccl.CommUserRank(nc, &c->rank));
+  int lo = 0, hi = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+  for (GatherSlot &s : c->slots) HIP_TRY(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
+  return MISIFT_OK;
+}
+
+extern "C" void misift_comm_destroy(misift_comm *c)
+{
+  if (!c) return;
+  if (c->ctx) hipSetDevice(c->ctx->device);
+  if (c->stream) { hipStreamSynchronize(c->stream); }
+  if (c->nccl && c->owns_nccl && g_rccl_state > 0) g_rccl.CommDestroy(c->nccl);
+  if (c->stream) hipStreamDestroy(c->stream);
+  for (GatherSlot &s : c->slots)
+    if (s.ready) hipEventDestroy(s.ready);
+  if (c->d_all_counts) hipFree(c->d_all_counts);
+  if (c->h_all_counts) hipHostFree(c->h_all_counts);
+  delete c;
+}
+
+extern "C" int misift_comm_create(misift_ctx *ctx, int nranks, int rank, const void *id128, misift_comm **out)
+{
+  MG_CHECK(ctx && out && id128 && nranks >= 1 && rank >= 0 && rank < nranks);
+  *out = nullptr;
+  int rc = rccl_bind();
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t nc = nullptr;
+  NCCL_TRY(g_rccl.CommInitRank(&nc, nranks, id, rank));
+  rc = comm_finish_create(ctx, nc, true, out);
+  if (rc) { misift_comm_destroy(*out); *out = nullptr; }
+  return rc;
+}
+
+extern "C" int misift_comm_adopt(misift_ctx *ctx, void *nccl_comm, misift_comm **out)
+{
+  MG_CHECK(ctx && out && nccl_comm);
+  *out = nullptr;
+  int rc = rccl_bind();
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  rc = comm_finish_create(ctx, (ncclComm_t)nccl_comm, false, out);
+  if (rc) { misift_comm_destroy(*out); *out = nullptr; }
+  return rc;
+}
+
+extern "C" int misift_comm_rank(const misift_comm *c) { return c ? c->rank : -1; }
+extern "C" int misift_comm_size(const misift_comm *c) { return c ? c->nranks : 0; }
+
+extern "C" int misift_comm_barrier(misift_comm *c)
+{
+  MG_CHECK(c != nullptr);
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  // an all-gather of one int per rank on the communication stream, then a host wait: every rank has arrived
+  if (c->cap_frames < 1) {
+    HIP_TRY(hipMalloc((void **)&c->d_all_counts, sizeof(int) * (size_t)c->nranks * 64));
+    HIP_TRY(hipHostMalloc((void **)&c->h_all_counts, sizeof(int) * (size_t)c->nranks * 64, hipHostMallocDefault));
+    HIP_TRY(hipMemsetAsync(c->d_all_counts, 0, sizeof(int) * (size_t)c->nranks * 64, c->stream));
+    c->cap_frames = 64;
+  }
+  NCCL_TRY(g_rccl.AllGather(c->d_all_counts + c->rank, c->d_all_counts, 1, ncclInt32, c->nccl, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return MISIFT_OK;
+}
+
+// ------------------------------------------------------------------ config 4: gather of SiftData
+extern "C" int misift_gather_post(misift_ctx *ctx, misift_comm *c, int slot, const int *d_counts, int nframes,
+                                  const void *d_packed)
+{
+  MG_CHECK(ctx && c && c->ctx == ctx && d_counts && d_packed && nframes >= 1);
+  MG_CHECK(slot >= 0 && slot < (int)c->slots.size());
+  GatherSlot &s = c->slots[slot];
+  s.d_counts = d_counts; s.d_packed = d_packed; s.nframes = nframes;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipEventRecord(s.ready, ctx->stream));      // the batch queued so far on the context stream produces these buffers
+  s.posted = true;
+  return MISIFT_OK;
+}
+
+extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h_all_counts, void *d_recv,
+                                      size_t capacity_records, size_t *h_rank_offsets)
+{
+  MG_CHECK(c && slot >= 0 && slot < (int)c->slots.size() && root >= 0 && root < c->nranks);
+  GatherSlot &s = c->slots[slot];
+  MG_CHECK(s.posted);
+  MG_CHECK(h_all_counts != nullptr);
+  MG_CHECK(c->rank != root || c->nranks == 1 || d_recv != nullptr);
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  const int nf = s.nframes, nr = c->nranks;
+  if (nf > c->cap_frames) {
+    if (c->d_all_counts) HIP_TRY(hipFree(c->d_all_counts));
+    if (c->h_all_counts) HIP_TRY(hipHostFree(c->h_all_counts));
+    c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0;
+    HIP_TRY(hipMalloc((void **)&c->d_all_counts, sizeof(int) * (size_t)nr * nf));
+    HIP_TRY(hipHostMalloc((void **)&c->h_all_counts, sizeof(int) * (size_t)nr * nf, hipHostMallocDefault));
+    c->cap_frames = nf;
+  }
+  HIP_TRY(hipStreamWaitEvent(c->stream, s.ready, 0));
+  // 1. per-frame counts of every rank (nframes ints per rank; every rank must post the same nframes)
+  NCCL_TRY(g_rccl.AllGather(s.d_counts, c->d_all_counts, (size_t)nf, ncclInt32, c->nccl, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_all_counts, c->d_all_counts, sizeof(int) * (size_t)nr * nf, hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));          // the message sizes must be known on the host (NCCL API)
+  memcpy(h_all_counts, c->h_all_counts, sizeof(int) * (size_t)nr * nf);
+  std::vector<size_t> nrec((size_t)nr, 0), off((size_t)nr + 1, 0);
+  for (int r = 0; r < nr; r++) {
+    for (int f = 0; f < nf; f++) {
+      const int v = c->h_all_counts[(size_t)r * nf + f];
+      if (v > 0) nrec[r] += (size_t)v;               // -1 marks an overflowed frame: no records
+    }
+    off[r + 1] = off[r] + nrec[r];
+  }
+  if (h_rank_offsets) memcpy(h_rank_offsets, off.data(), sizeof(size_t) * ((size_t)nr + 1));
+  int rc = MISIFT_OK;
+  if (c->rank == root) {
+    if (d_recv && off[nr] > capacity_records) {
+      // still take part in the exchange (the peers are already committed to their sends) but into nothing:
+      // report instead.  Peers cannot be told, so this is fatal for the caller's sizing, not for the job.
+      misift_set_error("misift_gather_complete: %zu records but room for %zu", off[nr], capacity_records);
+      rc = MISIFT_ENOMEM;
+    }
+  }
+  // 2. ONE point-to-point message per sender with exactly its valid bytes (xGMI: distinct links into the root)
+  if (rc == MISIFT_OK || c->rank != root) {
+    NCCL_TRY(g_rccl.GroupStart());
+    if (c->rank == root) {
+      for (int r = 0; r < nr; r++) {
+        if (r == root || nrec[r] == 0) continue;
+        NCCL_TRY(g_rccl.Recv((char *)d_recv + off[r] * sizeof(SiftPointD), nrec[r] * sizeof(SiftPointD), ncclUint8, r,
+                             c->nccl, c->stream));
+      }
+    } else if (nrec[c->rank]) {
+      NCCL_TRY(g_rccl.Send(s.d_packed, nrec[c->rank] * sizeof(SiftPointD), ncclUint8, root, c->nccl, c->stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    if (c->rank == root && d_recv && nrec[root])
+      HIP_TRY(hipMemcpyAsync((char *)d_recv + off[root] * sizeof(SiftPointD), s.d_packed, nrec[root] * sizeof(SiftPointD),
+                             hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));          // the slot's buffers are free again when this returns
+  s.posted = false;
+  return rc;
+}
+
+// ------------------------------------------------------------------ config 5: row-block matcher
+struct MatchResult { float score, ambiguity; int match; };     // the 12 B/row result of SURVEY 8e
+static_assert(sizeof(MatchResult) == 12, "result row");
+
+__global__ void pack_match_results_kernel(const SiftPointD *__restrict__ rows, int n, MatchResult *__restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    MatchResult r;
+    r.score = rows[i].score; r.ambiguity = rows[i].ambiguity; r.match = rows[i].match;
+    out[i] = r;
+  }
+}
+
+extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_rows1, int row_count, const void *d_shard2,
+                                    int shard_count, void *d_set2_all, void *d_results_all)
+{
+  MG_CHECK(ctx && c && c->ctx == ctx && row_count >= 0 && shard_count >= 0);
+  MG_CHECK(row_count == 0 || d_rows1);
+  MG_CHECK(shard_count == 0 || (d_shard2 && d_set2_all));
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int nr = c->nranks;
+  const long long n2 = (long long)shard_count * nr;
+  MG_CHECK(n2 < (1ll << 31));
+  // 1. replicate set 2: all-gather of the record shards (576 B x shard_count per rank; 57.6 MB at 100k) on the context
+  //    stream — it must precede the sweep, there is nothing to overlap it with
+  if (shard_count)
+    NCCL_TRY(g_rccl.AllGather(d_shard2, d_set2_all, (size_t)shard_count * sizeof(SiftPointD), ncclUint8, c->nccl,
+                              ctx->stream));
+  // 2. this rank's rows against all of set 2 (fp32 MFMA sweep, same kernel as misift_match)
+  if (row_count && n2) {
+    int rc = launch_match(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2);
+    if (rc) return rc;
+  }
+  // 3. results: 12 B per row, all-gathered so every rank holds the whole answer (row blocks in rank order)
+  if (d_results_all && row_count) {
+    MatchResult *all = (MatchResult *)d_results_all;
+    MatchResult *mine = all + (size_t)c->rank * row_count;
+    hipLaunchKernelGGL(pack_match_results_kernel, dim3((row_count + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const SiftPointD *)d_rows1, row_count, mine);
+    HIP_TRY(hipGetLastError());
+    NCCL_TRY(g_rccl.AllGather(mine, all, (size_t)row_count * sizeof(MatchResult), ncclUint8, c->nccl, ctx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));         // matching.cu:1191: MatchSiftData returns with the results in place
+  return MISIFT_OK;
+}

@@ -262,6 +262,52 @@ int misift_match(misift_ctx *ctx, void *d_pts1, int n1, const void *d_pts2, int 
 int misift_match_rows(misift_ctx *ctx, void *d_pts1, int row_begin, int row_count,
                       const void *d_pts2, int n2);
 
+/* ------------------------------------------------------------ multi-GPU
+ * The reference is single-GPU (InitCuda picks ONE device, cudaSiftH.cu:19-37); BASELINE configs 4 and 5 shard
+ * frames / matcher rows over the GPUs of a node.  One misift_ctx per device (one host thread or process each) and
+ * one misift_comm per context; collectives run on RCCL over xGMI, bound at run time (no link dependency: a
+ * single-GPU caller never loads RCCL).  Nothing here touches the extraction data path — frames shard
+ * embarrassingly; the only exchanges are the gather of SiftData after compute (config 4) and the set-2 /
+ * result all-gathers around the matcher sweep (config 5). */
+typedef struct misift_comm misift_comm;
+#define MISIFT_COMM_ID_BYTES 128
+/* Rendezvous like ncclGetUniqueId / ncclCommInitRank: rank 0 makes the id, ships its 128 bytes to the other
+ * ranks by any means (MPI, a file, torch.distributed's store), every rank then creates its communicator on its
+ * context's device.  misift_comm_adopt wraps a caller-supplied ncclComm_t instead (not destroyed with the comm). */
+int misift_comm_unique_id(void *id128);
+int misift_comm_create(misift_ctx *ctx, int nranks, int rank, const void *id128, misift_comm **out);
+int misift_comm_adopt(misift_ctx *ctx, void *nccl_comm, misift_comm **out);
+void misift_comm_destroy(misift_comm *comm);
+int misift_comm_rank(const misift_comm *comm);
+int misift_comm_size(const misift_comm *comm);
+int misift_comm_barrier(misift_comm *comm);        /* all ranks have arrived (host-blocking) */
+
+/* BASELINE config 4 — gather of SiftData on `root`, pipelined under the next batches' extraction.
+ *   misift_gather_post      right after misift_extract_batch_packed_async: remembers that batch's device buffers
+ *                           (d_counts[nframes], d_packed) in `slot` (0..3) and marks the point on the context stream
+ *                           where they are complete.  Returns at once.
+ *   misift_gather_complete  on the communicator's own high-priority stream: all-gather of the per-frame counts
+ *                           (nframes ints per rank, the same nframes on every rank), then ONE point-to-point message
+ *                           per sender carrying exactly its valid 576-byte records (xGMI is a full mesh: 7 senders use
+ *                           7 distinct links into the root).  h_all_counts[nranks*nframes] (host, every rank; -1 = that
+ *                           frame's candidate list overflowed, no records); on the root the records of rank r land at
+ *                           d_recv + h_rank_offsets[r] records (h_rank_offsets: nranks+1 entries, host, optional).
+ *                           Blocks the host until the transfer is done: the slot's buffers may be reused. */
+int misift_gather_post(misift_ctx *ctx, misift_comm *comm, int slot, const int *d_counts, int nframes,
+                       const void *d_packed);
+int misift_gather_complete(misift_comm *comm, int slot, int root, int *h_all_counts, void *d_recv,
+                           size_t capacity_records, size_t *h_rank_offsets);
+
+/* BASELINE config 5 — MatchSiftData (matching.cu:1090-1206) with set 1 split into row blocks, one per rank.
+ * d_rows1: this rank's row block (row_count records, updated in place like misift_match); d_shard2: this rank's
+ * shard of set 2 (shard_count records; row_count and shard_count must be equal on all ranks — pad the last block).
+ * Steps: all-gather of the set-2 shards into d_set2_all (nranks*shard_count records, rank order), the fp32-MFMA
+ * sweep of the rank's rows over all of it, then the all-gather of the 12-byte results {float score, float
+ * ambiguity, int match} of every row into d_results_all (nranks*row_count entries, may be NULL).  Match indices
+ * refer to the gathered set 2.  Returns with everything in place (matching.cu:1191). */
+int misift_match_sharded(misift_ctx *ctx, misift_comm *comm, void *d_rows1, int row_count, const void *d_shard2,
+                         int shard_count, void *d_set2_all, void *d_results_all);
+
 /* FindHomography (matching.cu:1000-1087): RANSAC over stored matches. */
 int misift_find_homography(misift_ctx *ctx, const void *d_pts, int npts, float *homography9,
                            int *num_matches, int num_loops, float min_score,

@@ -67,7 +67,7 @@ def lib():
                                   C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint)]
         L.orc_extract.restype = C.c_int
         L.orc_extract_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp,
-                                        C.c_int, C.c_int, vp, C.c_int, C.c_int]
+                                        C.c_int, C.c_int, vp, vp, C.c_int, C.c_int]
         L.orc_set_contract.argtypes = [C.c_int]
         L.orc_get_contract.restype = C.c_int
         L.orc_dot128.argtypes = [vp, vp]
@@ -191,16 +191,18 @@ def extract(img, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, sca
 
 def extract_batch(imgs, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, max_pts=32768, fracbits=8,
                   outer_threads=None, inner_threads=1):
-    """orc_extract_batch: frames [B,h,w] processed one per OpenMP thread.  Returns (points[B,max_pts], numPts[B])."""
+    """orc_extract_batch: frames [B,h,w] processed one per OpenMP thread.
+    Returns (points[B,max_pts], numPts[B], counters[B,17])."""
     imgs = _f32(imgs)
     B, h, w = imgs.shape
     pts = np.zeros((B, max_pts), POINT_DTYPE)
     n = np.zeros(B, np.int32)
+    cnt = np.zeros((B, 17), np.uint32)
     if outer_threads is None:
         outer_threads = min(B, os.cpu_count() or 1)
     lib().orc_extract_batch(_p(imgs), B, w, h, num_octaves, init_blur, thresh, lowest_scale, _p(pts), max_pts,
-                            fracbits, _p(n), outer_threads, inner_threads)
-    return pts, n
+                            fracbits, _p(n), _p(cnt), outer_threads, inner_threads)
+    return pts, n, cnt
 
 
 class contract:

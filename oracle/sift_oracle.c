@@ -776,13 +776,13 @@ int orc_extract(const float *img, int width, int height, int pitch, int numOctav
 
 /* Frame-parallel form for the CPU baseline of bench.py: `nframes` tightly packed frames, one per outer OpenMP
  * thread (the stage loops inside then run on `inner_threads` threads each).  pts: nframes*maxPts records,
- * numPts: nframes ints.  Same results as nframes calls of orc_extract. */
+ * numPts: nframes ints, counters17 (optional): nframes x 17.  Same results as nframes calls of orc_extract. */
 #ifdef _OPENMP
 #include <omp.h>
 #endif
 void orc_extract_batch(const float *imgs, int nframes, int width, int height, int numOctaves, float initBlur,
                        float thresh, float lowestScale, SiftPoint *pts, int maxPts, int fracbits, int *numPts,
-                       int outer_threads, int inner_threads)
+                       unsigned int *counters17, int outer_threads, int inner_threads)
 {
 #ifdef _OPENMP
   const int levels_saved = omp_get_max_active_levels();
@@ -796,7 +796,8 @@ void orc_extract_batch(const float *imgs, int nframes, int width, int height, in
     omp_set_num_threads(inner_threads);       /* per-thread ICV: team size of the nested stage loops */
 #endif
     numPts[f] = orc_extract(imgs + (size_t)f * width * height, width, height, width, numOctaves, initBlur, thresh,
-                            lowestScale, 0, pts + (size_t)f * maxPts, maxPts, fracbits, 0, NULL);
+                            lowestScale, 0, pts + (size_t)f * maxPts, maxPts, fracbits, 0,
+                            counters17 ? counters17 + 17 * (size_t)f : NULL);
   }
 #ifdef _OPENMP
   omp_set_max_active_levels(levels_saved);

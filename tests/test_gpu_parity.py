@@ -649,3 +649,68 @@ def test_extract_large_frame_4096x3072(ctx):
     assert nref > 5000 and ngot == nref and np.array_equal(cref, cgot)
     tot = int(cref[11])
     compare_points(ref[:tot], got[:tot], "extract_4096x3072_points", record)
+
+
+# ------------------------------------------------------------------ the path bench.py times
+def _packed_async_1080p(c, d_frames, B, scratch, cnt, packed, mp):
+    """One call of the exact entry point bench.py times: packed-only output (d_pts = NULL), 1920x1080, B frames."""
+    from cudasift_amd import capi
+    capi.check(capi.lib().misift_extract_batch_packed_async(c.h, d_frames.ptr, B, 1080 * 1920, 1920, 1080, 1920, 5, 1.0, 3.0,
+                                                            0.0, scratch.ptr, None, mp, cnt.ptr, cnt.ptr + 4 * B,
+                                                            packed.ptr), "misift_extract_batch_packed_async")
+    c.sync()
+    ci = c.download(cnt, (2 * B + 1,), np.int32)
+    counts, offs = ci[:B].copy(), ci[B:].copy()
+    recs = c.download(packed, (int(offs[B]),), capi.POINT_DTYPE)
+    counters = np.stack([c.get_counters(f) for f in range(B)])
+    return counts, offs, recs, counters
+
+
+def test_timed_path_16x1080p_packed_async_vs_oracle(ctx):
+    """The path bench.py times — misift_extract_batch_packed_async with d_pts = NULL on a batch of 1920x1080 frames
+    large enough (>= 8) to take the split-tail branch (second high-priority stream, fork/join events, two
+    dog_scan launches) — against the oracle, frame by frame: 17 counters + every record.  Then the same batch
+    with the split disabled (MISIFT_SPLIT_TAIL=0): byte-identical records after canonical sort."""
+    import os
+    from cudasift_amd import capi
+    B, mp = 16, 8192
+    frames = np.stack([synth_frame(7000 + f) for f in range(B)])
+    d = ctx.upload(frames)
+    scratch = capi.DevBuf(4 * capi.scratch_floats(1920, 1080, 5, False) * B)
+    cnt = ctx.zeros(4 * (2 * B + 1))
+    packed = ctx.upload(np.full(576 * mp * B, 0xA5, np.uint8))          # dirty: every byte of every record must be written
+    counts, offs, recs, counters = _packed_async_1080p(ctx, d, B, scratch, cnt, packed, mp)
+    prof_ctx = capi.Context(0)
+    try:                                                                  # the premise: this batch does take two scan launches
+        prof_ctx.profile_enable(True)
+        _packed_async_1080p(prof_ctx, d, B, scratch, cnt, ctx.zeros(576 * mp * B), mp)
+        assert prof_ctx.profile_read()["dog_scan"]["calls"] == 2
+    finally:
+        prof_ctx.close()
+    ref, nref, cref = orc().extract_batch(frames, num_octaves=5, init_blur=1.0, thresh=3.0, max_pts=mp)
+    assert offs[0] == 0 and np.array_equal(np.diff(offs), counts)
+    assert np.array_equal(counts, nref), (counts, nref)
+    assert np.array_equal(counters, cref), "17-counter protocol differs from the oracle"
+    assert 1500 < counts.min() and counts.max() < 3000
+    for f in range(B):
+        compare_points(ref[f, :nref[f]], recs[offs[f]:offs[f + 1]], "timed_path_f%d" % f, record)
+    record("timed_path", frames=B, keypoints=int(counts.sum()), split_tail=True)
+    saved = os.environ.get("MISIFT_SPLIT_TAIL")
+    os.environ["MISIFT_SPLIT_TAIL"] = "0"
+    try:
+        c2 = capi.Context(0)
+    finally:
+        if saved is None:
+            del os.environ["MISIFT_SPLIT_TAIL"]
+        else:
+            os.environ["MISIFT_SPLIT_TAIL"] = saved
+    try:
+        packed2 = c2.upload(np.full(576 * mp * B, 0x5A, np.uint8))
+        c2.profile_enable(True)
+        counts2, offs2, recs2, counters2 = _packed_async_1080p(c2, d, B, scratch, cnt, packed2, mp)
+        assert c2.profile_read()["dog_scan"]["calls"] == 1               # single-stream structure
+    finally:
+        c2.close()
+    assert np.array_equal(counts, counts2) and np.array_equal(offs, offs2) and np.array_equal(counters, counters2)
+    for f in range(B):
+        assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(recs2[offs[f]:offs[f + 1]]), f

@@ -522,8 +522,8 @@ def test_extract_batch_equals_single_calls():
     """orc_extract_batch (frame-parallel CPU baseline of bench.py) returns what per-frame orc_extract returns."""
     from synth import synth_frame
     imgs = np.stack([synth_frame(40 + f, 320, 240) for f in range(5)])
-    pts, n = orc.extract_batch(imgs, num_octaves=4, thresh=2.0, max_pts=4096, outer_threads=3, inner_threads=2)
+    pts, n, cnt = orc.extract_batch(imgs, num_octaves=4, thresh=2.0, max_pts=4096, outer_threads=3, inner_threads=2)
     for f in range(5):
-        ref, nref, _ = orc.extract(imgs[f], num_octaves=4, thresh=2.0, max_pts=4096)
-        assert nref == n[f] and nref > 50
+        ref, nref, cref = orc.extract(imgs[f], num_octaves=4, thresh=2.0, max_pts=4096)
+        assert nref == n[f] and nref > 50 and np.array_equal(cref, cnt[f])
         assert ref[:nref].tobytes() == pts[f, :nref].tobytes()
