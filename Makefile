@@ -13,7 +13,7 @@ HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_
             $(CSRC)/multigpu.hip
 HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
-all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle dropin
+all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle dropin build/pmc_calib
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
 	@mkdir -p $(BUILD)
@@ -24,6 +24,11 @@ cudasift_amd/libmisift.so: $(HIPOBJS)
 
 cudasift_amd/libcudasift.so: $(CSRC)/shim_cudasift.cpp include/cudaSift.h include/cudaImage.h include/misift.h cudasift_amd/libmisift.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Iinclude -o $@ $(CSRC)/shim_cudasift.cpp -Lcudasift_amd -lmisift -Wl,-rpath,'$$ORIGIN'
+
+# FETCH_SIZE calibration kernels (tools/pmc_calib.py runs them under rocprofv3 on the GPU box)
+build/pmc_calib: tools/pmc_calib.hip
+	@mkdir -p $(BUILD)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
 
 oracle:
 	$(MAKE) -C oracle all

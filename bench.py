@@ -1,23 +1,27 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark: 1920x1080 SIFT frames/s (+ 100k x 100k match Mpairs/s).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per
-GPU with torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the env, backend "nccl" = RCCL).
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
+torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the env).
 
 A step = one pass of the hot path (ExtractSift: LowPass -> pyramid -> DoG -> extrema -> orientation ->
-descriptors -> count read-back, mainSift.cpp:58-67 parameters) over one batch of FRAMES_PER_GPU
-synthetic 1920x1080 frames already resident in HBM, followed — when N > 1 — by the RCCL gather of the
-valid SiftPoint records to rank 0 (BASELINE config 4).  Per-GPU work is fixed as N grows ("weak").
-Rank 0 prints ONE JSON line; `value` is whole-job frames/s.
+descriptors -> count read-back, mainSift.cpp:58-67 parameters) over one batch of FRAMES_PER_GPU synthetic
+1920x1080 frames already resident in HBM.  Every rank holds 8 such batches of DISTINCT frames (512 frames = the
+whole BASELINE config 4 job at N = 1) and rotates through them; with N > 1 the valid SiftPoint records of every
+batch are gathered on rank 0 over RCCL/xGMI (misift_gather_*), pipelined under the following batches.  Per-GPU
+work is fixed as N grows ("weak").  Rank 0 prints ONE JSON line; `value` is whole-job frames/s.
 
-torch is used for device memory, streams and torch.distributed only; all compute goes through the
-C-ABI of libmisift.so (cudasift_amd.capi).  The oracle is used only for the `cpu_baseline` leg.
+torch is plumbing only (device memory, the frame generator, rendezvous/barrier): all compute AND the data-path
+collectives go through the C-ABI of libmisift.so (cudasift_amd.capi).  The oracle is the checker of the
+self-validation and the thing timed in the `cpu_baseline` leg — never part of the measured path.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,8 +30,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1920, 1080
 NUM_OCTAVES, INIT_BLUR, THRESH, MAX_PTS = 5, 1.0, 3.0, 32768
+NUM_BATCHES = 8                # distinct 64-frame batches per rank (8 x 64 = 512 frames, BASELINE config 4)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+VALU_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: peak FP32 (vector), 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32 matrix peak
+ALG_BYTES_PER_FRAME = 197.2e6
+# structural floor of a fused design: input 8.3 MB + pyramid written once 11.05 MB + read once by the
+# scan 11.05 MB + records 1.2 MB
+FLOOR_BYTES_PER_FRAME = 31.6e6
+
+KERNEL_NAMES = {"lowpass_kernel": "lowpass", "lowpass_down_kernel": "lowpass_down", "scaledown_kernel": "scaledown",
+                "scaledown_tail_kernel": "scaledown", "dog_scan_all_kernel": "dog_scan", "dog_scan_kernel": "dog_scan",
+                "refine_all_kernel": "refine", "orient_all_kernel": "orient_all", "descr_all_kernel": "descr_all",
+                "orient_descr_all_kernel": "orient_descr", "bin_detections_kernel": "bin_detections",
+                "laplace_kernel": "laplace", "detect_kernel": "detect", "match_kernel": "match_mfma"}
+import numpy as _np
+RESULT_DTYPE_NP = _np.dtype([("score", "<f4"), ("ambiguity", "<f4"), ("match", "<i4")])     # misift_match_sharded's 12 B/row
+GATHER_KERNELS = ("refine", "orient_all", "descr_all", "orient_descr")      # scattered 8-byte reads, not wide streaming
 
 
 def octave_pixels(w, h, n):
@@ -40,7 +59,7 @@ def octave_pixels(w, h, n):
 
 
 def algorithmic_bytes_per_frame():
-    """SURVEY.md §8(d): fp32, each intermediate written once and read once."""
+    """SURVEY.md 8(d): fp32, each intermediate written once and read once."""
     N = octave_pixels(W, H, NUM_OCTAVES)
     lowpass = 8 * N[0]
     scaledown = sum(4 * N[i] + 4 * N[i + 1] for i in range(NUM_OCTAVES - 1))
@@ -50,42 +69,250 @@ def algorithmic_bytes_per_frame():
             "dog_scan": laplace + findpoints}
 
 
-def gen_frames_torch(torch, nframes, first, device):
+def dog_scan_flop_per_px():
+    """fp32 operations the fused scan NEEDS per pixel of a pyramid level (kernels_dog.hip scan_strip), counted from
+    the blur structure: it evaluates the 6 blurs (scales 1..6) whose 5 differences are the centre DoG planes.
+      shared by the 6 blurs : 4 vertical pair sums r[-j] + r[+j]                         =   4
+      per blur, vertical    : 1 mul + 4 fma (centre tap, then 4 symmetric pairs)         =   9
+      per blur, horizontal  : 4 pair sums + 1 mul + 4 fma                                =  13
+      5 DoG differences, 5 |v| folded into the running maximum (abs is a free modifier)  =  10
+    = 4 + 6 * 22 + 10 = 146 flop/px (an fma counts 2).  The extremum tests run on < 1 % of the rows and are not
+    counted; neither are DPP moves, selects or address arithmetic — they are overhead against this roof."""
+    shared, per_blur, dog = 4, (1 + 2 * 4) + (4 + 1 + 2 * 4), 5 + 5
+    return shared + 6 * per_blur + dog
+
+
+def gen_frames_torch(torch, nframes, first, device, out=None):
     """tests/synth.py recipe on the GPU (torch.fft): equal-energy octave bands of Gaussian noise."""
     import math
     g = torch.Generator(device=device)
     fy = torch.fft.fftfreq(H, device=device)[:, None]
     fx = torch.fft.rfftfreq(W, device=device)[None, :]
     r2 = fx * fx + fy * fy
-    frames = torch.empty((nframes, H, W), dtype=torch.float32, device=device)
+    gks = [torch.exp(-2.0 * (math.pi ** 2) * ((2.0 ** j) ** 2) * r2) for j in range(6)]
+    frames = out if out is not None else torch.empty((nframes, H, W), dtype=torch.float32, device=device)
     for f in range(nframes):
         g.manual_seed(0x51F7 + first + f)
         acc = torch.zeros((H, W), dtype=torch.float32, device=device)
         for j in range(6):
             w = torch.randn((H, W), generator=g, device=device, dtype=torch.float32)
-            sigma = 2.0 ** j
-            gk = torch.exp(-2.0 * (math.pi ** 2) * (sigma ** 2) * r2)
-            b = torch.fft.irfft2(torch.fft.rfft2(w) * gk, s=(H, W))
+            b = torch.fft.irfft2(torch.fft.rfft2(w) * gks[j], s=(H, W))
             acc += b / b.std()
         frames[f] = torch.clamp(128.0 + 26.0 * acc / acc.std(), 0.0, 255.0)
     return frames
 
 
+# ------------------------------------------------------------------------------------------------ PMC (live)
+def pmc_child():
+    """Run under `rocprofv3 --pmc ...` by collect_pmc(): 1 warm-up + 3 steps of the timed entry point on one batch."""
+    import torch
+    from cudasift_amd import capi
+    device = torch.device("cuda", 0)
+    B = int(os.environ.get("BENCH_PMC_FRAMES", "64"))
+    ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_options(quiet=1)
+    frames = gen_frames_torch(torch, B, 0, device)
+    scratch = torch.empty((B * capi.scratch_floats(W, H, NUM_OCTAVES, False),), dtype=torch.float32, device=device)
+    packed = torch.empty((B * MAX_PTS * 576,), dtype=torch.uint8, device=device)
+    cnts = torch.zeros((2 * B + 1,), dtype=torch.int32, device=device)
+    for _ in range(4):
+        capi.check(capi.lib().misift_extract_batch_packed_async(
+            ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), None,
+            MAX_PTS, cnts.data_ptr(), cnts[B:].data_ptr(), packed.data_ptr()), "misift_extract_batch_packed_async")
+        torch.cuda.synchronize()
+    ctx.close()
+
+
+def _parse_pmc_csv(path):
+    import collections
+    import csv
+    tot, n = collections.defaultdict(float), collections.Counter()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+            if k in KERNEL_NAMES:
+                tot[KERNEL_NAMES[k]] += float(r["Counter_Value"])
+                n[KERNEL_NAMES[k]] += 1
+    return tot, n
+
+
+def collect_pmc(frames_per_launch, gather_read_factor, timeout_s=240):
+    """Two separate rocprofv3 passes (FETCH_SIZE, WRITE_SIZE — they do not fit one pass, MI355X_MICROARCH.md) over a
+    4-step child run of the timed entry point.  Returns {kernel: {read, write, launches}} in BYTES PER STEP with the
+    guide's gfx950 correction (FETCH_SIZE in KB counts half the bytes of wide coalesced reads: x2; the scattered
+    8-byte gathers of the per-keypoint kernels use the factor calibrated by tools/pmc_calib), or (None, reason)."""
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_FRAMES=str(frames_per_launch))
+    env.pop("RANK", None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, p.returncode,
+                                                                       p.stdout.decode(errors="replace")[-300:])
+            tot, n = _parse_pmc_csv(files[0])
+            steps = 4.0
+            for k in tot:
+                e = res.setdefault(k, {"read": 0.0, "write": 0.0, "launches": 0})
+                if counter == "FETCH_SIZE":
+                    factor = gather_read_factor if k in GATHER_KERNELS else 2.0
+                    e["read"] = factor * tot[k] * 1024.0 / steps
+                    e["launches"] = n[k] / steps
+                else:
+                    e["write"] = tot[k] * 1024.0 / steps
+    except Exception as e:                                   # noqa: BLE001 — the bench line must still come out
+        return None, "PMC collection failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res, None
+
+
+# ------------------------------------------------------------------------------------------------ matcher leg
+class CabiMatchOps:
+    """Production ops of the matcher leg: device memory through torch, compute + collectives through the C-ABI
+    (misift_match_rows at N = 1; misift_match_sharded = set-2 all-gather + MFMA sweep + 12 B/row result all-gather
+    on RCCL at N > 1)."""
+
+    def __init__(self, torch, capi, ctx, comm, device, rank, world):
+        self.torch, self.capi, self.ctx, self.comm, self.device, self.rank, self.world = torch, capi, ctx, comm, device, rank, world
+
+    def to_device(self, recs):
+        import numpy as np
+        return self.torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(self.device)
+
+    def empty(self, nbytes):
+        return self.torch.zeros((max(nbytes, 16),), dtype=self.torch.uint8, device=self.device)
+
+    def match_step(self, rows1, nrows, shard2, nshard, set2_all, results_all):
+        capi = self.capi
+        if self.comm is None:
+            capi.check(capi.lib().misift_match_rows(self.ctx.h, rows1.data_ptr(), 0, nrows, shard2.data_ptr(), nshard),
+                       "misift_match_rows")
+        else:
+            self.comm.match_sharded(rows1.data_ptr(), nrows, shard2.data_ptr(), nshard, set2_all.data_ptr(),
+                                    results_all.data_ptr())
+
+    def to_host(self, t, count, dtype):
+        import numpy as np
+        return t[: count * np.dtype(dtype).itemsize].cpu().numpy().view(dtype).copy()
+
+    def barrier(self):
+        if self.comm is not None:
+            self.comm.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        import torch.distributed as dist
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def kernel_ms(self, fn):
+        self.ctx.profile_reset()
+        self.ctx.profile_enable(True)
+        fn()
+        mp = self.ctx.profile_read()
+        self.ctx.profile_enable(False)
+        return mp.get("match_mfma", {"total_ms": 0.0})["total_ms"]
+
+
+def matcher_leg(ops, rank, world, nm, msteps=3, validate_rows=100, l2=False, point_dtype=None, result_dtype=None,
+                oracle=None):
+    """BASELINE config 5: nm x nm x 128 brute force, set 1 split into row blocks (one per rank), set 2 sharded the
+    same way and replicated by one all-gather per step, the 12 B/row results all-gathered afterwards.  Descriptors
+    follow match.cu:945-957 (uniform, scaled by sqrt(128)/sum) from mt19937(12345) — or unit-L2 when `l2`.
+    `ops` supplies memory, the per-step call and the reductions (CabiMatchOps in production; the world-size-2 gloo
+    test drives this same function with the oracle standing in for the GPU).  Returns the result dict (rank 0 view)."""
+    import numpy as np
+    from synth import descriptors_to_points, synth_descriptors
+    nm = nm // (32 * world) * (32 * world)
+    rows = nm // world
+    # every rank generates the same two sets (0.3 s) and keeps its row block / shard
+    set1 = descriptors_to_points(synth_descriptors(nm, 12345, l2), point_dtype)
+    set2 = descriptors_to_points(synth_descriptors(nm, 12346, l2), point_dtype)
+    b = rank * rows
+    my1_host = set1[b:b + rows].copy()
+    rows1 = ops.to_device(my1_host)
+    shard2 = ops.to_device(set2[b:b + rows].copy())
+    set2_all = ops.empty(576 * nm) if world > 1 else ops.to_device(set2)
+    results_all = ops.empty(12 * nm) if world > 1 else None
+
+    def mstep():
+        if world > 1:
+            ops.match_step(rows1, rows, shard2, rows, set2_all, results_all)
+        else:
+            ops.match_step(rows1, rows, set2_all, nm, set2_all, None)
+    mstep()
+    ops.barrier()
+    t0 = time.perf_counter()
+    for _ in range(msteps):
+        mstep()
+    ops.barrier()
+    mdt = ops.max_over_ranks((time.perf_counter() - t0) / msteps)
+    kms = ops.kernel_ms(mstep)
+    flops = 2.0 * 128 * rows * nm
+    out = {"metric": "match Mpairs/s", "value": round(nm * float(nm) / mdt / 1e6, 1), "n1": nm, "n2": nm,
+           "ms": round(mdt * 1e3, 3), "split": "row-block x%d" % world,
+           "descriptors": ("unit-L2" if l2 else "match.cu:945-957 recipe (scaled by sqrt(128)/sum)") + ", mt19937(12345)",
+           "exchange": ("set-2 all-gather + 12 B/row result all-gather on RCCL (misift_match_sharded)" if world > 1
+                        else "none (one GPU)"),
+           "roofline": {"kernel": "match_mfma", "bound": "mfma",
+                        "achieved": round(flops / (kms * 1e-3) / 1e12, 2) if kms > 0 else None,
+                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(flops / (kms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if kms > 0 else None,
+                        "kernel_ms": round(kms, 3)}}
+    # ---- spot check against the oracle's sequential-FMA definition (orc_match_rows -> orc_dot128 chains): ~100 rows
+    # of this rank's block, score / index / ambiguity bit for bit; with N > 1 also the all-gathered 12-byte results
+    if oracle is not None and validate_rows > 0:
+        got = ops.to_host(rows1, rows, point_dtype)
+        pick = np.unique(np.linspace(0, rows - 1, validate_rows).astype(int))
+        ref = my1_host[pick].copy()
+        oracle.match_rows(ref, 0, len(pick), set2, nm)
+        for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+            if not np.array_equal(ref[f], got[f][pick]):
+                raise RuntimeError("matcher self-validation failed: field %s differs from the oracle" % f)
+        if world > 1:
+            res = ops.to_host(results_all, nm, result_dtype)
+            for f in ("score", "ambiguity", "match"):
+                if not np.array_equal(res[f][b + pick], ref[f]):
+                    raise RuntimeError("matcher self-validation failed: gathered result field %s" % f)
+        out["validated_rows"] = int(len(pick))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--batches", type=int, default=NUM_BATCHES, help="distinct batches per rank to rotate through")
     ap.add_argument("--match-n", type=int, default=100000)
     ap.add_argument("--no-match", action="store_true")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg AND the oracle self-validation")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU leg (0 = one per core, capped by RAM)")
     ap.add_argument("--unfused", action="store_true", help="separate laplace/detect kernels (DoG planes in HBM)")
-    ap.add_argument("--selftest-dist", action="store_true", help="single GPU: run the RCCL count all-gather / barrier path with world_size 1")
+    ap.add_argument("--selftest-dist", action="store_true", help="single GPU: run the RCCL gather path with a 1-rank communicator")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency side measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (H2D + extract + D2H) side measurement")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC traffic passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child()
 
     import numpy as np
     import torch                     # first: libmisift.so then binds to torch's HIP runtime
@@ -95,139 +322,149 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    elif args.selftest_dist:                                  # single GPU: exercise the RCCL path with one rank
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=0, world_size=1)
+        dist.init_process_group("nccl", rank=rank, world_size=world)       # rendezvous, barrier, time reduction only
 
-    B = args.frames_per_gpu
+    B, NB = args.frames_per_gpu, max(1, args.batches)
     stream = torch.cuda.current_stream()
     ctx = capi.Context(local_rank, stream.cuda_stream)
     ctx.set_options(quiet=1, fused=0 if args.unfused else 1)
 
-    # ---------------- inputs resident in HBM before the timed region
-    frames = gen_frames_torch(torch, B, rank * B, device)                   # [B,1080,1920], pitch 1920
+    # the data-path communicator lives behind the C-ABI (RCCL over xGMI): rank 0 makes the id, torch ships it
+    comm = None
+    if world > 1 or args.selftest_dist:
+        idt = torch.zeros((capi.COMM_ID_BYTES,), dtype=torch.uint8, device=device)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(idt, 0)
+        comm = capi.Comm(ctx, world, rank, bytes(idt.cpu().numpy().tobytes()))
+
+    # ---------------- inputs resident in HBM before the timed region: NB batches of B distinct frames per rank
+    frames = torch.empty((NB * B, H, W), dtype=torch.float32, device=device)
+    gen_frames_torch(torch, NB * B, rank * NB * B, device, out=frames)
     S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
     scratch = torch.empty((B * S,), dtype=torch.float32, device=device)
-    pts = torch.zeros((B * MAX_PTS * 576,), dtype=torch.uint8, device=device)
+    pts = torch.zeros((B * MAX_PTS * 576,), dtype=torch.uint8, device=device) if args.unfused else None
     counts = (C.c_int * B)()
     torch.cuda.synchronize()
 
-    from cudasift_amd.dist import RecordGather
-
     # Software-pipelined step loop, the same for every N: batch k is extracted AND packed on the device
-    # (misift_extract_batch_packed_async, nothing synchronises), then the host completes batch k-1: reads its
+    # (misift_extract_batch_packed_async, nothing synchronises), then the host completes batch k-LAG: reads its
     # per-frame counts back and — with more than one GPU — gathers the packed SiftPoint records of all ranks on
-    # rank 0 over RCCL/xGMI on a communication stream (BASELINE config 4), overlapping batch k's extraction.
-    # Every batch's read-back/gather completes before the closing barrier: nothing is skipped, only overlapped.
-    NSLOT, LAG = 3, 2          # batch k-2 is completed after batch k was queued: the GPU never waits for the host
-    packed = [torch.empty((B * MAX_PTS * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
+    # rank 0 (misift_gather_post / misift_gather_complete on the communicator's own stream), overlapping the
+    # extraction of the batches queued behind it.  Every batch's read-back/gather completes before the closing
+    # barrier: nothing is skipped, only overlapped.
+    NSLOT, LAG = 3, 2
+    REC_CAP = MAX_PTS                   # mainSift.cpp:58-67 capacity (32768 records per frame)
+    packed = [torch.empty((B * REC_CAP * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
     cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(NSLOT)]
-    gather = RecordGather(dist, torch, rank, world, device, dst=0, nslots=NSLOT,
-                          force_collectives=args.selftest_dist)
-    torch.cuda.synchronize()
+    done_ev = [None] * NSLOT
+    recv = torch.empty((world * B * REC_CAP * 576,), dtype=torch.uint8, device=device) if (comm and rank == 0) else None
+    rb_stream = torch.cuda.Stream(device=device, priority=-1)
+    step_ev = []
 
     def enqueue(k):
         slot = k % NSLOT
-        fe = gather.free_event(slot)
-        if fe is not None:
-            torch.cuda.current_stream().wait_event(fe)          # slot's previous transfer has left the buffers
+        b0 = (k % NB) * B
         capi.check(capi.lib().misift_extract_batch_packed_async(
-            ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(),
+            ctx.h, frames[b0].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(),
             pts.data_ptr() if args.unfused else None,      # merged-octave path writes the packed array directly
-            MAX_PTS, cnts[slot].data_ptr(), cnts[slot][B:].data_ptr(), packed[slot].data_ptr()),
+            REC_CAP, cnts[slot].data_ptr(), cnts[slot][B:].data_ptr(), packed[slot].data_ptr()),
             "misift_extract_batch_packed_async")
-        ev = torch.cuda.Event()
-        ev.record()
-        gather.post(slot, cnts[slot][:B], packed[slot], ev)
+        if comm is not None:
+            comm.gather_post(slot, cnts[slot].data_ptr(), B, packed[slot].data_ptr())
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            done_ev[slot] = ev
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        step_ev.append(e)
 
-    trace = [] if os.environ.get("BENCH_TRACE") else None
+    def complete(k):
+        slot = k % NSLOT
+        if comm is not None:
+            c, _ = comm.gather_complete(slot, B, 0, recv.data_ptr() if recv is not None else None, world * B * REC_CAP)
+            return c
+        with torch.cuda.stream(rb_stream):                  # count read-back beside the running extraction
+            rb_stream.wait_event(done_ev[slot])
+            c = cnts[slot][:B].cpu().numpy()
+        return c[None, :]
 
-    def run(nsteps):
-        res = None
-        for k in range(nsteps):
+    def run(k0, nsteps):
+        last = None
+        for k in range(k0, k0 + nsteps):
             enqueue(k)
-            if trace is not None:
-                trace.append(("enq", k, time.perf_counter()))
-            if k >= LAG:
-                res = gather.complete((k - LAG) % NSLOT)
-                if trace is not None:
-                    trace.append(("done", k - LAG, time.perf_counter()))
-        for k in range(max(0, nsteps - LAG), nsteps):
-            res = gather.complete(k % NSLOT)
-            if trace is not None:
-                trace.append(("done", k, time.perf_counter()))
-        all_counts = res[0]
-        if (all_counts < 0).any():
+            if k - k0 >= LAG:
+                last = complete(k - LAG)
+                if (last < 0).any():
+                    raise RuntimeError("candidate list overflow in the bench workload")
+        for k in range(max(k0, k0 + nsteps - LAG), k0 + nsteps):
+            last = complete(k)
+        if (last < 0).any():
             raise RuntimeError("candidate list overflow in the bench workload")
-        return all_counts
+        return last
 
     def barrier():
-        if world > 1 or args.selftest_dist:
+        if comm is not None:
+            comm.barrier()
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     if args.warmup > 0:
-        run(args.warmup)
+        run(0, args.warmup)
     barrier()
+    step_ev.clear()
     t0 = time.perf_counter()
-    all_counts = run(args.steps)
+    all_counts = run(args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if trace is not None and rank == 0:
-        for kind, k, t in trace[-(3 * args.steps):]:
-            if t >= t0:
-                print("trace %-4s %3d %8.3f ms" % (kind, k, 1e3 * (t - t0)), file=sys.stderr)
-        print("trace end %8.3f ms" % (1e3 * dt), file=sys.stderr)
-    n = all_counts[rank if world > 1 else 0]
-    kp_per_frame = float(np.mean(n))
+    last_k = args.warmup + args.steps - 1
+    kp_per_frame = float(np.mean(all_counts[rank if all_counts.shape[0] > 1 else 0]))
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = 1e3 * dt / args.steps
     fps = world * B * args.steps / dt
+    # distribution of the pipelined loop's steps on the GPU timeline (median + p10/p90)
+    step_ms = None
+    if rank == 0 and len(step_ev) >= 3:
+        d = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(len(step_ev) - 1)])
+        step_ms = {"p10": round(float(np.percentile(d, 10)), 4), "p50": round(float(np.percentile(d, 50)), 4),
+                   "p90": round(float(np.percentile(d, 90)), 4), "samples": int(len(d)),
+                   "note": "HIP-event interval between consecutive steps of the timed, pipelined loop"}
 
-    # ---------------- distribution of the synchronous step (median + p10/p90), same workload, one
-    # misift_extract_batch call incl. its count read-back per sample
-    dist_ms = None
-    if rank == 0:
-        ts = []
-        for _ in range(40):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            capi.check(capi.lib().misift_extract_batch(ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
-                                                       INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
-                                                       MAX_PTS, counts), "misift_extract_batch")
-            ts.append(1e3 * (time.perf_counter() - t1))
-        ts = np.sort(np.array(ts[8:]))
-        dist_ms = {"p10": round(float(np.percentile(ts, 10)), 4), "p50": round(float(np.percentile(ts, 50)), 4),
-                   "p90": round(float(np.percentile(ts, 90)), 4), "samples": int(len(ts)),
-                   "note": "synchronous misift_extract_batch of the same 64-frame batch (no pipelining)"}
+    # ---------------- the timed loop's LAST step, kept for the self-validation below
+    last_slot, last_b0 = last_k % NSLOT, (last_k % NB) * B
+    last_cnt = cnts[last_slot].cpu().numpy().copy()
+    last_counts, last_offs = last_cnt[:B], last_cnt[B:]
+    last_recs = packed[last_slot][: int(last_offs[B]) * 576].cpu().numpy().view(capi.POINT_DTYPE).copy()
 
     # ---------------- per-kernel durations (HIP events on the launch stream) for the roofline
+    if pts is None:
+        pts = torch.zeros((B * MAX_PTS * 576,), dtype=torch.uint8, device=device)
     ctx.profile_reset()
     ctx.profile_enable(True)
-    psteps = max(2, min(args.steps, 5))
-    for _ in range(psteps):
-        capi.check(capi.lib().misift_extract_batch(ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
+    psteps = 5
+    for i in range(psteps):
+        capi.check(capi.lib().misift_extract_batch(ctx.h, frames[(i % NB) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
                                                    INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
                                                    MAX_PTS, counts), "misift_extract_batch")
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     alg = algorithmic_bytes_per_frame()
+    N = octave_pixels(W, H, NUM_OCTAVES)
     if "lowpass_down" in prof:
         # fused prefilter + first ScaleDown: its algorithmic bytes are the sum of the two reference kernels' figures
         # (LowPass 8*N0 + ScaleDown_1 4*N0 + 4*N1); the remaining ScaleDown launches cover levels 2..
-        N = octave_pixels(W, H, NUM_OCTAVES)
         alg["lowpass_down"] = 8 * N[0] + 4 * N[0] + 4 * N[1]
         alg["scaledown"] = sum(4 * N[i] + 4 * N[i + 1] for i in range(1, NUM_OCTAVES - 1))
     kernels = {}
@@ -237,47 +474,83 @@ def main():
         if name in alg:
             e["alg_GBps"] = round(alg[name] * B / (per_step_ms * 1e-3) / 1e9, 1)
         kernels[name] = e
-    dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k]["ms_per_step"])
+
+    # ---------------- live PMC traffic (rank 0, N = 1): two rocprofv3 passes over a child run of the same entry point
+    pmc, pmc_note = None, "not collected (N > 1 or --no-pmc)"
+    calib = {"gather_read_factor": 2.0, "source": "uncalibrated: the guide's x2 for wide coalesced reads applied to the gathers too"}
+    cj = os.path.join(ROOT, "profiles", "r02_pmc_calibration.json")
+    if os.path.exists(cj):
+        try:
+            cc = json.load(open(cj))
+            calib = {"gather_read_factor": float(cc["gather_read_factor"]), "source": "profiles/r02_pmc_calibration.json (tools/pmc_calib)"}
+        except Exception:
+            pass
+    if rank == 0 and world == 1 and not args.no_pmc:
+        torch.cuda.synchronize()
+        pmc, pmc_note = collect_pmc(B, calib["gather_read_factor"])
+        if pmc is not None:
+            pmc_note = ("collected live in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) "
+                        "over 4 steps of the timed entry point; read = 2 x FETCH_SIZE KB (gfx950 correction for wide "
+                        "coalesced reads; gather kernels x%.2f, see pmc_calibration), write = WRITE_SIZE KB"
+                        % calib["gather_read_factor"])
+            for k, e in pmc.items():
+                if k in kernels:
+                    kernels[k]["traffic_MB_per_frame"] = round((e["read"] + e["write"]) / B / 1e6, 3)
+                    kernels[k]["read_MB_per_frame"] = round(e["read"] / B / 1e6, 3)
+
+    # ---------------- roofline of the dominant kernel: dog_scan is fp32-VALU-bound (its 60 B/px of algorithmic
+    # traffic never reach HBM), so its roof is the vector peak and the fraction is <= 1 by construction
+    dom = "dog_scan" if "dog_scan" in kernels else max((k for k in kernels if k in alg), key=lambda k: kernels[k]["ms_per_step"])
     dom_ms = kernels[dom]["ms_per_step"]
     dom_launches = max(1, kernels[dom]["launches_per_step"])
-    achieved = alg[dom] * B / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tj):                       # bytes per frame per kernel from the committed rocprofv3 PMC passes
-        try:
-            t = json.load(open(tj))
-            if dom in t.get("bytes_per_frame", {}):
-                traffic = int(t["bytes_per_frame"][dom] * B / dom_launches)
-        except Exception:
-            traffic = None
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: "
-                                "2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), not collected live",
-                "alg_bytes_per_launch": int(alg[dom] * B / dom_launches),
-                "avg_launch_ms": round(dom_ms / dom_launches, 4),
-                "pipeline_alg_GBps": round(197.2e6 * fps / world / 1e9, 1),
-                "pipeline_frac": round(197.2e6 * fps / world / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "dog_scan fuses LaplaceMulti+FindPointsMulti: its algorithmic bytes (60 B/px, SURVEY 8d) never "
-                        "reach HBM (see traffic), so achieved > peak is possible; the kernel itself is fp32-VALU-bound"}
-    # the genuinely HBM-bound kernels, same definition (algorithmic bytes / summed launch time)
+    if dom == "dog_scan":
+        fpp = dog_scan_flop_per_px()
+        flops_step = float(fpp) * sum(N) * B
+        ach = flops_step / (dom_ms * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "valu", "achieved": round(ach, 2), "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(min(ach / VALU_F32_PEAK_TF, 1.0), 4),
+                    "flop_per_px": fpp, "flop_per_launch": int(flops_step / dom_launches),
+                    "flop_note": "6 blurs x (9 vertical + 13 horizontal) + 4 shared pair sums + 5 DoG + 5 |v|max; "
+                                 "algorithmic flops only (halo lanes, DPP moves, selects and the extremum tests are overhead)",
+                    "alg_GBps": kernels[dom].get("alg_GBps"),
+                    "alg_note": "60 B/px of LaplaceMulti + FindPointsMulti traffic (SURVEY 8d) that the fused kernel never moves; "
+                                "not a fraction of anything"}
+    else:
+        ach = alg[dom] * B / (dom_ms * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(min(ach / HBM_PEAK_GBS, 1.0), 4)}
+    roofline["avg_launch_ms"] = round(dom_ms / dom_launches, 4)
+    roofline["launches_per_step"] = dom_launches
+    roofline["traffic"] = int((pmc[dom]["read"] + pmc[dom]["write"]) / dom_launches) if pmc and dom in pmc else None
+    roofline["traffic_note"] = pmc_note
+    roofline["pmc_calibration"] = calib
+    # the genuinely HBM-bound kernels: algorithmic bytes AND bytes actually moved, each over the summed launch time
     hbm_kernels = {}
-    tbytes = {}
-    if os.path.exists(tj):
-        try:
-            tbytes = json.load(open(tj)).get("bytes_per_frame", {})
-        except Exception:
-            tbytes = {}
     split = kernels.get("dog_scan", {}).get("launches_per_step", 1) > 1
     for k in ("lowpass", "lowpass_down", "scaledown"):
         if k == "scaledown" and split:
             continue      # runs beside the fine-level scan on a second stream: its duration says nothing about HBM
         if k in kernels:
             a = alg[k] * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
-            hbm_kernels[k] = {"achieved": round(a, 1), "frac": round(a / HBM_PEAK_GBS, 4)}
-            if k in tbytes:          # bytes actually moved (PMC): the fused prefilter never re-reads the finest level
-                hbm_kernels[k]["traffic_GBps"] = round(tbytes[k] * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e9, 1)
+            hbm_kernels[k] = {"alg_GBps": round(a, 1), "alg_frac": round(a / HBM_PEAK_GBS, 4)}
+            if pmc and k in pmc:
+                t = (pmc[k]["read"] + pmc[k]["write"]) / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
+                hbm_kernels[k]["traffic_GBps"] = round(t, 1)
+                hbm_kernels[k]["traffic_frac"] = round(t / HBM_PEAK_GBS, 4)
     roofline["hbm_bound_kernels"] = hbm_kernels
+    pipe_rf = {"alg_bytes_per_frame": int(ALG_BYTES_PER_FRAME),
+               "alg_GBps": round(ALG_BYTES_PER_FRAME * fps / world / 1e9, 1),
+               "floor_bytes_per_frame": int(FLOOR_BYTES_PER_FRAME),
+               "floor_frac": round(FLOOR_BYTES_PER_FRAME * fps / world / 1e9 / HBM_PEAK_GBS, 4),
+               "note": "floor = input + pyramid written once + read once by the scan + records; traffic = PMC bytes of all "
+                       "kernels of a step; both x frames/s / 8 TB/s.  The algorithmic figure (197.2 MB/frame, SURVEY 8d) "
+                       "is mostly traffic the fused design avoids, so it is reported as a rate only"}
+    if pmc:
+        tb = sum(e["read"] + e["write"] for e in pmc.values()) / B
+        pipe_rf["traffic_bytes_per_frame"] = int(tb)
+        pipe_rf["traffic_frac"] = round(tb * fps / world / 1e9 / HBM_PEAK_GBS, 4)
+        pipe_rf["traffic_over_floor"] = round(tb / FLOOR_BYTES_PER_FRAME, 3)
+    roofline["pipeline"] = pipe_rf
     # achievable-copy ceiling: device-to-device copy of 1 GiB, read + write bytes counted
     if rank == 0:
         a = torch.empty(1 << 28, dtype=torch.float32, device=device)
@@ -293,9 +566,6 @@ def main():
         copy_gbs = 2.0 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
         roofline["copy_ceiling_GBps"] = round(copy_gbs, 1)
-        for k in hbm_kernels:
-            if "traffic_GBps" in hbm_kernels[k]:
-                hbm_kernels[k]["traffic_frac_of_copy_ceiling"] = round(hbm_kernels[k]["traffic_GBps"] / copy_gbs, 4)
 
     # ---------------- single-frame latencies (BASELINE configs 2 and 3; reported, never `value`)
     latency = None
@@ -328,22 +598,20 @@ def main():
     # ---------------- PCIe-inclusive side measurement (never `value`): pinned host frames -> H2D -> extract -> D2H
     pcie = None
     if rank == 0 and world == 1 and not args.no_pcie:
-        # host-fed pipeline (misift_pipe_*): pinned host frames -> H2D | extraction | packed records -> D2H on three
-        # streams, 3 batches in flight; fp32 frames (what the reference uploads) and 8-bit frames
         torch.cuda.synchronize()
         nb, nbatches = 16, 12
         pcie = {"batch_frames": nb, "batches": nbatches, "depth": 3,
                 "note": "misift_pipe: pinned host frames uploaded, valid SiftPoint records packed and downloaded, "
                         "upload/compute/read-back overlapped; never `value`"}
         host_recs = capi.PinnedArray((nb * 4096,), capi.POINT_DTYPE)
-        for key, dt in (("frames_per_s_u8", np.uint8), ("frames_per_s_f32", np.float32)):
-            src = capi.PinnedArray((nb, H, W), dt)
+        for key, dtp in (("frames_per_s_u8", np.uint8), ("frames_per_s_f32", np.float32)):
+            src = capi.PinnedArray((nb, H, W), dtp)
             f = frames[:nb].round().clamp(0, 255)
-            src.array[...] = f.cpu().numpy().astype(dt)
-            pipe = capi.Pipe(ctx, W, H, nb, src_u8=(dt == np.uint8), num_octaves=NUM_OCTAVES, init_blur=INIT_BLUR,
+            src.array[...] = f.cpu().numpy().astype(dtp)
+            pipe = capi.Pipe(ctx, W, H, nb, src_u8=(dtp == np.uint8), num_octaves=NUM_OCTAVES, init_blur=INIT_BLUR,
                              thresh=THRESH, max_pts=MAX_PTS, depth=3)
 
-            def run(k):
+            def prun(k):
                 tot = 0
                 for i in range(k):
                     if pipe.pending() == 3:
@@ -352,128 +620,112 @@ def main():
                 while pipe.pending():
                     tot += pipe.collect(host_recs.ptr, nb * 4096)[1]
                 return tot
-            run(3)
-            t0 = time.perf_counter()
-            tot = run(nbatches)
-            pdt = time.perf_counter() - t0
+            prun(3)
+            tp0 = time.perf_counter()
+            tot = prun(nbatches)
+            pdt = time.perf_counter() - tp0
             pcie[key] = round(nb * nbatches / pdt, 1)
             pcie["records_per_frame"] = round(tot / (nb * nbatches), 1)
             pipe.close()
             src.free()
         host_recs.free()
 
-    # ---------------- matcher: n x n x 128 brute force on fp32 MFMA, row-block split over ranks
+    # ---------------- matcher (BASELINE config 5)
     match = None
-    if not args.no_match:
-        nm = args.match_n // (32 * world) * (32 * world)
-        rows = nm // world
-        rec = np.dtype(capi.POINT_DTYPE)
-        gm = torch.Generator(device=device)
-        gm.manual_seed(12345 + rank)
-
-        def make_set(n):
-            t = torch.zeros((n, 144), dtype=torch.float32, device=device)
-            d = torch.rand((n, 128), generator=gm, device=device, dtype=torch.float32)
-            t[:, 16:] = d * (128.0 ** 0.5 / d.sum(dim=1, keepdim=True))       # match.cu:945-957 recipe
-            return t
-        set1 = make_set(nm) if world == 1 else None
-        shard2 = make_set(rows)
-        if world == 1:
-            set2 = shard2
-            my1 = set1
-            row0 = 0
-        else:
-            my1 = make_set(rows)          # this rank's row block of set 1 (rows [rank*rows, ...))
-            set2 = torch.empty((nm, 144), dtype=torch.float32, device=device)
-            row0 = 0
-        torch.cuda.synchronize()
-
-        def mstep():
-            if world > 1:
-                dist.all_gather_into_tensor(set2, shard2)                     # set-2 descriptors over xGMI
-            capi.check(capi.lib().misift_match_rows(ctx.h, my1.data_ptr(), row0, rows, set2.data_ptr(), nm),
-                       "misift_match_rows")
-        mstep()
-        barrier()
-        msteps = 3
-        t0 = time.perf_counter()
-        for _ in range(msteps):
-            mstep()
-        barrier()
-        mdt = (time.perf_counter() - t0) / msteps
-        if world > 1:
-            tmax = torch.tensor([mdt], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            mdt = float(tmax.item())
-        ctx.profile_reset()
-        ctx.profile_enable(True)
-        mstep()
-        mp = ctx.profile_read()
-        ctx.profile_enable(False)
-        kms = mp.get("match_mfma", {"total_ms": 0.0})["total_ms"]
-        flops = 2.0 * 128 * rows * nm
-        match = {"metric": "match Mpairs/s", "value": round(nm * float(nm) / mdt / 1e6, 1), "n1": nm, "n2": nm,
-                 "ms": round(mdt * 1e3, 3), "split": "row-block x%d" % world,
-                 "roofline": {"kernel": "match_mfma", "bound": "mfma",
-                              "achieved": round(flops / (kms * 1e-3) / 1e12, 2) if kms > 0 else None,
-                              "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": round(flops / (kms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if kms > 0 else None,
-                              "kernel_ms": round(kms, 3)}}
-
-    # ---------------- CPU baseline (rank 0, N = 1 only): the oracle port on a bounded sample
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    orc = None
+    if not args.no_cpu and rank == 0:
         from oracle import pyoracle as orc
-        host = frames[:args.cpu_frames].cpu().numpy()
-        orc.extract(host[0], NUM_OCTAVES, INIT_BLUR, THRESH)      # warm-up (page-in, OpenMP pool)
-        t0 = time.perf_counter()
-        tot = 0
-        for f in range(args.cpu_frames):
-            _, nn, _ = orc.extract(host[f], NUM_OCTAVES, INIT_BLUR, THRESH)
-            tot += nn
-        cdt = time.perf_counter() - t0
-        cpu = {"value": round(args.cpu_frames / cdt, 3), "unit": "frames/s", "cores": os.cpu_count(),
-               "kind": "port",
-               "sample": "%d of the same synthetic 1920x1080 frames, oracle/sift_oracle.c with OpenMP "
-                         "(OpenCV cv::SIFT is not installed on this image)" % args.cpu_frames,
-               "keypoints_per_frame": round(tot / args.cpu_frames, 1)}
+    if not args.no_match:
+        ops = CabiMatchOps(torch, capi, ctx, comm if world > 1 else None, device, rank, world)
+        match = matcher_leg(ops, rank, world, args.match_n, msteps=3, validate_rows=100, l2=False,
+                            point_dtype=capi.POINT_DTYPE, result_dtype=capi.RESULT_DTYPE, oracle=orc)
+        m2 = matcher_leg(ops, rank, world, args.match_n, msteps=2, validate_rows=0, l2=True,
+                         point_dtype=capi.POINT_DTYPE, result_dtype=capi.RESULT_DTYPE, oracle=None)
+        match["unit_l2_variant"] = {"value": m2["value"], "ms": m2["ms"], "frac": m2["roofline"]["frac"]}
 
-        # matcher CPU baseline: the reference's OWN AVX2/OpenMP routine MatchC3 (match.cu:102-130, built from the
-        # reference tree into oracle/_ref by oracle/build_ref.sh) on its own 16384 x 16384 problem
-        L = orc.ref_lib(16384)
-        if L is not None and match is not None:
-            a = orc.aligned_f32(16384 * 128); b = orc.aligned_f32(16384 * 128)
-            sc = orc.aligned_f32(16384); ix = np.zeros(16384, np.int32)
-            L.ref_generate(a.ctypes.data, b.ctypes.data, 1)
-            L.ref_match_c3(a.ctypes.data, b.ctypes.data, sc.ctypes.data, ix.ctypes.data)     # warm-up
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                L.ref_match_c3(a.ctypes.data, b.ctypes.data, sc.ctypes.data, ix.ctypes.data)
-            mdt = (time.perf_counter() - t0) / reps
-            match["cpu_baseline"] = {"value": round(16384.0 * 16384.0 / mdt / 1e6, 1), "unit": "Mpairs/s",
-                                     "cores": os.cpu_count(), "kind": "reference",
-                                     "sample": "reference MatchC3 (AVX2+FMA, OpenMP; argmax only, no runner-up) on "
-                                               "16384 x 16384 x 128, its own generator"}
+    # ---------------- self-validation of the TIMED loop's last step + CPU baseline (rank 0, N = 1 baseline only)
+    cpu, validated = None, None
+    if rank == 0 and orc is not None:
+        from util import compare_points
+        cores = os.cpu_count() or 1
+        ncpu = args.cpu_frames
+        if ncpu <= 0:
+            try:
+                import psutil
+                avail = psutil.virtual_memory().available
+            except Exception:
+                avail = 16 << 30
+            ncpu = int(max(8, min(cores, 256, NB * B, avail // 2 // (260 << 20))))      # ~260 MB of oracle scratch per frame
+        ncpu = min(ncpu, NB * B)
+        # frames of the last timed batch first (they are validated), then the following ones
+        order = [(last_b0 + i) % (NB * B) for i in range(ncpu)]
+        host = frames[order].cpu().numpy()
+        outer = min(ncpu, cores)
+        inner = max(1, cores // outer)
+        orc.extract_batch(host[:min(ncpu, outer)], NUM_OCTAVES, INIT_BLUR, THRESH, max_pts=8192, outer_threads=outer,
+                          inner_threads=inner)                                           # warm-up (page-in, OpenMP pools)
+        tc0 = time.perf_counter()
+        ref, nref, cref = orc.extract_batch(host, NUM_OCTAVES, INIT_BLUR, THRESH, max_pts=8192, outer_threads=outer,
+                                            inner_threads=inner)
+        cdt = time.perf_counter() - tc0
+        nval = min(ncpu, B)
+        for f in range(nval):
+            got = last_recs[last_offs[f]:last_offs[f + 1]]
+            if int(nref[f]) != int(last_counts[f]) or len(got) != int(nref[f]):
+                raise RuntimeError("self-validation failed: frame %d of the last timed step has %d records, oracle %d"
+                                   % (f, int(last_counts[f]), int(nref[f])))
+            compare_points(ref[f, :nref[f]], got, "bench_validate_f%d" % f)              # raises AssertionError on mismatch
+        validated = nval
+        if world == 1:
+            cpu = {"value": round(ncpu / cdt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+                   "threads": "%d frames in parallel x %d threads each" % (outer, inner),
+                   "sample": "%d of the same synthetic 1920x1080 frames (%.1f s), oracle/sift_oracle.c: one frame per OpenMP "
+                             "thread + OpenMP inside every stage (OpenCV cv::SIFT is not installed on this image)" % (ncpu, cdt),
+                   "keypoints_per_frame": round(float(np.mean(nref)), 1)}
+            # matcher CPU baseline: the reference's OWN AVX2/OpenMP routine MatchC3 (match.cu:102-130, built from the
+            # reference tree into oracle/_ref by oracle/build_ref.sh) on its own 16384 x 16384 problem
+            L = orc.ref_lib(16384)
+            if L is not None and match is not None:
+                a = orc.aligned_f32(16384 * 128); b = orc.aligned_f32(16384 * 128)
+                sc = orc.aligned_f32(16384); ix = np.zeros(16384, np.int32)
+                L.ref_generate(a.ctypes.data, b.ctypes.data, 1)
+                L.ref_match_c3(a.ctypes.data, b.ctypes.data, sc.ctypes.data, ix.ctypes.data)     # warm-up
+                tm0 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    L.ref_match_c3(a.ctypes.data, b.ctypes.data, sc.ctypes.data, ix.ctypes.data)
+                mdt = (time.perf_counter() - tm0) / reps
+                match["cpu_baseline"] = {"value": round(16384.0 * 16384.0 / mdt / 1e6, 1), "unit": "Mpairs/s",
+                                         "cores": cores, "kind": "reference",
+                                         "sample": "reference MatchC3 (AVX2+FMA, OpenMP; argmax only, no runner-up) on "
+                                                   "16384 x 16384 x 128, its own generator"}
 
     if rank == 0:
         out = {"metric": "1920x1080 SIFT frames/sec", "value": round(fps, 1), "unit": "frames/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
-               "config": {"workload": "batch of %d synthetic 1920x1080 frames per GPU (BASELINE config 4: 512 "
-                                      "frames over 8 GPUs), ExtractSift 5 octaves initBlur 1.0 thresh 3.0 "
-                                      "maxPts 32768, frames resident in HBM, count read-back%s" %
-                                      (B, " + RCCL gather of SiftData to rank 0" if world > 1 else ""),
-                          "frames_per_gpu": B, "path": "unfused" if args.unfused else "fused dog+detect",
+               "config": {"workload": "batches of %d synthetic 1920x1080 frames per GPU, %d distinct batches per GPU rotated "
+                                      "(%d distinct frames per GPU; BASELINE config 4: 512 frames over 8 GPUs), ExtractSift "
+                                      "5 octaves initBlur 1.0 thresh 3.0 maxPts 32768, frames resident in HBM, count read-back%s"
+                                      % (B, NB, NB * B, " + RCCL gather of SiftData to rank 0 (misift_gather_*)" if comm else ""),
+                          "frames_per_gpu": B, "distinct_frames_per_gpu": NB * B,
+                          "path": "unfused" if args.unfused else "fused dog+detect",
                           "keypoints_per_frame": round(kp_per_frame, 1)},
-               "roofline": roofline, "kernels": kernels, "match": match, "cpu_baseline": cpu, "pcie_inclusive": pcie, "single_frame": latency,
-               "sync_step_ms": dist_ms,
-               "kernels_note": "dog_scan runs as two launches per step (fine levels on the context stream, the coarse "
-                               "ScaleDowns + coarse levels beside it on a second stream): their durations overlap, so "
-                               "the per-kernel times add up to more than the step"}
+               "validated_frames": validated,
+               "validation": ("frames 0..%d of the LAST timed step: counts and every record equal to the oracle (tests/util.py "
+                              "compare_points: identical keypoint set, 1e-4 fields, descriptor cosine >= 1-1e-6)" % (validated - 1))
+               if validated else "skipped (--no-cpu)",
+               "roofline": roofline, "kernels": kernels, "step_ms": step_ms, "match": match, "cpu_baseline": cpu,
+               "pcie_inclusive": pcie, "single_frame": latency,
+               "kernels_note": "per-kernel times are HIP-event durations on the launch stream from 5 profiled synchronous "
+                               "steps; dog_scan runs as two launches per step (fine levels on the context stream, the coarse "
+                               "ScaleDowns + coarse levels beside it on a second stream) whose durations overlap, so the "
+                               "per-kernel times add up to more than the step"}
         print(json.dumps(out))
-    if world > 1 or args.selftest_dist:
+    if comm is not None:
+        comm.close()
+    if world > 1:
         dist.destroy_process_group()
     ctx.close()
 

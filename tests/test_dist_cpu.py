@@ -152,3 +152,86 @@ def test_pipelined_record_gather_world3_with_silent_rank(tmp_path):
     port = _free_port()
     mp.spawn(_pipe_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     assert all(open(tmp_path / ("pok%d" % r)).read() == "1" for r in range(3))
+
+
+# ------------------------------------------------------------------ bench.py's N > 1 matcher branch under gloo
+class _GlooOracleOps:
+    """Stands in for bench.CabiMatchOps on a machine without GPUs: memory = numpy arrays, the per-step call does what
+    misift_match_sharded does (all-gather of the set-2 shards, row-block sweep, all-gather of the 12 B/row results)
+    with gloo collectives and the CPU oracle as the matcher."""
+
+    def __init__(self, dist, torch, orc, rank, world):
+        self.dist, self.torch, self.orc, self.rank, self.world = dist, torch, orc, rank, world
+
+    def to_device(self, recs):
+        return recs.copy()
+
+    def empty(self, nbytes):
+        return np.zeros(nbytes, np.uint8)
+
+    def match_step(self, rows1, nrows, shard2, nshard, set2_all, results_all):
+        from bench import RESULT_DTYPE_NP as RD
+        t, dist = self.torch, self.dist
+        if self.world == 1:
+            self.orc.match_rows(rows1, 0, nrows, shard2, nshard)
+            return
+        parts = [t.empty((nshard * 576,), dtype=t.uint8) for _ in range(self.world)]
+        dist.all_gather(parts, t.from_numpy(shard2.view(np.uint8).reshape(-1)))
+        set2_all[:] = t.cat(parts).numpy()
+        full = set2_all.view(self.orc.POINT_DTYPE)
+        self.orc.match_rows(rows1, 0, nrows, full, nshard * self.world)
+        mine = np.zeros(nrows, RD)
+        for f in ("score", "ambiguity", "match"):
+            mine[f] = rows1[f]
+        outs = [t.empty((nrows * 12,), dtype=t.uint8) for _ in range(self.world)]
+        dist.all_gather(outs, t.from_numpy(mine.view(np.uint8).reshape(-1)))
+        results_all[:] = t.cat(outs).numpy()
+
+    def to_host(self, a, count, dtype):
+        return a.view(np.uint8)[: count * np.dtype(dtype).itemsize].view(dtype).copy()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        v = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
+        return float(v.item())
+
+    def kernel_ms(self, fn):
+        import time
+        t0 = time.perf_counter()
+        fn()
+        return 1e3 * (time.perf_counter() - t0)
+
+
+def _bench_match_worker(rank, world, port, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from oracle import pyoracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops = _GlooOracleOps(dist, torch, orc, rank, world)
+    res = bench.matcher_leg(ops, rank, world, 640, msteps=1, validate_rows=25, l2=(rank < 0), point_dtype=orc.POINT_DTYPE,
+                            result_dtype=bench.RESULT_DTYPE_NP, oracle=orc)
+    ok = res["n1"] == 640 and res["validated_rows"] >= 20 and res["split"] == "row-block x%d" % world and res["value"] > 0
+    open(os.path.join(out_dir, "bok%d" % rank), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_bench_matcher_branch_world2_gloo_oracle(tmp_path):
+    """bench.py's N > 1 matcher leg (row blocks, set-2 shards, gathered 12-byte results, per-rank spot check against
+    the sequential-FMA oracle, max-over-ranks timing) executed with world_size 2 — gloo + the oracle standing in for
+    the RCCL / MFMA calls of the C-ABI."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_bench_match_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "bok0").read() == "1" and open(tmp_path / "bok1").read() == "1"
