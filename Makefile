@@ -13,7 +13,7 @@ HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_
             $(CSRC)/multigpu.hip
 HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
-all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle dropin build/pmc_calib
+all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle dropin build/pmc_calib build/valu_rates
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
 	@mkdir -p $(BUILD)
@@ -27,6 +27,11 @@ cudasift_amd/libcudasift.so: $(CSRC)/shim_cudasift.cpp include/cudaSift.h includ
 
 # FETCH_SIZE calibration kernels (tools/pmc_calib.py runs them under rocprofv3 on the GPU box)
 build/pmc_calib: tools/pmc_calib.hip
+	@mkdir -p $(BUILD)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
+
+# instruction issue-cost microbenchmark (what the VALU-bound kernels are priced against)
+build/valu_rates: tools/valu_rates.hip
 	@mkdir -p $(BUILD)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
 

@@ -89,6 +89,7 @@ SIGNATURES = {
     "misift_extract_batch_packed_async": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "misift_lowpass_scaledown": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f, _vp, _i]),
     "misift_extract_batch_u8": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _ip]),
+    "misift_extract_batch_ex": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _i, _vp, _vp, _i, _ip]),
     "misift_pipe_create": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, C.POINTER(_vp)]),
     "misift_pipe_destroy": (None, [_vp]),
     "misift_pipe_submit": (_i, [_vp, _vp, _i]),
@@ -366,6 +367,21 @@ class Context:
         n = (C.c_int * B)()
         check(lib().misift_extract_batch(self.h, d.ptr, B, h * p, w, h, p, num_octaves, init_blur, thresh,
                                          lowest_scale, sc.ptr, pts.ptr, max_pts, n), "misift_extract_batch")
+        return self.download(pts, (B, max_pts), POINT_DTYPE), np.array(list(n), np.int32)
+
+    def extract_batch_ex(self, imgs, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, scale_up=False,
+                         max_pts=32768):
+        """imgs: [B,h,w] uint8 or float32 host array (tightly packed).  Returns (points[B,max_pts], numPts[B])."""
+        u8 = imgs.dtype == np.uint8
+        imgs = np.ascontiguousarray(imgs, np.uint8 if u8 else np.float32)
+        B, h, w = imgs.shape
+        d = self.upload(imgs)
+        sc = DevBuf(4 * scratch_floats(w, h, num_octaves, scale_up) * B)
+        pts = self.zeros(576 * max_pts * B)
+        n = (C.c_int * B)()
+        check(lib().misift_extract_batch_ex(self.h, d.ptr, int(u8), B, h * w, w, h, w, num_octaves, init_blur, thresh,
+                                            lowest_scale, int(scale_up), sc.ptr, pts.ptr, max_pts, n),
+              "misift_extract_batch_ex")
         return self.download(pts, (B, max_pts), POINT_DTYPE), np.array(list(n), np.int32)
 
     def extract_batch_u8(self, imgs, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, max_pts=32768):

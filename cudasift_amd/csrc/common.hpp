@@ -47,6 +47,7 @@ struct OctaveInfo {
 };
 struct PyramidInfo {
   int noct, nframes;
+  float out_scale;                 // 0.5 when the frames were up-sampled first (RescalePositions, cudaSiftH.cu:130), else 1
   long long frame_stride;          // floats between frames' arenas
   OctaveInfo o[MISIFT_MAX_OCTAVES + 1];
 };
@@ -191,15 +192,21 @@ __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch
   float xb = x - 0.5f, yb = y - 0.5f;
   float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
-  if (frac8) {
-    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
-    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+  if (frac8) {          // a * 256 is exact, so the fused form rounds exactly like the oracle's mul + add
+    a = floorf(__builtin_fmaf(a, 256.0f, 0.5f)) * (1.0f / 256.0f);
+    b = floorf(__builtin_fmaf(b, 256.0f, 0.5f)) * (1.0f / 256.0f);
   }
   float t00, t10, t01, t11;
+  // Addresses are 32-bit BYTE offsets from the level's base pointer (wave-uniform: an SGPR pair), so each texel-pair
+  // load is `global_load_dwordx2 v, voffset, s[base]` after ONE v_mad_u32_u24 + shift — the 64-bit form the compiler
+  // derives from size_t indexing costs two v_mad_i64_i32 and five 64-bit shifts/adds per fetch (r02: the per-keypoint
+  // kernels are VALU-issue-bound, and this was a third of their sampling loop).  A pyramid level is < 2^31 bytes.
+  const char *base = reinterpret_cast<const char *>(img);
   if (INTERIOR) {
     const int ix = (int)fx, iy = (int)fy;
-    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(img + (size_t)iy * pitch + ix);
-    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(img + (size_t)(iy + 1) * pitch + ix);
+    const unsigned off = (__umul24((unsigned)iy, (unsigned)pitch) + (unsigned)ix) * 4u;      // v_mad_u32_u24: rows, pitch < 2^24
+    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(base + off);
+    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(base + (off + (unsigned)pitch * 4u));
     t00 = r0.a; t10 = r0.b; t01 = r1.a; t11 = r1.b;
   } else {
     fx = fminf(fmaxf(fx, -2.0f), (float)w);
@@ -208,12 +215,10 @@ __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch
     const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
     const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
     // The two texels of a row are adjacent except at the clamped image edges: fetch them with ONE 8-byte load at
-    // column xl (4-byte aligned is enough on gfx950) and pick.  rocprof: the per-keypoint kernels are bound by the
-    // L1's one-cache-line-per-clock lookup rate on these scattered gathers, so halving the load instructions
-    // (64 -> 32 per lane and descriptor) matters more than the extra selects.
+    // column xl (4-byte aligned is enough on gfx950) and pick.
     const int xl = clampi(ix, 0, w - 2);
-    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(img + (size_t)y0 * pitch + xl);
-    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(img + (size_t)y1 * pitch + xl);
+    const Pair2 r0 = *reinterpret_cast<const Pair2 *>(base + (__umul24((unsigned)y0, (unsigned)pitch) + (unsigned)xl) * 4u);
+    const Pair2 r1 = *reinterpret_cast<const Pair2 *>(base + (__umul24((unsigned)y1, (unsigned)pitch) + (unsigned)xl) * 4u);
     const bool lo0 = x0 == xl, hi1 = x1 == xl + 1;
     t00 = lo0 ? r0.a : r0.b; t10 = hi1 ? r0.b : r0.a;
     t01 = lo0 ? r1.a : r1.b; t11 = hi1 ? r1.b : r1.a;
@@ -244,7 +249,13 @@ struct misift_ctx {
   int cap_frames;
   unsigned int *d_cand;         // candidate lists [cap_frames][cand_cap]
   size_t cand_cap;              // entries per frame
-  Detection *d_det;             // staging [cap_det_frames][MISIFT_MAX_OCTAVES][det_max_pts]
+  Detection *d_det;             // staging [cap_det_frames][MISIFT_MAX_OCTAVES][det_max_pts] (refine's append order)
+  Detection *d_det_sorted;      // the same records binned by 32x32-px tile (what orient_all / descr_all consume)
+  int scan_variant;             // dog_scan_all: 0 = taps from LDS, 1 = taps in SGPRs, 2 = SGPR taps at 4 waves/SIMD (MISIFT_SCAN)
+  int descr_occ;                // descr_all_kernel variant: registers held to 3 or 4 waves/SIMD (MISIFT_DESCR_OCC)
+  int tile_descr, tile_orient;  // 1 = LDS-staged window in descr_all / orient_all, 0 = bilinear fetches from global memory
+                                // (MISIFT_TILE_DESCR / MISIFT_TILE_ORIENT; MISIFT_TILE sets both)
+  int bin_detections;           // 1 = run bin_detections_kernel between refine_all and orient_all (MISIFT_BIN=0 disables)
   int cap_det_frames, det_max_pts;
   float *d_own_scratch;         // scratch allocated on behalf of the caller (NULL tempMemory)
   size_t own_scratch_floats;
@@ -313,7 +324,8 @@ int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const Stri
                         long long dst2_frame_stride, const float k5[5], int *done);
 int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
                      long long dst_frame_stride, const float k5[5]);
-int launch_scaleup(misift_ctx *ctx, const void *src, int src_u8, int w, int h, int spitch, float *dst, int dpitch);
+int launch_scaleup(misift_ctx *ctx, const void *src, int src_u8, int w, int h, int spitch, long long src_frame_stride,
+                   int nframes, float *dst, int dpitch, long long dst_frame_stride);
 int launch_laplace(misift_ctx *ctx, const float *base, const StripGeom &g, float *dog,
                    long long dog_frame_stride, const LaplaceTaps &taps);
 int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long long dog_frame_stride,
@@ -329,6 +341,8 @@ int launch_orient(misift_ctx *ctx, const float *base, long long base_frame_strid
 int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride, int w, int h, int pitch,
                  int nframes, float subsampling, int octave, SiftPointD *pts, int max_pts);
 int launch_rescale(misift_ctx *ctx, SiftPointD *pts, int npts, float scale);
+int launch_rescale_batch(misift_ctx *ctx, SiftPointD *pts, int max_pts, int nframes, int num_octaves, float scale);
+int launch_bin_detections(misift_ctx *ctx, const PyramidInfo &P, int max_pts);
 int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts);
 int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts,
                      const int *pack_offsets, SiftPointD *pack_dst);

@@ -405,9 +405,25 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
 // Keeping only the current DoG row in registers (no 3-row window, no box minima) leaves the
 // kernel at ~1/2 the registers and ~1/3 the instructions of a full in-register 3x3x3 test.
 // One wavefront's strip/segment of the fused DoG scan (see dog_scan_kernel above for the method).
-template <bool FAST>
+// Tap pairs of the three scale pairs, from LDS (re-read every row) or from scalar registers (30 SGPRs: frees the 20
+// VGPRs the double-buffered LDS reads need and the 15 ds_read_b64 + waits per row).
+struct LdsTaps {
+  const v2f *tk;
+  __device__ __forceinline__ Taps2 pair(int p) const { return load_taps2(tk + 5 * p); }
+};
+struct RegTaps {
+  v2f k[NUM_SCAN_PAIRS * 5];
+  __device__ __forceinline__ Taps2 pair(int p) const
+  {
+    Taps2 t;
+    t.k0 = k[5 * p]; t.k1 = k[5 * p + 1]; t.k2 = k[5 * p + 2]; t.k3 = k[5 * p + 3]; t.k4 = k[5 * p + 4];
+    return t;
+  }
+};
+
+template <bool FAST, typename TAPS>
 __device__ __forceinline__ void scan_strip(const float *img, int width, int height, int pitch, int q, int lane,
-                                           int y0, int y1, const v2f *tk, float thresh, unsigned *cnt,
+                                           int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
                                            unsigned *list, unsigned cand_cap, int octave, bool al)
 {
   struct { int width, height, pitch; } g = {width, height, pitch};
@@ -431,12 +447,12 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
     // The six blurs are computed as three scale pairs (see blur_pair); the tap pairs of the next scale pair
     // are fetched from LDS while the current one is computed.
     float4 d[NUM_SCALES];
-    Taps2 tcur = load_taps2(tk), tnext = load_taps2(tk + 5);
+    Taps2 tcur = taps_src.pair(0), tnext = taps_src.pair(1);
     __builtin_amdgcn_sched_barrier(0);
     const Pair4 b0 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 1, 2
     tcur = tnext;
     asm volatile("" ::: "memory");                                 // re-read from LDS: do not pin tap pairs across the row loop
-    tnext = load_taps2(tk + 10);
+    tnext = taps_src.pair(2);
     __builtin_amdgcn_sched_barrier(0);
     d[0] = make_float4(b0.x.y - b0.x.x, b0.y.y - b0.y.x, b0.z.y - b0.z.x, b0.w.y - b0.w.x);
     const Pair4 b1 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 3, 4
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
   const int q = it.strip * (OUT_LANES - 2) + lane - 2;
   const int y0 = it.seg * g.seg_rows;
   scan_strip<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
-                   min(y0 + g.seg_rows, g.height), s_taps, thresh, counters + (size_t)it.frame * CNT_STRIDE,
+                   min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh, counters + (size_t)it.frame * CNT_STRIDE,
                    cand + (size_t)it.frame * cand_cap, cand_cap, octave, aligned != 0);
 }
 
@@ -557,11 +573,14 @@ struct ScanAllGeom {
   ScanOct o[MISIFT_MAX_OCTAVES];              // o[0] = finest level: the long items are dispatched first
 };
 
-template <bool FAST>
 #ifndef SCAN_OCC
 #define SCAN_OCC 3
 #endif
-__global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
+// STAPS: tap pairs in scalar registers instead of LDS; OCC: waves per SIMD the register allocation is held to
+// (tools/valu_rates: a SIMD issues one VALU instruction per 2 cycles only with >= 4 resident wavefronts, one per
+// 8/W cycles with W < 4 — the scan is VALU-issue-bound, so 3 -> 4 wavefronts is worth up to a third).
+template <bool FAST, bool STAPS, int OCC>
+__global__ __launch_bounds__(256, OCC) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
                                                               AllTaps taps, float thresh,
                                                               unsigned *__restrict__ counters,
                                                               unsigned *__restrict__ cand)
@@ -584,16 +603,29 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   const long long r = item / L.nsegs;
   const int strip = (int)(r % L.nstrips);
   const int frame = (int)(r / L.nstrips);
-  // this wavefront's private copy of its octave's tap pairs
-  if (lane < NUM_SCAN_PAIRS * 5) s_taps[wave][lane] = scan_pair_tap(taps.t[L.octave], lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int q = strip * (OUT_LANES - 2) + lane - 2;
   const int y0 = seg * L.seg_rows;
-  scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
-                   min(y0 + L.seg_rows, L.h), s_taps[wave], thresh, counters + (size_t)frame * CNT_STRIDE,
-                   cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
+  if (STAPS) {
+    RegTaps rt;
+#pragma unroll
+    for (int i = 0; i < NUM_SCAN_PAIRS * 5; i++) {
+      const v2f t = scan_pair_tap(taps.t[L.octave], i);           // wave-uniform kernel-argument loads
+      rt.k[i] = mk2(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.x))),
+                    __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.y))));
+    }
+    scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
+                     min(y0 + L.seg_rows, L.h), rt, thresh, counters + (size_t)frame * CNT_STRIDE,
+                     cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
+  } else {
+    // this wavefront's private copy of its octave's tap pairs
+    if (lane < NUM_SCAN_PAIRS * 5) s_taps[wave][lane] = scan_pair_tap(taps.t[L.octave], lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
+                     min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, counters + (size_t)frame * CNT_STRIDE,
+                     cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
+  }
 }
 
 // ------------------------------------------------------------------- refine
@@ -1011,12 +1043,13 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
   const AllTaps at = pack_taps(taps, P.noct);
   const dim3 grid((unsigned)((items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
   LaunchScope ls(ctx, "dog_scan");
-  if (fast)
-    hipLaunchKernelGGL(dog_scan_all_kernel<true>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
-                       ctx->d_counters, ctx->d_cand);
-  else
-    hipLaunchKernelGGL(dog_scan_all_kernel<false>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
-                       ctx->d_counters, ctx->d_cand);
+#define SCAN_LAUNCH(F, S, O) hipLaunchKernelGGL((dog_scan_all_kernel<F, S, O>), grid, dim3(256), 0, ctx->stream, scratch, G, at, \
+                                                thresh, ctx->d_counters, ctx->d_cand)
+  if (!fast) SCAN_LAUNCH(false, false, SCAN_OCC);
+  else if (ctx->scan_variant == 2) SCAN_LAUNCH(true, true, 4);       // taps in SGPRs, 128 VGPRs -> 4 waves/SIMD
+  else if (ctx->scan_variant == 1) SCAN_LAUNCH(true, true, SCAN_OCC);
+  else SCAN_LAUNCH(true, false, SCAN_OCC);
+#undef SCAN_LAUNCH
   return ls.finish();
 }
 

@@ -33,8 +33,171 @@ __device__ __forceinline__ float wave_sum(float v)
   return v;
 }
 
+// ---------------------------------------------------------------- LDS-staged image patch
+// rocprof (r01): orient_all / descr_all were bound by the L1's one-cache-line-per-clock lookup rate — every one of a
+// descriptor's 2048 texel-pair gathers (338 for an orientation) is its own L1 lookup, and the L1 is shared by the
+// CU's four SIMDs.  The patch a keypoint samples is small and square, so it is now fetched ONCE with row-contiguous
+// loads (13 dwordx2 per lane for the descriptor's 40x40 window, 4 dwords for the orientation's 16x16: ~15x fewer
+// lookups), parked in a wave-private LDS tile with clamp-to-edge already applied (so border keypoints need no
+// selects either), and all bilinear fetches read the tile: one address, two ds_read2_b32 (offsets {0,1} and
+// {W,W+1}).  Same texels, same weights, same fmaf chain as tex2d() — bit-identical results.  The next keypoint's
+// tile is loaded into registers while the current one is being sampled (its Detection record one step earlier
+// still), so the global-memory latency is off the critical path.
+#define PW 40                               // descriptor window: 40 x 40 texels around floor(xpos), floor(ypos)
+#define PATCH_FLOATS (PW * PW)              // 1600 = 25 texels per lane
+#define PATCH_LOADS 25
+#define PATCH_REACH 17.9f                   // largest sample distance (in texels) the window covers, see patch_geom()
+#define OW 16                               // orientation window: 16 x 16 texels
+
+struct PatchGeom {
+  int x0, y0;            // window origin (texel coordinates of tile[0][0])
+  bool fits;             // every texel the descriptor touches lies inside the window
+};
+
+// The descriptor samples tex(x, y) with |x - xpos|, |y - ypos| <= 7.5*sqrt(2)*S + 1 (rotated 16x16 grid of spacing
+// S = 0.75*scale, +-1 for the central differences; the +0.5 of the sample position cancels against tex2d's -0.5), so
+// the texel columns run from floor(xpos - reach) to floor(xpos + reach) + 1.  With reach <= 17.9 that is inside
+// [floor(xpos) - 18, floor(xpos) + 19], one column short of the window [floor(xpos) - 19, floor(xpos) + 20] on either
+// side (slack for the few ulps the float coordinate arithmetic can move a sample).  Larger scales (scale > 2.12:
+// only reachable through the refinement's unclamped fallback step) take the global-memory path.
+__device__ __forceinline__ PatchGeom patch_geom(float xpos, float ypos, float pscale, int w, int h)
+{
+  PatchGeom g;
+  const float reach = 10.6067f * (0.75f * pscale) + 1.0f;
+  // coordinates far outside the image cannot come out of the refinement; guard the int conversion anyway
+  const bool sane = xpos > -64.0f && ypos > -64.0f && xpos < (float)(w + 64) && ypos < (float)(h + 64);
+  g.fits = sane && reach <= PATCH_REACH;
+  g.x0 = (int)floorf(sane ? xpos : 0.0f) - 19;
+  g.y0 = (int)floorf(sane ? ypos : 0.0f) - 19;
+  return g;
+}
+
+// Texel t = lane + 64*k of the window is (row t / 40, column t % 40); 320 = 8 rows, so k = 5m + j is row r_j + 8m,
+// column c_j with five lane constants (r_j, c_j).  Clamp-to-edge is applied here, once per texel, instead of in every
+// bilinear fetch.  A load instruction covers 64 consecutive texels = 1.6 rows: 4..6 cache lines.
+struct PatchLane { int r[5], c[5]; };
+__device__ __forceinline__ PatchLane patch_lane(int lane)
+{
+  PatchLane pl;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const int t = lane + 64 * j;
+    pl.r[j] = t / PW;
+    pl.c[j] = t - pl.r[j] * PW;
+  }
+  return pl;
+}
+__device__ __forceinline__ void patch_fetch(const float *img, int w, int h, int pitch, const PatchGeom &g,
+                                            int lane, float (&R)[PATCH_LOADS])
+{
+  const PatchLane pl = patch_lane(lane);      // recomputed per keypoint (20 VALU): ten registers less across the main loop
+  unsigned col[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) col[j] = (unsigned)clampi(g.x0 + pl.c[j], 0, w - 1);
+#pragma unroll
+  for (int m = 0; m < 5; m++)
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const unsigned row = (unsigned)clampi(g.y0 + pl.r[j] + 8 * m, 0, h - 1);
+      R[5 * m + j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(img) +
+                                                       (__umul24(row, (unsigned)pitch) + col[j]) * 4u);   // saddr + 32-bit voffset
+    }
+}
+__device__ __forceinline__ void patch_store(float *tile, int lane, const float (&R)[PATCH_LOADS])
+{
+#pragma unroll
+  for (int k = 0; k < PATCH_LOADS; k++) tile[lane + 64 * k] = R[k];     // row-major, row stride PW
+}
+
+// tex2d() on a staged tile of row stride TW whose element [0][0] is texel (x0, y0): same operation sequence, the
+// clamp-to-edge addressing is already in the tile's contents.
+template <int TW>
+__device__ __forceinline__ float tex2d_tile(const float *tile, int x0, int y0, float x, float y, bool frac8)
+{
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (frac8) {
+    a = floorf(__builtin_fmaf(a, 256.0f, 0.5f)) * (1.0f / 256.0f);
+    b = floorf(__builtin_fmaf(b, 256.0f, 0.5f)) * (1.0f / 256.0f);
+  }
+  const float *p = tile + (__mul24((int)fy - y0, TW) + ((int)fx - x0));
+  const float t00 = p[0], t10 = p[1], t01 = p[TW], t11 = p[TW + 1];
+  const float ia = 1.0f - a, ib = 1.0f - b;
+  float v = (ia * ib) * t00;
+  v = __builtin_fmaf(a * ib, t10, v);
+  v = __builtin_fmaf(ia * b, t01, v);
+  v = __builtin_fmaf(a * b, t11, v);
+  return v;
+}
+
 // ------------------------------------------------------------- orientation
 struct OrientResult { float ori1, ori2; bool has2; };      // meaningful in lane 0 only
+
+// Second half of the orientation (reference cudaSiftD.cu:1011-1037): histogram of the 121 (bin, weight) samples in
+// smp[], smoothing, the two best local maxima, parabolic peaks.  Result meaningful in lane 0.
+__device__ __forceinline__ OrientResult orient_finish(float *hist, const float2 *smp, int lane)
+{
+  wave_sync();
+  // privatized histogram (no LDS atomics): lane (b, half) sums the samples of its half that fall in bin b
+  {
+    const float fb = (float)(lane & 31);
+    const float2 *sp = smp + (lane >> 5) * 64;
+    float acc = 0.0f;
+#pragma unroll 16
+    for (int j = 0; j < 64; j++) {
+      const float2 e = sp[j];
+      acc += (e.x == fb) ? e.y : 0.0f;
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < 32) hist[lane] = acc;
+  }
+  wave_sync();
+  const int t = lane & 31;
+  const int x1m = (t >= 1 ? t - 1 : t + 31), x1p = (t <= 30 ? t + 1 : t - 31);
+  const int x2m = (t >= 2 ? t - 2 : t + 30), x2p = (t <= 29 ? t + 2 : t - 30);
+  if (lane < 32) hist[t + 32] = 6.0f * hist[t] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
+  wave_sync();
+  // non-maximum suppression, then the two largest peaks by wave reductions (the reference scans the 32 bins
+  // serially, cudaSiftD.cu:1020-1033: first index of the maximum, first index of the runner-up)
+  float pk = 0.0f;
+  if (lane < 32) {
+    const float v = hist[32 + t];
+    pk = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
+  }
+  float maxval1 = pk;
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) maxval1 = fmaxf(maxval1, __shfl_xor(maxval1, m, 64));
+  maxval1 = __shfl(maxval1, 0, 64);
+  const unsigned long long b1 = __ballot(lane < 32 && pk == maxval1 && maxval1 > 0.0f);
+  const int i1 = b1 ? __ffsll((long long)b1) - 1 : -1;
+  const float pk2 = lane == i1 ? 0.0f : pk;
+  float maxval2 = pk2;
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) maxval2 = fmaxf(maxval2, __shfl_xor(maxval2, m, 64));
+  maxval2 = __shfl(maxval2, 0, 64);
+  const unsigned long long b2 = __ballot(lane < 32 && pk2 == maxval2 && maxval2 > 0.0f);
+  const int i2 = b2 ? __ffsll((long long)b2) - 1 : -1;
+  OrientResult r;
+  r.ori1 = 0.0f; r.ori2 = 0.0f; r.has2 = false;
+  if (lane == 0) {
+    if (i1 >= 0) {                                      // empty histogram -> orientation 0 (SURVEY Appendix B #8)
+      const float val1 = hist[32 + ((i1 + 1) & 31)];
+      const float val2 = hist[32 + ((i1 + 31) & 31)];
+      const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
+      r.ori1 = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+      if (maxval2 > 0.8f * maxval1) {
+        const float v1 = hist[32 + ((i2 + 1) & 31)];
+        const float v2 = hist[32 + ((i2 + 31) & 31)];
+        const float peak2 = i2 + 0.5f * (v1 - v2) / (2.0f * maxval2 - v1 - v2);
+        r.ori2 = 11.25f * (peak2 < 0.0f ? peak2 + 32.0f : peak2);
+        r.has2 = true;
+      }
+    }
+  }
+  wave_sync();
+  return r;
+}
 
 // Orientation of one keypoint by one wavefront (reference cudaSiftD.cu:984-1037).  hist[64], gauss[16] and
 // smp[128], tgrid[169] are wave-private LDS slices; smp[121..127] must hold bin -1 (never matches).
@@ -109,67 +272,62 @@ __device__ __forceinline__ OrientResult orient_core(const float *img, int w, int
       }
     }
   }
-  wave_sync();
-  // privatized histogram (no LDS atomics): lane (b, half) sums the samples of its half that fall in bin b
-  {
-    const float fb = (float)(lane & 31);
-    const float2 *sp = smp + (lane >> 5) * 64;
-    float acc = 0.0f;
-#pragma unroll 16
-    for (int j = 0; j < 64; j++) {
-      const float2 e = sp[j];
-      acc += (e.x == fb) ? e.y : 0.0f;
-    }
-    acc += __shfl_xor(acc, 32, 64);
-    if (lane < 32) hist[lane] = acc;
-  }
-  wave_sync();
-  const int t = lane & 31;
-  const int x1m = (t >= 1 ? t - 1 : t + 31), x1p = (t <= 30 ? t + 1 : t - 31);
-  const int x2m = (t >= 2 ? t - 2 : t + 30), x2p = (t <= 29 ? t + 2 : t - 30);
-  if (lane < 32) hist[t + 32] = 6.0f * hist[t] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
-  wave_sync();
-  // non-maximum suppression, then the two largest peaks by wave reductions (the reference scans the 32 bins
-  // serially, cudaSiftD.cu:1020-1033: first index of the maximum, first index of the runner-up)
-  float pk = 0.0f;
-  if (lane < 32) {
-    const float v = hist[32 + t];
-    pk = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
-  }
-  float maxval1 = pk;
-#pragma unroll
-  for (int m = 16; m > 0; m >>= 1) maxval1 = fmaxf(maxval1, __shfl_xor(maxval1, m, 64));
-  maxval1 = __shfl(maxval1, 0, 64);
-  const unsigned long long b1 = __ballot(lane < 32 && pk == maxval1 && maxval1 > 0.0f);
-  const int i1 = b1 ? __ffsll((long long)b1) - 1 : -1;
-  const float pk2 = lane == i1 ? 0.0f : pk;
-  float maxval2 = pk2;
-#pragma unroll
-  for (int m = 16; m > 0; m >>= 1) maxval2 = fmaxf(maxval2, __shfl_xor(maxval2, m, 64));
-  maxval2 = __shfl(maxval2, 0, 64);
-  const unsigned long long b2 = __ballot(lane < 32 && pk2 == maxval2 && maxval2 > 0.0f);
-  const int i2 = b2 ? __ffsll((long long)b2) - 1 : -1;
-  OrientResult r;
-  r.ori1 = 0.0f; r.ori2 = 0.0f; r.has2 = false;
-  if (lane == 0) {
-    if (i1 >= 0) {                                      // empty histogram -> orientation 0 (SURVEY Appendix B #8)
-      const float val1 = hist[32 + ((i1 + 1) & 31)];
-      const float val2 = hist[32 + ((i1 + 31) & 31)];
-      const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
-      r.ori1 = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
-      if (maxval2 > 0.8f * maxval1) {
-        const float v1 = hist[32 + ((i2 + 1) & 31)];
-        const float v2 = hist[32 + ((i2 + 31) & 31)];
-        const float peak2 = i2 + 0.5f * (v1 - v2) / (2.0f * maxval2 - v1 - v2);
-        r.ori2 = 11.25f * (peak2 < 0.0f ? peak2 + 32.0f : peak2);
-        r.has2 = true;
-      }
-    }
-  }
-  wave_sync();
-  return r;
+  return orient_finish(hist, smp, lane);
 }
 
+// Orientation from a staged 16x16 window (tile[0][0] = texel (x0, y0), clamp-to-edge applied when it was loaded):
+// the 169 grid values are bilinear fetches from LDS.  x0 = floor(xpos) - 7: the grid spans tex(x) with
+// x - 0.5 in [xpos - 6, xpos + 6] (up to a rounding of the float sums, which can only move a coordinate ONTO the next
+// integer, never across it), so the texel columns lie in [floor(xpos) - 6, floor(xpos) + 8] — inside
+// [x0, x0 + 15] with a column to spare on the left.  Keypoints whose coordinate sums are not binade-safe take the
+// literal per-sample path from global memory (orient_core's second branch) — bit-identical either way.
+__device__ __forceinline__ OrientResult orient_core_tile(const float *img, int w, int h, int pitch, bool q8, float xpos,
+                                                         float ypos, float scale, const float *tile, int x0, int y0,
+                                                         float *hist, float *gauss, float2 *smp, float *tgrid, int lane)
+{
+  const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
+  if (lane < 11) gauss[lane] = expf(i2sigma2 * (lane - 5) * (lane - 5));
+  const float xp = xpos - 4.5f;
+  const float yp = ypos - 4.5f;
+  bool same = true;
+  if (lane < 40) {
+    const float base = lane < 20 ? xp : yp;
+    const int k = lane < 20 ? lane : lane - 20;
+    if (k < 10) same = ((base + (float)k) + 1.0f) == (base + (float)(k + 1));          // xd = 0..9, "+1"
+    else same = ((base + (float)(k - 9)) - 1.0f) == (base + (float)(k - 10));           // xd = 1..10, "-1"
+  }
+  if (!__all(same))
+    return orient_core(img, w, h, pitch, q8, xpos, ypos, scale, hist, gauss, smp, tgrid, lane);
+#pragma unroll
+  for (int rep = 0; rep < 3; rep++) {
+    const int id = lane + 64 * rep;
+    if (id < 169) {
+      const int gy = id / 13, gx = id - gy * 13;          // grid index + 1
+      const float xf = gx == 0 ? (xp + 0.0f) - 1.0f : (gx == 12 ? (xp + 10.0f) + 1.0f : xp + (float)(gx - 1));
+      const float yf = gy == 0 ? (yp + 0.0f) - 1.0f : (gy == 12 ? (yp + 10.0f) + 1.0f : yp + (float)(gy - 1));
+      tgrid[id] = tex2d_tile<OW>(tile, x0, y0, xf, yf, q8);
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int rep = 0; rep < 2; rep++) {
+    const int tx = lane + 64 * rep;
+    if (tx < 121) {
+      const int yd = tx / 11;
+      const int xd = tx - yd * 11;
+      const float *t = tgrid + (yd + 1) * 13 + (xd + 1);
+      const float dx = t[1] - t[-1];
+      const float dy = t[13] - t[-13];
+      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+      if (bin > 31) bin = 0;
+      const float grad = sqrtf(dx * dx + dy * dy);
+      smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
+    }
+  }
+  return orient_finish(hist, smp, lane);
+}
+
+template <bool Q8>
 __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ base, long long base_frame_stride,
                                                      int w, int h, int pitch, int octave,
                                                      unsigned *__restrict__ counters, SiftPointD *__restrict__ pts,
@@ -184,7 +342,7 @@ __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ b
   const float *img = base + (long long)frame * base_frame_stride;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   SiftPointD *sift = pts + (size_t)frame * max_pts;
-  const bool q8 = frac8 != 0;
+  const bool q8 = Q8;          // compile-time: no per-fetch branch on the weight quantisation
 
   const int fstPts = (int)min(cnt[2 * octave - 1], (unsigned)max_pts);
   const int totPts = (int)min(cnt[2 * octave + 0], (unsigned)max_pts);
@@ -390,6 +548,7 @@ __device__ __forceinline__ void descr_core(const float *img, int w, int h, int p
   out1 = c1 * rs2;
 }
 
+template <bool Q8>
 __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ base, long long base_frame_stride,
                                                     int w, int h, int pitch, float subsampling, int octave,
                                                     const unsigned *__restrict__ counters,
@@ -402,7 +561,7 @@ __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ ba
   const float *img = base + (long long)frame * base_frame_stride;
   const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   SiftPointD *sift = pts + (size_t)frame * max_pts;
-  const bool q8 = frac8 != 0;
+  const bool q8 = Q8;          // compile-time: no per-fetch branch on the weight quantisation
   descr_init(s_smp[wave], s_gauss[wave], lane);
   const int cell = lane >> 2;
 
@@ -467,7 +626,507 @@ __device__ __forceinline__ bool flat_to_octave(const FrameCounts &c, int noct, i
   return found;
 }
 
+// ------------------------------------------------- spatial binning of the staged detections
+// refine_all appends detections in atomic order, i.e. spatially random: consecutive wavefronts of orient_all /
+// descr_all then share no cache lines and every keypoint's window comes from HBM (r01 PMC: 6 KB fetched per
+// keypoint, as much as the whole DoG scan).  One workgroup per (octave, frame) counting-sorts the octave's
+// Detection records by 32x32-pixel tile (row-major tile order; larger tiles when a level has more than 4096 of
+// them): wavefronts that run at the same time now work on neighbouring keypoints.  The order inside a tile stays
+// arbitrary, like the reference's atomic append order (cudaSiftD.cu:1420).
+#define BIN_MAX_TILES 4096
+__global__ __launch_bounds__(256) void bin_detections_kernel(PyramidInfo P, const unsigned *__restrict__ counters,
+                                                             const Detection *__restrict__ in,
+                                                             Detection *__restrict__ out, int max_pts)
+{
+  __shared__ unsigned s_hist[BIN_MAX_TILES];
+  __shared__ unsigned s_part[256];
+  const int o = blockIdx.x + 1, frame = blockIdx.y, tid = threadIdx.x;
+  const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const int n = (int)min(cnt[CNT_DET + o], (unsigned)max_pts);
+  if (n == 0) return;
+  const Detection *src = in + ((size_t)frame * MISIFT_MAX_OCTAVES + (o - 1)) * max_pts;
+  Detection *dst = out + ((size_t)frame * MISIFT_MAX_OCTAVES + (o - 1)) * max_pts;
+  int shift = 5;
+  int tx = (P.o[o].w >> shift) + 1, ty = (P.o[o].h >> shift) + 1;
+  while (tx * ty > BIN_MAX_TILES) { shift++; tx = (P.o[o].w >> shift) + 1; ty = (P.o[o].h >> shift) + 1; }
+  const int ntiles = tx * ty;
+  for (int t = tid; t < ntiles; t += 256) s_hist[t] = 0;
+  __syncthreads();
+  auto key = [&](const Detection &d) -> int {
+    const int kx = clampi((int)d.xpos >> shift, 0, tx - 1), ky = clampi((int)d.ypos >> shift, 0, ty - 1);
+    return ky * tx + kx;
+  };
+  for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[key(src[i])], 1u);
+  __syncthreads();
+  // exclusive prefix sum over the tiles: 16 consecutive tiles per thread, then a scan of the 256 partial sums
+  const int per = (ntiles + 255) / 256;
+  unsigned local = 0;
+  for (int t = tid * per; t < min((tid + 1) * per, ntiles); t++) local += s_hist[t];
+  s_part[tid] = local;
+  __syncthreads();
+  for (int ofs = 1; ofs < 256; ofs <<= 1) {
+    const unsigned v = tid >= ofs ? s_part[tid - ofs] : 0u;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  unsigned run = s_part[tid] - local;                   // exclusive prefix of this thread's first tile
+  for (int t = tid * per; t < min((tid + 1) * per, ntiles); t++) {
+    const unsigned c = s_hist[t];
+    s_hist[t] = run;
+    run += c;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const Detection d = src[i];
+    dst[atomicAdd(&s_hist[key(d)], 1u)] = d;
+  }
+}
+
+template <bool Q8>
 __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                         unsigned *__restrict__ counters,
+                                                         Detection *__restrict__ det, int max_pts, int frac8)
+{
+  __shared__ float s_hist[WAVES_PER_BLOCK][64];
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  __shared__ float2 s_smp[WAVES_PER_BLOCK][128];
+  __shared__ float s_tgrid[WAVES_PER_BLOCK][176];
+  __shared__ float s_tile[WAVES_PER_BLOCK][OW * OW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
+  const bool q8 = Q8;          // compile-time: no per-fetch branch on the weight quantisation
+  if (lane >= 57) s_smp[wave][64 + lane] = make_float2(-1.0f, 0.0f);
+  const FrameCounts fc = load_frame_counts(cnt, P.noct, max_pts, false);
+  const int stride = gridDim.x * WAVES_PER_BLOCK;
+  // window texel t = lane + 64*k, k = 0..3, is (row 4k + lane/16, column lane%16): one load instruction covers 4 rows
+  const int tr = lane >> 4, tc = lane & 15;
+  auto fetch = [&](const float4 &k, const OctaveInfo &L, float (&T)[4]) {
+    const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
+    const bool sane = k.x > -64.0f && k.y > -64.0f && k.x < (float)(L.w + 64) && k.y < (float)(L.h + 64);
+    const int x0 = (int)floorf(sane ? k.x : 0.0f) - 7, y0 = (int)floorf(sane ? k.y : 0.0f) - 7;
+    const unsigned col = (unsigned)clampi(x0 + tc, 0, L.w - 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      T[q] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(img) +
+                                              (__umul24((unsigned)clampi(y0 + tr + 4 * q, 0, L.h - 1), (unsigned)L.p) + col) * 4u);
+  };
+  int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave);
+  int o, i, o1 = 0, i1 = 0, o2 = 0, i2 = 0;
+  bool more = flat_to_octave(fc, P.noct, idx, o, i);
+  if (!more) return;
+  // three-deep software pipeline: record of keypoint n+2 | window of keypoint n+1 (registers) | keypoint n (LDS)
+  float4 cur = *reinterpret_cast<const float4 *>(&fdet[(size_t)(o - 1) * max_pts + i]), nxt = cur, nxt2 = cur;
+  bool more1 = flat_to_octave(fc, P.noct, idx + stride, o1, i1);
+  if (more1) nxt = *reinterpret_cast<const float4 *>(&fdet[(size_t)(o1 - 1) * max_pts + i1]);
+  float T[4];
+  fetch(cur, P.o[o], T);
+  while (more) {
+    const OctaveInfo &L = P.o[o];
+    const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
+    Detection *d = &fdet[(size_t)(o - 1) * max_pts + i];
+    const int co = o;
+    const bool sane = cur.x > -64.0f && cur.y > -64.0f && cur.x < (float)(L.w + 64) && cur.y < (float)(L.h + 64);
+    const int x0 = (int)floorf(sane ? cur.x : 0.0f) - 7, y0 = (int)floorf(sane ? cur.y : 0.0f) - 7;
+#pragma unroll
+    for (int q = 0; q < 4; q++) s_tile[wave][lane + 64 * q] = T[q];
+    wave_sync();
+    if (more1) fetch(nxt, P.o[o1], T);
+    const bool more2 = more1 && flat_to_octave(fc, P.noct, idx + 2 * stride, o2, i2);
+    if (more2) nxt2 = *reinterpret_cast<const float4 *>(&fdet[(size_t)(o2 - 1) * max_pts + i2]);
+    const OrientResult r = sane ? orient_core_tile(img, L.w, L.h, L.p, q8, cur.x, cur.y, cur.z, s_tile[wave], x0, y0,
+                                                   s_hist[wave], s_gauss[wave], s_smp[wave], s_tgrid[wave], lane)
+                                : orient_core(img, L.w, L.h, L.p, q8, cur.x, cur.y, cur.z, s_hist[wave], s_gauss[wave],
+                                              s_smp[wave], s_tgrid[wave], lane);
+    if (lane == 0) {
+      d->ori1 = r.ori1;
+      d->ori2 = r.ori2;
+      d->dupslot = r.has2 ? (int)atomicAdd(&cnt[CNT_DUP + co], 1u) : -1;
+    }
+    idx += stride;
+    more = more1; o = o1; i = i1; cur = nxt;
+    more1 = more2; o1 = o2; i1 = i2; nxt = nxt2;
+  }
+}
+
+// Phase 1 of the descriptor from the staged tile: this lane's 4 of the 256 rotated samples -> the two votes of each
+// (iangf*grad into angle bin angi, angf*grad into bin angi+1) and angi itself; two samples per trip of a rolled loop.
+__device__ __forceinline__ void descr_samples_tile(const float *tile, int x0, int y0, bool q8, float px, float py,
+                                                   float sina, float cosa, float ssina, float scosa,
+                                                   const float *gauss, int lane, float (&vx)[4], float (&vy)[4],
+                                                   int (&ang)[4])
+{
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    float tvx[2], tvy[2];
+    int ta[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int id = lane + 64 * (2 * half + j);
+      const int tx = id & 15, y = id >> 4;
+      const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
+      const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+      const float dx = tex2d_tile<PW>(tile, x0, y0, xpos + cosa, ypos + sina, q8) -
+                       tex2d_tile<PW>(tile, x0, y0, xpos - cosa, ypos - sina, q8);
+      const float dy = tex2d_tile<PW>(tile, x0, y0, xpos - sina, ypos + cosa, q8) -
+                       tex2d_tile<PW>(tile, x0, y0, xpos + sina, ypos - cosa, q8);
+      const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
+      float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+      const int angi = (int)angf;
+      angf -= angi;
+      tvx[j] = (1.0f - angf) * grad;
+      tvy[j] = angf * grad;
+      ta[j] = angi;
+    }
+    if (half == 0) {
+      vx[0] = tvx[0]; vy[0] = tvy[0]; ang[0] = ta[0];
+      vx[1] = tvx[1]; vy[1] = tvy[1]; ang[1] = ta[1];
+    } else {
+      vx[2] = tvx[0]; vy[2] = tvy[0]; ang[2] = ta[0];
+      vx[3] = tvx[1]; vy[3] = tvy[1]; ang[3] = ta[1];
+    }
+  }
+}
+
+// 8x8 footprint of a cell, four rows at a time (8 b128 loads in flight: the fully unrolled form holds 64 registers)
+__device__ __forceinline__ float footprint_sum2(const float *base, float acc)
+{
+#pragma unroll 1
+  for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int my = 4 * h + r;
+      const float4 lo = *reinterpret_cast<const float4 *>(base + my * SMP_W);
+      const float4 hi = *reinterpret_cast<const float4 *>(base + my * SMP_W + 4);
+      // spatial_w(my) for my = 4h + r: (r + 0.5)/4 in the upper half, (3.5 - r)/4 in the lower one
+      const float wy = h == 0 ? (r + 0.5f) * 0.25f : (3.5f - r) * 0.25f;
+      acc = __builtin_fmaf(wy * spatial_w(0), lo.x, acc);
+      acc = __builtin_fmaf(wy * spatial_w(1), lo.y, acc);
+      acc = __builtin_fmaf(wy * spatial_w(2), lo.z, acc);
+      acc = __builtin_fmaf(wy * spatial_w(3), lo.w, acc);
+      acc = __builtin_fmaf(wy * spatial_w(4), hi.x, acc);
+      acc = __builtin_fmaf(wy * spatial_w(5), hi.y, acc);
+      acc = __builtin_fmaf(wy * spatial_w(6), hi.z, acc);
+      acc = __builtin_fmaf(wy * spatial_w(7), hi.w, acc);
+    }
+  }
+  return acc;
+}
+
+// Votes -> normalised descriptor bins (8*cell + (lane&3)) and (+4).  tbl: FOUR per-bin planes [bin][20][20] over the
+// 16x16 sample grid (2-sample zero border), all zero on entry and on exit; bins 0..3 first, then the same planes are
+// re-used for bins 4..7 (see the comment above SMP_W).  Sample j of this lane sits at plane position pos_j.
+__device__ __forceinline__ void descr_accumulate(float *tbl, int lane, const float (&vx)[4], const float (&vy)[4],
+                                                 const int (&ang)[4], float &out0, float &out1)
+{
+  const int cell = lane >> 2, cx = cell & 3, cy = cell >> 2;
+  const float *mine = tbl + (lane & 3) * SMP_PLANE + (4 * cy) * SMP_W + 4 * cx;
+  int pos[4], bx[4], by[4];
+  bool has8 = false;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int id = lane + 64 * j;
+    pos[j] = ((id >> 4) + 2) * SMP_W + (id & 15) + 2;
+    bx[j] = ang[j];                                   // bin of the iangf vote (8: the special case below)
+    by[j] = ang[j] >= 7 ? 0 : ang[j] + 1;             // bin of the angf vote: wraps to 0 (7 and 8 alike)
+    has8 |= ang[j] >= 8;
+  }
+  // ---- bins 0..3
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (bx[j] < 4) tbl[bx[j] * SMP_PLANE + pos[j]] = vx[j];
+    if (by[j] < 4) tbl[by[j] * SMP_PLANE + pos[j]] = vy[j];
+  }
+  wave_sync();
+  float acc0 = footprint_sum2(mine, 0.0f);
+  wave_sync();
+  // ---- bins 4..7 re-use planes 0..3 (a lane's pass-A and pass-B slots never coincide: different plane or position)
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (bx[j] < 4) tbl[bx[j] * SMP_PLANE + pos[j]] = 0.0f;
+    if (by[j] < 4) tbl[by[j] * SMP_PLANE + pos[j]] = 0.0f;
+    if (bx[j] >= 4 && bx[j] < 8) tbl[(bx[j] - 4) * SMP_PLANE + pos[j]] = vx[j];
+    if (by[j] >= 4) tbl[(by[j] - 4) * SMP_PLANE + pos[j]] = vy[j];
+  }
+  wave_sync();
+  float acc1 = footprint_sum2(mine, 0.0f);
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (bx[j] >= 4 && bx[j] < 8) tbl[(bx[j] - 4) * SMP_PLANE + pos[j]] = 0.0f;
+    if (by[j] >= 4) tbl[(by[j] - 4) * SMP_PLANE + pos[j]] = 0.0f;
+  }
+  if (__any(has8)) {
+    // rare (dy == +0 and dx < 0): angi == 8 makes the iangf vote land in bin 0 of the NEXT cell
+    // of the flattened 4x4 grid, with the spatial weights of the cell it was computed for; cell 16 does not exist
+    // (dropped).  Third pass: those votes go to plane 0 and every cell >= 1 adds the PREVIOUS cell's footprint.
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (bx[j] >= 8) tbl[pos[j]] = vx[j];
+    wave_sync();
+    if ((lane & 3) == 0 && cell >= 1) {
+      const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
+      acc0 = footprint_sum2(tbl + (4 * pcy) * SMP_W + 4 * pcx, acc0);
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (bx[j] >= 8) tbl[pos[j]] = 0.0f;
+  }
+  // normalise, clamp at 0.2, normalise again (reference cudaSiftD.cu:390-409)
+  const float tsum1 = wave_sum(acc0 * acc0 + acc1 * acc1);
+  const float rs1 = 1.0f / sqrtf(tsum1);
+  const float c0 = fminf(acc0 * rs1, 0.2f), c1 = fminf(acc1 * rs1, 0.2f);
+  const float tsum2 = wave_sum(c0 * c0 + c1 * c1);
+  const float rs2 = 1.0f / sqrtf(tsum2);
+  out0 = c0 * rs2;
+  out1 = c1 * rs2;
+}
+
+// Write one finished record (both targets: the per-frame array and / or the packed array).
+__device__ __forceinline__ void descr_write(SiftPointD *sift, SiftPointD *pack_dst, int pack_off, unsigned pack_cnt,
+                                            unsigned dst, int lane, float o0, float o1v, const Detection &d,
+                                            float orientation, float subsampling, float out_scale)
+{
+  const int cell = lane >> 2;
+#pragma unroll
+  for (int tgt = 0; tgt < 2; tgt++) {
+    SiftPointD *p = tgt == 0 ? (sift ? &sift[dst] : nullptr)
+                             : (pack_dst && dst < pack_cnt ? pack_dst + pack_off + dst : nullptr);
+    if (!p) continue;
+    p->data[8 * cell + (lane & 3)] = o0;
+    p->data[8 * cell + (lane & 3) + 4] = o1v;
+    if (lane == 0) {
+      p->xpos = d.xpos * subsampling * out_scale;       // out_scale is 1 or 0.5: exact, = a later RescalePositions
+      p->ypos = d.ypos * subsampling * out_scale;
+      p->scale = d.scale * subsampling * out_scale;
+      p->sharpness = d.sharpness;
+      p->edgeness = d.edgeness;
+      p->orientation = orientation;
+      p->subsampling = subsampling;
+      if (tgt == 1) {                       // a packed record is complete: the match fields start out cleared
+        p->score = 0.0f; p->ambiguity = 0.0f; p->match = 0; p->match_xpos = 0.0f; p->match_ypos = 0.0f;
+        p->match_error = 0.0f; p->empty[0] = 0.0f; p->empty[1] = 0.0f; p->empty[2] = 0.0f;
+      }
+    }
+  }
+}
+
+// descr_all_kernel — the default descriptor kernel.  One wavefront per keypoint; ONE 6.4 KB LDS buffer per wavefront
+// that is first the keypoint's 40x40 image window and then, once all samples are taken, the 4-plane vote table
+// (1600 floats either way) — so LDS never limits the occupancy and the kernel runs at the 4 waves/SIMD the VALU issue
+// rate needs (tools/valu_rates: a wavefront issues one VALU instruction per 8 cycles, a SIMD one per 2).
+//   per keypoint:  window (registers, prefetched) -> LDS | samples of the 1st and, if there is one, the 2nd orientation
+//                  (votes stay in registers) | clear | votes -> table -> footprints -> normalise -> record, once per
+//                  orientation.
+// Keypoints whose window would not fit (scale > 2.1: only through the refinement's unclamped fallback step) are
+// appended to a per-frame list and done by descr_big_kernel from global memory afterwards.
+#ifndef DESCR_OCC
+#define DESCR_OCC 4
+#endif
+#define CNT_BIG 48            // counter slot: keypoints deferred to descr_big_kernel
+template <bool Q8, int OCC>
+__global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                        unsigned *__restrict__ counters,
+                                                        const Detection *__restrict__ det,
+                                                        SiftPointD *__restrict__ pts, int max_pts, int frac8,
+                                                        const int *__restrict__ pack_offsets,
+                                                        SiftPointD *__restrict__ pack_dst,
+                                                        unsigned *__restrict__ big_list, unsigned big_stride)
+{
+  __shared__ __attribute__((aligned(16))) float s_buf[WAVES_PER_BLOCK][PATCH_FLOATS];      // window, then vote table
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  __shared__ float s_park[WAVES_PER_BLOCK][12 * 64];       // votes of a first orientation while the second is sampled
+  static_assert(PATCH_FLOATS == 4 * SMP_PLANE, "the window and the four vote planes share one buffer");
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
+  SiftPointD *sift = pts ? pts + (size_t)frame * max_pts : nullptr;
+  // packed output: this frame's first numPts records go to pack_dst[pack_offsets[frame] ...] (what a gather ships)
+  const int pack_off = pack_dst ? __builtin_amdgcn_readfirstlane(pack_offsets[frame]) : 0;
+  const unsigned pack_cnt = pack_dst ? (unsigned)(__builtin_amdgcn_readfirstlane(pack_offsets[frame + 1]) - pack_off) : 0u;
+  const bool q8 = Q8;          // compile-time: no per-fetch branch on the weight quantisation
+  float *buf = s_buf[wave];
+  const float *gauss = s_gauss[wave];
+  if (lane < 16) s_gauss[wave][lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
+  // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
+  if (blockIdx.x == 0 && threadIdx.x == 0) {             // publish the reference's counters (cudaSiftD.cu:14)
+    unsigned b = 0;
+    for (int k = 1; k <= P.noct; k++) {
+      cnt[2 * k - 1] = b;
+      b += cnt[CNT_DET + k];
+      cnt[2 * k] = b;
+      b += cnt[CNT_DUP + k];
+      cnt[2 * k + 1] = b;
+    }
+  }
+  const int stride = gridDim.x * WAVES_PER_BLOCK;
+  // Keypoints of a frame are numbered octave after octave (coarsest first); a wavefront takes every stride-th one.
+  // (octave, index) advance incrementally — the per-octave counts are re-read only when an octave is exhausted.
+  auto ndet = [&](int k) -> int {
+    return (int)min(__builtin_amdgcn_readfirstlane(cnt[CNT_DET + k]), (unsigned)max_pts);
+  };
+  auto advance = [&](int &o, int &i, int by) -> bool {      // false: past the last keypoint
+    i += by;
+    while (o <= P.noct) {
+      const int n = ndet(o);
+      if (i < n) return true;
+      i -= n;
+      o++;
+    }
+    return false;
+  };
+  // three-deep software pipeline over this wavefront's keypoints:
+  //   Detection record of keypoint n+2 | window of keypoint n+1 (global -> registers) | keypoint n (LDS)
+  int o = 1, i = 0, o1, i1, o2, i2;
+  bool more = advance(o, i, __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave));
+  if (!more) return;
+  o1 = o; i1 = i;
+  bool more1 = advance(o1, i1, stride);
+  o2 = o1; i2 = i1;
+  Detection d = fdet[(size_t)(o - 1) * max_pts + i], d1 = d, d2 = d;
+  if (more1) d1 = fdet[(size_t)(o1 - 1) * max_pts + i1];
+  PatchGeom g = patch_geom(d.xpos, d.ypos, d.scale, P.o[o].w, P.o[o].h), g1 = g;
+  float R[PATCH_LOADS];
+  if (g.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + P.o[o].img_off, P.o[o].w, P.o[o].h, P.o[o].p, g, lane, R);
+  int cur_o = 0;
+  unsigned bdet = 0, bdup = 0;                            // segment bases of octave cur_o in the reference layout
+  while (more) {
+    const float subsampling = P.o[o].subsampling;
+    if (g.fits) patch_store(buf, lane, R);
+    wave_sync();
+    // ---- keypoint n+1: window loads into the registers just drained; keypoint n+2: its record
+    if (more1) {
+      const OctaveInfo &L1 = P.o[o1];
+      g1 = patch_geom(d1.xpos, d1.ypos, d1.scale, L1.w, L1.h);
+      if (g1.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + L1.img_off, L1.w, L1.h, L1.p, g1, lane, R);
+    }
+    const bool more2 = more1 && advance(o2, i2, stride);
+    if (more2) d2 = fdet[(size_t)(o2 - 1) * max_pts + i2];
+    // ---- keypoint n
+    if (o != cur_o) {                                     // octave changed: segment bases (cudaSiftD.cu:1297-1300)
+      unsigned b = 0;
+      for (int k = 1; k < o; k++)
+        b += __builtin_amdgcn_readfirstlane(cnt[CNT_DET + k]) + __builtin_amdgcn_readfirstlane(cnt[CNT_DUP + k]);
+      bdet = b;
+      bdup = b + __builtin_amdgcn_readfirstlane(cnt[CNT_DET + o]);
+      cur_o = o;
+    }
+    const unsigned dstA = bdet + (unsigned)i;
+    const bool dup = d.dupslot >= 0;
+    const unsigned dstB = bdup + (unsigned)(dup ? d.dupslot : 0);
+    const bool doA = dstA < (unsigned)max_pts, doB = dup && dstB < (unsigned)max_pts;   // capacity: dropped, still counted
+    if (!g.fits) {
+      if (lane == 0 && (doA || doB)) {                    // too large for the window: descr_big_kernel takes it
+        const unsigned slot = atomicAdd(&cnt[CNT_BIG], 1u);
+        if (slot < big_stride) big_list[(size_t)frame * big_stride + slot] = ((unsigned)o << 24) | (unsigned)i;
+      }
+    } else if (doA || doB) {
+      // one set of vote registers: when a keypoint has both orientations, the first one's votes wait in LDS (s_park)
+      // while the second one is sampled — two live sets cost 12 registers the kernel does not have at 4 waves/SIMD
+      float vx[4], vy[4];
+      int ang[4];
+      const float scale = 12.0f / 16.0f * d.scale;
+      const int nori = (doA ? 1 : 0) + (doB ? 1 : 0);
+      float *park = s_park[wave] + lane;
+      // sampling: the orientation(s) to do, first then second (ONE copy of the sampling code: rolled loop)
+#pragma unroll 1
+      for (int k = 0; k < nori; k++) {
+        if (k == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            park[64 * j] = vx[j];
+            park[64 * (4 + j)] = vy[j];
+            park[64 * (8 + j)] = __builtin_bit_cast(float, ang[j]);
+          }
+        }
+        const float theta = 2.0f * 3.1415f / 360.0f * ((k == 0 && doA) ? d.ori1 : d.ori2);
+        const float sina = sinf(theta), cosa = cosf(theta);
+        descr_samples_tile(buf, g.x0, g.y0, q8, d.xpos, d.ypos, sina, cosa, scale * sina, scale * cosa, gauss, lane, vx, vy, ang);
+      }
+      wave_sync();                                        // every lane is done with the window
+#pragma unroll
+      for (int k = 0; k < 7; k++) {                       // the same 1600 floats become the (all-zero) vote table
+        const int q = lane + 64 * k;
+        if (q < PATCH_FLOATS / 4) *reinterpret_cast<float4 *>(buf + 4 * q) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+      wave_sync();
+      // accumulation: the orientation sampled last first (its votes are in registers), then the parked one
+#pragma unroll 1
+      for (int k = nori - 1; k >= 0; k--) {
+        if (k == 0 && nori == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            vx[j] = park[64 * j];
+            vy[j] = park[64 * (4 + j)];
+            ang[j] = __builtin_bit_cast(int, park[64 * (8 + j)]);
+          }
+        }
+        const bool first = k == 0 && doA;
+        float o0, o1v;
+        descr_accumulate(buf, lane, vx, vy, ang, o0, o1v);
+        descr_write(sift, pack_dst, pack_off, pack_cnt, first ? dstA : dstB, lane, o0, o1v, d, first ? d.ori1 : d.ori2,
+                    subsampling, P.out_scale);
+      }
+    }
+    wave_sync();                                          // the buffer is free (and all zero or about to be overwritten)
+    more = more1; o = o1; i = i1; d = d1; g = g1;
+    more1 = more2; o1 = o2; i1 = i2; d1 = d2;
+  }
+}
+
+// The few keypoints descr_all_kernel deferred (window larger than 40x40 texels): bilinear fetches from global memory.
+template <bool Q8>
+__global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                        const unsigned *__restrict__ counters,
+                                                        const Detection *__restrict__ det,
+                                                        SiftPointD *__restrict__ pts, int max_pts,
+                                                        const int *__restrict__ pack_offsets,
+                                                        SiftPointD *__restrict__ pack_dst,
+                                                        const unsigned *__restrict__ big_list, unsigned big_stride)
+{
+  __shared__ __attribute__((aligned(16))) float s_smp[WAVES_PER_BLOCK][DESCR_TBL];
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const unsigned nbig = min(cnt[CNT_BIG], big_stride);
+  if (nbig == 0) return;
+  const Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
+  SiftPointD *sift = pts ? pts + (size_t)frame * max_pts : nullptr;
+  const int pack_off = pack_dst ? pack_offsets[frame] : 0;
+  const unsigned pack_cnt = pack_dst ? (unsigned)(pack_offsets[frame + 1] - pack_off) : 0u;
+  descr_init(s_smp[wave], s_gauss[wave], lane);
+  for (unsigned t = blockIdx.x * WAVES_PER_BLOCK + wave; t < nbig; t += gridDim.x * WAVES_PER_BLOCK) {
+    const unsigned code = big_list[(size_t)frame * big_stride + t];
+    const int o = (int)(code >> 24), i = (int)(code & 0xffffffu);
+    const OctaveInfo &L = P.o[o];
+    const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
+    const Detection d = fdet[(size_t)(o - 1) * max_pts + i];
+    unsigned b = 0;
+    for (int k = 1; k < o; k++) b += cnt[CNT_DET + k] + cnt[CNT_DUP + k];
+    const unsigned bdet = b, bdup = b + cnt[CNT_DET + o];
+    for (int which = 0; which < 2; which++) {
+      if (which == 1 && d.dupslot < 0) break;
+      const unsigned dst = which == 0 ? bdet + (unsigned)i : bdup + (unsigned)d.dupslot;
+      if (dst >= (unsigned)max_pts) continue;
+      float o0, o1v;
+      descr_core(img, L.w, L.h, L.p, Q8, d.xpos, d.ypos, d.scale, which == 0 ? d.ori1 : d.ori2, s_smp[wave], s_gauss[wave],
+                 lane, o0, o1v);
+      descr_write(sift, pack_dst, pack_off, pack_cnt, dst, lane, o0, o1v, d, which == 0 ? d.ori1 : d.ori2, L.subsampling,
+                  P.out_scale);
+    }
+  }
+}
+
+// ---- the r01 forms of the two merged-octave kernels: bilinear fetches straight from global memory (no staged
+// tile), 4 waves/SIMD.  Selected with MISIFT_TILE=0 (A/B measurements).
+template <bool Q8>
+__global__ __launch_bounds__(256) void orient_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                          unsigned *__restrict__ counters,
                                                          Detection *__restrict__ det, int max_pts, int frac8)
 {
@@ -479,7 +1138,7 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
   const int frame = blockIdx.y;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
-  const bool q8 = frac8 != 0;
+  const bool q8 = Q8;
   if (lane >= 57) s_smp[wave][64 + lane] = make_float2(-1.0f, 0.0f);
   const FrameCounts fc = load_frame_counts(cnt, P.noct, max_pts, false);
   const int stride = gridDim.x * WAVES_PER_BLOCK;
@@ -508,10 +1167,9 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
   }
 }
 
-#ifndef DESCR_OCC
-#define DESCR_OCC 4
-#endif
-__global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+
+template <bool Q8>
+__global__ __launch_bounds__(256, 4) void descr_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                         unsigned *__restrict__ counters,
                                                         const Detection *__restrict__ det,
                                                         SiftPointD *__restrict__ pts, int max_pts, int frac8,
@@ -528,7 +1186,7 @@ __global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *
   // packed output: this frame's first numPts records go to pack_dst[pack_offsets[frame] ...] (what a gather ships)
   const int pack_off = pack_dst ? __builtin_amdgcn_readfirstlane(pack_offsets[frame]) : 0;
   const unsigned pack_cnt = pack_dst ? (unsigned)(__builtin_amdgcn_readfirstlane(pack_offsets[frame + 1]) - pack_off) : 0u;
-  const bool q8 = frac8 != 0;
+  const bool q8 = Q8;
   descr_init(s_smp[wave], s_gauss[wave], lane);
   const int cell = lane >> 2;
   // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
@@ -571,9 +1229,9 @@ __global__ __launch_bounds__(256, DESCR_OCC) void descr_all_kernel(const float *
         p->data[8 * cell + (lane & 3)] = o0;
         p->data[8 * cell + (lane & 3) + 4] = o1;
         if (lane == 0) {
-          p->xpos = d.xpos * L.subsampling;
-          p->ypos = d.ypos * L.subsampling;
-          p->scale = d.scale * L.subsampling;
+          p->xpos = d.xpos * L.subsampling * P.out_scale;       // out_scale is 1 or 0.5: exact, = a later RescalePositions
+          p->ypos = d.ypos * L.subsampling * P.out_scale;
+          p->scale = d.scale * L.subsampling * P.out_scale;
           p->sharpness = d.sharpness;
           p->edgeness = d.edgeness;
           p->orientation = which == 0 ? d.ori1 : d.ori2;
@@ -599,6 +1257,18 @@ __global__ void rescale_kernel(SiftPointD *pts, int npts, float scale)
   }
 }
 
+// RescalePositions over a batch (unfused path with scaleUp): frame f's first numPts records, numPts from the counters
+__global__ void rescale_batch_kernel(SiftPointD *pts, int max_pts, const unsigned *__restrict__ counters, int slot, float scale)
+{
+  SiftPointD *p = pts + (size_t)blockIdx.y * max_pts;
+  const int n = (int)min(counters[(size_t)blockIdx.y * CNT_STRIDE + slot], (unsigned)max_pts);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    p[i].xpos *= scale;
+    p[i].ypos *= scale;
+    p[i].scale *= scale;
+  }
+}
+
 // ------------------------------------------------------------- host wrappers
 static inline int points_grid_x(misift_ctx *ctx, int nframes, int blocks_per_cu = 0)
 {
@@ -611,13 +1281,19 @@ static inline int points_grid_x(misift_ctx *ctx, int nframes, int blocks_per_cu 
   return per_frame;
 }
 
+// the texture-weight quantisation (texfrac_bits 8 / 23) is a template parameter of the kernels
+#define LAUNCH_Q8(kernel, grid, block, ...)                                                       \
+  do {                                                                                            \
+    if (ctx->opt.texfrac_bits == 8) hipLaunchKernelGGL(kernel<true>, grid, block, 0, ctx->stream, __VA_ARGS__);   \
+    else hipLaunchKernelGGL(kernel<false>, grid, block, 0, ctx->stream, __VA_ARGS__);             \
+  } while (0)
+
 int launch_orient(misift_ctx *ctx, const float *base, long long base_frame_stride, int w, int h, int pitch,
                   int nframes, int octave, SiftPointD *pts, int max_pts)
 {
   LaunchScope ls(ctx, "orient");
-  hipLaunchKernelGGL(orient_kernel, dim3(points_grid_x(ctx, nframes), nframes), dim3(256), 0, ctx->stream, base,
-                     base_frame_stride, w, h, pitch, octave, ctx->d_counters, pts, max_pts,
-                     ctx->opt.texfrac_bits == 8 ? 1 : 0);
+  LAUNCH_Q8(orient_kernel, dim3(points_grid_x(ctx, nframes), nframes), dim3(256), base, base_frame_stride, w, h, pitch,
+            octave, ctx->d_counters, pts, max_pts, 0);
   return ls.finish();
 }
 
@@ -625,9 +1301,16 @@ int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride
                  int nframes, float subsampling, int octave, SiftPointD *pts, int max_pts)
 {
   LaunchScope ls(ctx, "descr");
-  hipLaunchKernelGGL(descr_kernel, dim3(points_grid_x(ctx, nframes), nframes), dim3(256), 0, ctx->stream, base,
-                     base_frame_stride, w, h, pitch, subsampling, octave, ctx->d_counters, pts, max_pts,
-                     ctx->opt.texfrac_bits == 8 ? 1 : 0);
+  LAUNCH_Q8(descr_kernel, dim3(points_grid_x(ctx, nframes), nframes), dim3(256), base, base_frame_stride, w, h, pitch,
+            subsampling, octave, ctx->d_counters, pts, max_pts, 0);
+  return ls.finish();
+}
+
+int launch_bin_detections(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
+{
+  LaunchScope ls(ctx, "bin_detections");
+  hipLaunchKernelGGL(bin_detections_kernel, dim3(P.noct, P.nframes), dim3(256), 0, ctx->stream, P, ctx->d_counters,
+                     ctx->d_det, ctx->d_det_sorted, max_pts);
   return ls.finish();
 }
 
@@ -635,8 +1318,10 @@ int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
 {
   (void)pts;
   LaunchScope ls(ctx, "orient_all");
-  hipLaunchKernelGGL(orient_all_kernel, dim3(points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu), P.nframes), dim3(256), 0, ctx->stream,
-                     scratch, P, ctx->d_counters, ctx->d_det, max_pts, ctx->opt.texfrac_bits == 8 ? 1 : 0);
+  Detection *det = ctx->bin_detections ? ctx->d_det_sorted : ctx->d_det;
+  const dim3 grid(points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu), P.nframes);
+  if (ctx->tile_orient) LAUNCH_Q8(orient_all_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
+  else LAUNCH_Q8(orient_all_gather_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
   return ls.finish();
 }
 
@@ -644,9 +1329,32 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
                      const int *pack_offsets, SiftPointD *pack_dst)
 {
   LaunchScope ls(ctx, "descr_all");
-  hipLaunchKernelGGL(descr_all_kernel, dim3(points_grid_x(ctx, P.nframes), P.nframes), dim3(256), 0, ctx->stream,
-                     scratch, P, ctx->d_counters, ctx->d_det, pts, max_pts, ctx->opt.texfrac_bits == 8 ? 1 : 0,
-                     pack_offsets, pack_dst);
+  const Detection *det = ctx->bin_detections ? ctx->d_det_sorted : ctx->d_det;
+  const dim3 grid(points_grid_x(ctx, P.nframes), P.nframes);
+  if (ctx->tile_descr) {
+    // keypoints too large for the LDS window go to a per-frame list in the (by now idle) candidate buffer
+    unsigned big_stride = 0;
+    for (int o = 1; o <= P.noct; o++) big_stride += P.o[o].cand_cap;
+#define DESCR_LAUNCH(Q, O) hipLaunchKernelGGL((descr_all_kernel<Q, O>), grid, dim3(256), 0, ctx->stream, scratch, P, ctx->d_counters, \
+                                              det, pts, max_pts, 0, pack_offsets, pack_dst, ctx->d_cand, big_stride)
+    const bool q8 = ctx->opt.texfrac_bits == 8;
+    if (ctx->descr_occ >= 4) { if (q8) DESCR_LAUNCH(true, 4); else DESCR_LAUNCH(false, 4); }
+    else { if (q8) DESCR_LAUNCH(true, 3); else DESCR_LAUNCH(false, 3); }
+#undef DESCR_LAUNCH
+    LAUNCH_Q8(descr_big_kernel, dim3(2, P.nframes), dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts,
+              pack_offsets, pack_dst, ctx->d_cand, big_stride);
+  } else
+    LAUNCH_Q8(descr_all_gather_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts, 0, pack_offsets,
+              pack_dst);
+  return ls.finish();
+}
+
+int launch_rescale_batch(misift_ctx *ctx, SiftPointD *pts, int max_pts, int nframes, int num_octaves, float scale)
+{
+  LaunchScope ls(ctx, "rescale");
+  const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
+  hipLaunchKernelGGL(rescale_batch_kernel, dim3(16, nframes), dim3(256), 0, ctx->stream, pts, max_pts, ctx->d_counters,
+                     slot, scale);
   return ls.finish();
 }
 

@@ -293,12 +293,15 @@ __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict_
 
 // ------------------------------------------------------------------ ScaleUp
 template <typename SRC>
-__global__ __launch_bounds__(256) void scaleup_kernel(const SRC *__restrict__ src, int w, int h, int spitch,
-                                                      float *__restrict__ dst, int dpitch)
+__global__ __launch_bounds__(256) void scaleup_kernel(const SRC *__restrict__ src0, int w, int h, int spitch,
+                                                      long long src_frame_stride, float *__restrict__ dst0, int dpitch,
+                                                      long long dst_frame_stride)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
+  const SRC *src = src0 + (long long)blockIdx.z * src_frame_stride;          // one grid layer per frame of the batch
+  float *dst = dst0 + (long long)blockIdx.z * dst_frame_stride;
   const int xr = min(x + 1, w - 1), yd = min(y + 1, h - 1);
   const float vul = (float)src[(size_t)y * spitch + x], vur = (float)src[(size_t)y * spitch + xr];
   const float vdl = (float)src[(size_t)yd * spitch + x], vdr = (float)src[(size_t)yd * spitch + xr];
@@ -394,15 +397,17 @@ int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, floa
   return ls.finish();
 }
 
-int launch_scaleup(misift_ctx *ctx, const void *src, int src_u8, int w, int h, int spitch, float *dst, int dpitch)
+int launch_scaleup(misift_ctx *ctx, const void *src, int src_u8, int w, int h, int spitch, long long src_frame_stride,
+                   int nframes, float *dst, int dpitch, long long dst_frame_stride)
 {
   LaunchScope ls(ctx, "scaleup");
-  const dim3 grid((w + 63) / 64, (h + 3) / 4);
+  const dim3 grid((w + 63) / 64, (h + 3) / 4, nframes);
   if (src_u8)
     hipLaunchKernelGGL(scaleup_kernel<unsigned char>, grid, dim3(256), 0, ctx->stream,
-                       static_cast<const unsigned char *>(src), w, h, spitch, dst, dpitch);
+                       static_cast<const unsigned char *>(src), w, h, spitch, src_frame_stride, dst, dpitch,
+                       dst_frame_stride);
   else
     hipLaunchKernelGGL(scaleup_kernel<float>, grid, dim3(256), 0, ctx->stream, static_cast<const float *>(src), w, h,
-                       spitch, dst, dpitch);
+                       spitch, src_frame_stride, dst, dpitch, dst_frame_stride);
   return ls.finish();
 }

@@ -36,6 +36,38 @@ extern "C" const char *misift_last_error(void) { return g_err; }
     }                                                                         \
   } while (0)
 
+// ------------------------------------------------------------------ roctx
+// Named ranges for rocprofv3 --marker-trace / rocprof-sys: one range per entry-point call and one
+// per kernel launch.  The marker library is bound at run time, and only when a profiler has already mapped it into
+// the process or MISIFT_ROCTX=1 asks for it — ordinary runs pay one predictable branch per launch.
+#include <dlfcn.h>
+static int (*g_roctx_push)(const char *) = nullptr;
+static int (*g_roctx_pop)(void) = nullptr;
+static int g_roctx_state = 0;          // 0 = untried, 1 = bound, -1 = off
+static void roctx_bind(void)
+{
+  if (g_roctx_state) return;
+  g_roctx_state = -1;
+  const char *names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+  const char *env = getenv("MISIFT_ROCTX");
+  if (env && atoi(env) == 0) return;
+  void *h = nullptr;
+  for (const char *n : names)
+    if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  if (!h && env && atoi(env) != 0)
+    for (const char *n : names)
+      if (!h) h = dlopen(n, RTLD_NOW);
+  if (!h) return;
+  *(void **)(&g_roctx_push) = dlsym(h, "roctxRangePushA");
+  *(void **)(&g_roctx_pop) = dlsym(h, "roctxRangePop");
+  if (g_roctx_push && g_roctx_pop) g_roctx_state = 1;
+}
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char *name) : on(g_roctx_state > 0) { if (on) g_roctx_push(name); }
+  ~RoctxRange() { if (on) g_roctx_pop(); }
+};
+
 // --------------------------------------------------------------- profiling
 struct PendingProf { int slot; hipEvent_t a, b; };
 // Identity of one synchronous extraction call; a repeated call (the reference demo extracts the same image
@@ -70,6 +102,7 @@ static CtxExtra *extra(misift_ctx *ctx);
 
 LaunchScope::LaunchScope(misift_ctx *c, const char *n) : ctx(c), name(n)
 {
+  if (g_roctx_state > 0) g_roctx_push(n);
   if (ctx->profile) {
     CtxExtra *x = extra(ctx);
     hipEvent_t a, b;
@@ -97,6 +130,7 @@ LaunchScope::LaunchScope(misift_ctx *c, const char *n) : ctx(c), name(n)
 
 int LaunchScope::finish()
 {
+  if (g_roctx_state > 0) g_roctx_pop();
   if (ctx->profile) {
     CtxExtra *x = extra(ctx);
     hipEventRecord(x->pending.back().b, ctx->stream);
@@ -211,6 +245,17 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }
+  ctx->bin_detections = 1;
+  if (const char *e = getenv("MISIFT_BIN")) ctx->bin_detections = atoi(e) != 0;
+  ctx->scan_variant = 0;
+  if (const char *e = getenv("MISIFT_SCAN")) ctx->scan_variant = atoi(e);
+  ctx->descr_occ = 3;
+  if (const char *e = getenv("MISIFT_DESCR_OCC")) ctx->descr_occ = atoi(e);
+  ctx->tile_descr = 1;
+  ctx->tile_orient = 0;
+  if (const char *e = getenv("MISIFT_TILE")) ctx->tile_descr = ctx->tile_orient = atoi(e) != 0;
+  if (const char *e = getenv("MISIFT_TILE_DESCR")) ctx->tile_descr = atoi(e) != 0;
+  if (const char *e = getenv("MISIFT_TILE_ORIENT")) ctx->tile_orient = atoi(e) != 0;
   ctx->orient_blocks_per_cu = 4;
   if (const char *e = getenv("MISIFT_ORIENT_BLOCKS")) ctx->orient_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 4;
   ctx->point_blocks_per_cu = 8;
@@ -228,6 +273,7 @@ extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
 {
   ARG_CHECK(out != nullptr);
   *out = nullptr;
+  roctx_bind();
   int n = misift_device_count();
   if (n <= 0) {
     misift_set_error("no HIP device visible");
@@ -263,6 +309,7 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   if (ctx->h_counters) hipHostFree(ctx->h_counters);
   if (ctx->d_cand) hipFree(ctx->d_cand);
   if (ctx->d_det) hipFree(ctx->d_det);
+  if (ctx->d_det_sorted) hipFree(ctx->d_det_sorted);
   if (ctx->d_own_scratch) hipFree(ctx->d_own_scratch);
   if (ctx->d_match_tmp) hipFree(ctx->d_match_tmp);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -355,8 +402,10 @@ static int ensure_det(misift_ctx *ctx, int nframes, int max_pts)
     const int nf = nframes > ctx->cap_det_frames ? nframes : ctx->cap_det_frames;
     const int mp = max_pts > ctx->det_max_pts ? max_pts : ctx->det_max_pts;
     if (ctx->d_det) HIP_TRY(hipFree(ctx->d_det));
-    ctx->d_det = nullptr; ctx->cap_det_frames = 0; ctx->det_max_pts = 0;
+    if (ctx->d_det_sorted) HIP_TRY(hipFree(ctx->d_det_sorted));
+    ctx->d_det = nullptr; ctx->d_det_sorted = nullptr; ctx->cap_det_frames = 0; ctx->det_max_pts = 0;
     HIP_TRY(hipMalloc((void **)&ctx->d_det, sizeof(Detection) * (size_t)nf * MISIFT_MAX_OCTAVES * mp));
+    HIP_TRY(hipMalloc((void **)&ctx->d_det_sorted, sizeof(Detection) * (size_t)nf * MISIFT_MAX_OCTAVES * mp));
     ctx->alloc_gen++;
     ctx->cap_det_frames = nf;
     ctx->det_max_pts = mp;
@@ -607,13 +656,13 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
                            int width, int height, int pitch, int num_octaves, float init_blur, float thresh,
                            float lowest_scale, int scale_up, float *d_scratch, SiftPointD *pts, int max_pts)
 {
+  RoctxRange range("misift_extract");
   ARG_CHECK(ctx && d_imgs && (pts || (ctx->pack_dst && ctx->opt.fused)));
   ARG_CHECK(nframes >= 1 && width >= 16 && height >= 16 && pitch >= width);
   ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);       // before the shifts below
   ARG_CHECK((width >> (num_octaves - 1)) >= 8 && (height >> (num_octaves - 1)) >= 8);
   ARG_CHECK(max_pts >= 1);
   ARG_CHECK(width * (scale_up ? 2 : 1) < 16384 && height * (scale_up ? 2 : 1) < 16384);
-  ARG_CHECK(!scale_up || nframes == 1);
   HIP_TRY(hipSetDevice(ctx->device));
   // candidate list: pre-candidates of the fused scan (or true extrema of the unfused detect) of ONE
   // octave; sized from the image, not from max_pts (overflow is detected and handled by the callers)
@@ -666,9 +715,10 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     long long pre_stride = frame_stride;
     if (scale_up) {
       float *upImg = memoryTmp;
-      rc = launch_scaleup(ctx, d_imgs, src_u8, width, height, pitch, upImg, L.p);
+      // every frame's up-sampled copy borrows the DoG region of its own arena (cudaSiftH.cu:119-123)
+      rc = launch_scaleup(ctx, d_imgs, src_u8, width, height, pitch, frame_stride, nframes, upImg, L.p, SS);
       if (rc) return rc;
-      pre_src = upImg; pre_u8 = 0; pre_pitch = L.p; pre_frames = 1; pre_stride = SS;
+      pre_src = upImg; pre_u8 = 0; pre_pitch = L.p; pre_frames = nframes; pre_stride = SS;
       lowest_scale *= 2.0f;
     }
     if (num_octaves >= 2 && ctx->opt.fused) {
@@ -689,6 +739,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   std::vector<LaplaceTaps> tapsv(num_octaves + 1);
   if (ctx->opt.fused) {
     P.noct = num_octaves; P.nframes = nframes; P.frame_stride = SS;
+    P.out_scale = scale_up ? 0.5f : 1.0f;             // RescalePositions (cudaSiftH.cu:130) folded into the record write
     unsigned off = 0;
     for (int o = 1; o <= num_octaves; o++) {
       OctaveInfo &L = P.o[o];
@@ -751,6 +802,10 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     }
     rc = launch_refine_all(ctx, d_scratch, P, tapsv.data(), thresh, 10.0f, 1.0f / NUM_SCALES, max_pts);
     if (rc) return rc;
+    if (ctx->bin_detections) {          // spatial order for the per-keypoint kernels (L1/L2 reuse between neighbours)
+      rc = launch_bin_detections(ctx, P, max_pts);
+      if (rc) return rc;
+    }
     rc = launch_orient_all(ctx, d_scratch, P, pts, max_pts);
     if (rc) return rc;
     if (ctx->pack_dst) {                // counts and offsets are known as soon as the orientations are: pack while writing
@@ -779,6 +834,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     rc = launch_descr(ctx, L.img, SS, L.w, L.h, L.p, nframes, subsampling, o, pts, max_pts);
     if (rc) return rc;
   }
+  if (scale_up) return launch_rescale_batch(ctx, pts, max_pts, nframes, num_octaves, 0.5f);      // cudaSiftH.cu:130
   return MISIFT_OK;
 }
 
@@ -910,11 +966,7 @@ extern "C" int misift_extract(misift_ctx *ctx, const float *d_img, int width, in
   int rc = misift_extract_sync(ctx, d_img, 0, 1, 0, width, height, pitch, num_octaves, init_blur, thresh, lowest_scale,
                         scale_up, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
-  if (scale_up) {                                    // cudaSiftH.cu:130
-    rc = launch_rescale(ctx, (SiftPointD *)d_pts, *num_pts_out, 0.5f);
-    if (rc) return rc;
-  }
-  return resolve_profile(ctx);
+  return resolve_profile(ctx);                       // RescalePositions (cudaSiftH.cu:130) is part of the launch sequence
 }
 
 extern "C" int misift_extract_batch(misift_ctx *ctx, const float *d_imgs, int nframes, size_t frame_stride, int width,
@@ -925,6 +977,19 @@ extern "C" int misift_extract_batch(misift_ctx *ctx, const float *d_imgs, int nf
   ARG_CHECK(num_pts_out != nullptr);
   int rc = misift_extract_sync(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch, num_octaves,
                         init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts, max_pts, num_pts_out);
+  if (rc) return rc;
+  return resolve_profile(ctx);
+}
+
+extern "C" int misift_extract_batch_ex(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, size_t frame_stride,
+                                       int width, int height, int pitch, int num_octaves, float init_blur, float thresh,
+                                       float lowest_scale, int scale_up, float *d_scratch, void *d_pts, int max_pts,
+                                       int *num_pts_out)
+{
+  ARG_CHECK(num_pts_out != nullptr);
+  int rc = misift_extract_sync(ctx, d_imgs, src_u8 ? 1 : 0, nframes, (long long)frame_stride, width, height, pitch,
+                               num_octaves, init_blur, thresh, lowest_scale, scale_up ? 1 : 0, d_scratch,
+                               (SiftPointD *)d_pts, max_pts, num_pts_out);
   if (rc) return rc;
   return resolve_profile(ctx);
 }
@@ -1055,7 +1120,7 @@ extern "C" int misift_scaleup(misift_ctx *ctx, const float *d_src, int width, in
 {
   ARG_CHECK(ctx && d_src && d_dst && width > 0 && height > 0 && spitch >= width && dpitch >= 2 * width &&
             (dpitch & 1) == 0);
-  int rc = launch_scaleup(ctx, d_src, 0, width, height, spitch, d_dst, dpitch);
+  int rc = launch_scaleup(ctx, d_src, 0, width, height, spitch, 0, 1, d_dst, dpitch, 0);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return resolve_profile(ctx);
@@ -1164,6 +1229,7 @@ extern "C" int misift_match_rows(misift_ctx *ctx, void *d_pts1, int row_begin, i
   ARG_CHECK(ctx && row_begin >= 0 && row_count >= 0 && n2 >= 0);
   if (row_count == 0 || n2 == 0) return MISIFT_OK;       // matching.cu:1095-1096
   ARG_CHECK(d_pts1 && d_pts2);
+  RoctxRange range("misift_match");
   HIP_TRY(hipSetDevice(ctx->device));
   int rc = launch_match(ctx, (SiftPointD *)d_pts1, row_begin, row_count, (const SiftPointD *)d_pts2, n2);
   if (rc) return rc;

@@ -171,6 +171,14 @@ int misift_extract_batch_u8(misift_ctx *ctx, const unsigned char *d_imgs, int nf
                             float lowest_scale, float *d_scratch, void *d_pts,
                             int max_pts, int *num_pts_out);
 
+/* ExtractSift's whole argument surface over a batch: 8-bit or fp32 frames (src_u8; pitch and frame_stride in source
+ * elements) and scaleUp (cudaSiftH.cu:118-132: every frame is doubled first, lowestScale doubles, positions and
+ * scales are halved at the end).  d_scratch: nframes * misift_scratch_floats(width, height, num_octaves, scale_up). */
+int misift_extract_batch_ex(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, size_t frame_stride,
+                            int width, int height, int pitch, int num_octaves, float init_blur, float thresh,
+                            float lowest_scale, int scale_up, float *d_scratch, void *d_pts, int max_pts,
+                            int *num_pts_out);
+
 /* ------------------------------------------------- host-fed pipeline
  * Streams batches of HOST frames through upload -> extraction -> read-back on three
  * HIP streams, replacing the blocking CudaImage::Download (cudaImage.cu:55-66) and the

@@ -714,3 +714,25 @@ def test_timed_path_16x1080p_packed_async_vs_oracle(ctx):
     assert np.array_equal(counts, counts2) and np.array_equal(offs, offs2) and np.array_equal(counters, counters2)
     for f in range(B):
         assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(recs2[offs[f]:offs[f + 1]]), f
+
+
+def test_extract_batch_scaleup_and_u8(ctx, stereo):
+    """misift_extract_batch_ex: the scaleUp path over a BATCH (the reference applies it per call, cudaSiftH.cu:118-132),
+    fp32 and 8-bit frames — every frame against the oracle's scaleUp extraction."""
+    crops = np.stack([stereo[0][300:540, 400:720], stereo[1][200:440, 100:420], stereo[0][600:840, 800:1120]])
+    f8 = np.clip(np.rint(crops), 0, 255).astype(np.uint8)
+    for imgs in (crops.astype(np.float32), f8):
+        pts, n = ctx.extract_batch_ex(imgs, num_octaves=4, thresh=3.0, scale_up=True, max_pts=8192)
+        for f in range(len(imgs)):
+            ref, nref, cref = orc().extract(imgs[f].astype(np.float32), num_octaves=4, thresh=3.0, scale_up=True, max_pts=8192)
+            assert nref == n[f] and nref > 200, (f, nref, n)
+            compare_points(ref[:nref], pts[f][:n[f]], "extract_batch_scaleup_%s_f%d" % (imgs.dtype.name, f), record)
+    ctx.set_options(fused=0)                         # dense kernels + the batched RescalePositions kernel
+    try:
+        pts2, n2 = ctx.extract_batch_ex(crops.astype(np.float32), num_octaves=4, thresh=3.0, scale_up=True, max_pts=8192)
+    finally:
+        ctx.set_options(fused=1)
+    pts, n = ctx.extract_batch_ex(crops.astype(np.float32), num_octaves=4, thresh=3.0, scale_up=True, max_pts=8192)
+    assert np.array_equal(n, n2)
+    for f in range(len(crops)):
+        assert _canon(pts[f][:n[f]]) == _canon(pts2[f][:n2[f]])
