@@ -13,7 +13,7 @@ HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_
             $(CSRC)/multigpu.hip
 HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
-all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so oracle dropin build/pmc_calib build/valu_rates
+all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so cudasift_amd/libcudasift_managed.so oracle dropin build/pmc_calib build/valu_rates
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
 	@mkdir -p $(BUILD)
@@ -35,6 +35,10 @@ build/valu_rates: tools/valu_rates.hip
 	@mkdir -p $(BUILD)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
 
+# the MANAGEDMEM flavour of the drop-in API (cudaSift.h:27-32: SiftData holds ONE managed pointer, m_data)
+cudasift_amd/libcudasift_managed.so: $(CSRC)/shim_cudasift.cpp include/cudaSift.h include/cudaImage.h include/misift.h cudasift_amd/libmisift.so
+	$(CXX) -O2 -std=c++17 -fPIC -shared -DMANAGEDMEM -Iinclude -o $@ $(CSRC)/shim_cudasift.cpp -Lcudasift_amd -lmisift -Wl,-rpath,'$$ORIGIN'
+
 oracle:
 	$(MAKE) -C oracle all
 
@@ -48,10 +52,13 @@ clean:
 # $(REF) against include/cudaSift.h + libcudasift.so (mini-OpenCV stand-in because OpenCV is absent).
 # Output under oracle/_ref/ (git-ignored, travels to the GPU box).  Skipped where $(REF) is absent.
 REF ?= /root/reference
-dropin: cudasift_amd/libcudasift.so
+dropin: cudasift_amd/libcudasift.so cudasift_amd/libcudasift_managed.so
 	@if [ -f $(REF)/mainSift.cpp ]; then mkdir -p oracle/_ref && \
 	  $(CXX) -O2 -std=c++17 -Iinclude -Icudasift_amd/compat -o oracle/_ref/cudasift_dropin \
 	    $(REF)/mainSift.cpp $(REF)/geomFuncs.cpp -Lcudasift_amd -lcudasift -lmisift \
-	    -Wl,-rpath,'$$ORIGIN/../../cudasift_amd' && echo "built oracle/_ref/cudasift_dropin"; \
+	    -Wl,-rpath,'$$ORIGIN/../../cudasift_amd' && echo "built oracle/_ref/cudasift_dropin" && \
+	  $(CXX) -O2 -std=c++17 -DMANAGEDMEM -Iinclude -Icudasift_amd/compat -o oracle/_ref/cudasift_dropin_managed \
+	    $(REF)/mainSift.cpp $(REF)/geomFuncs.cpp -Lcudasift_amd -lcudasift_managed -lmisift \
+	    -Wl,-rpath,'$$ORIGIN/../../cudasift_amd' && echo "built oracle/_ref/cudasift_dropin_managed"; \
 	else echo "dropin: $(REF) absent, keeping prebuilt binary"; fi
 .PHONY: dropin

@@ -75,6 +75,8 @@ SIGNATURES = {
     "misift_rescale_positions": (_i, [_vp, _vp, _i, _f]),
     "misift_match": (_i, [_vp, _vp, _i, _vp, _i]),
     "misift_match_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
+    "misift_improve_homography": (_i, [_vp, _vp, _i, _fp, _i, _f, _f, _f, _ip]),
+    "misift_malloc_managed": (_i, [_sz, C.POINTER(_vp)]),
     "misift_comm_unique_id": (_i, [_vp]),
     "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "misift_comm_adopt": (_i, [_vp, _vp, C.POINTER(_vp)]),
@@ -413,6 +415,13 @@ class Context:
         check(lib().misift_find_homography(self.h, dpts_ptr, npts, H, C.byref(nm), num_loops, min_score,
                                            max_ambiguity, thresh), "misift_find_homography")
         return np.array(list(H), np.float32).reshape(3, 3), nm.value
+
+    def improve_homography(self, dpts_ptr, npts, H, num_loops=5, min_score=0.0, max_ambiguity=0.80, thresh=3.0):
+        h = (C.c_float * 9)(*[float(v) for v in np.asarray(H, np.float32).reshape(9)])
+        nf = C.c_int(0)
+        check(lib().misift_improve_homography(self.h, dpts_ptr, npts, h, num_loops, min_score, max_ambiguity, thresh,
+                                              C.byref(nf)), "misift_improve_homography")
+        return np.array(list(h), np.float32).reshape(3, 3), nf.value
 
     # ---- profiling
     def profile_enable(self, on=True):

@@ -251,7 +251,6 @@ struct misift_ctx {
   size_t cand_cap;              // entries per frame
   Detection *d_det;             // staging [cap_det_frames][MISIFT_MAX_OCTAVES][det_max_pts] (refine's append order)
   Detection *d_det_sorted;      // the same records binned by 32x32-px tile (what orient_all / descr_all consume)
-  int scan_variant;             // dog_scan_all: 0 = taps from LDS, 1 = taps in SGPRs, 2 = SGPR taps at 4 waves/SIMD (MISIFT_SCAN)
   int descr_occ;                // descr_all_kernel variant: registers held to 3 or 4 waves/SIMD (MISIFT_DESCR_OCC)
   int tile_descr, tile_orient;  // 1 = LDS-staged window in descr_all / orient_all, 0 = bilinear fetches from global memory
                                 // (MISIFT_TILE_DESCR / MISIFT_TILE_ORIENT; MISIFT_TILE sets both)

@@ -311,3 +311,162 @@ extern "C" int misift_find_homography(misift_ctx *ctx, const void *d_pts, int np
   memcpy(num_matches, &h_result[8], sizeof(int));
   return MISIFT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// ImproveHomography on the device (reference geomFuncs.cpp:6-72, a HOST function there: it walks
+// SiftData.h_data).  Same arithmetic as oracle orc_improve_homography — which is pinned bit for bit against the
+// reference's own geomFuncs.cpp — and the same summation ORDER: the 36 distinct entries of the symmetric 8x8 normal
+// matrix and the 8 entries of the right-hand side each belong to one lane, and every lane walks the points in index
+// order, so each double-precision sum is accumulated exactly as the reference's sequential loop accumulates it.  The
+// problem is tiny (a few thousand points, 5 loops); what the device version buys is that the records never leave HBM.
+namespace {
+
+struct ImproveArgs {
+  const SiftPointD *pts;
+  int npts, num_loops;
+  float min_score, max_ambiguity, limit;
+  double a0[8];
+};
+
+__device__ __forceinline__ double pick8(int k, double v0, double v1, double v2, double v3, double v4, double v5, double v6,
+                                        double v7)
+{
+  double r = v0;
+  r = k == 1 ? v1 : r; r = k == 2 ? v2 : r; r = k == 3 ? v3 : r; r = k == 4 ? v4 : r;
+  r = k == 5 ? v5 : r; r = k == 6 ? v6 : r; r = k == 7 ? v7 : r;
+  return r;
+}
+
+__global__ __launch_bounds__(64) void improve_homography_kernel(ImproveArgs P, SiftPointD *__restrict__ pts_rw,
+                                                                float *__restrict__ result)
+{
+  __shared__ double s_M[64], s_X[8], s_A[8];
+  const int lane = threadIdx.x;
+  // lane -> accumulator: lanes 0..35 = M[r][c] for r <= c (row-major upper triangle), lanes 36..43 = X[r]
+  int r = 0, c = 0;
+  bool is_m = lane < 36, is_x = lane >= 36 && lane < 44;
+  if (is_m) {
+    int k = lane;
+    for (r = 0; r < 8; r++) {
+      const int len = 8 - r;
+      if (k < len) { c = r + k; break; }
+      k -= len;
+    }
+  } else if (is_x) {
+    r = lane - 36;
+  }
+  if (lane < 8) s_A[lane] = P.a0[lane];
+  __syncthreads();
+  for (int loop = 0; loop < P.num_loops; loop++) {
+    const double A0 = s_A[0], A1 = s_A[1], A2 = s_A[2], A3 = s_A[3], A4 = s_A[4], A5 = s_A[5], A6 = s_A[6], A7 = s_A[7];
+    double acc = 0.0;
+    for (int i = 0; i < P.npts; i++) {
+      const SiftPointD &pt = P.pts[i];
+      const float x = pt.xpos, y = pt.ypos, mx = pt.match_xpos, my = pt.match_ypos;
+      if (pt.score < P.min_score || pt.ambiguity > P.max_ambiguity) continue;
+      const float den = A6 * x + A7 * y + 1.0f;
+      const float dx = (A0 * x + A1 * y + A2) / den - mx;
+      const float dy = (A3 * x + A4 * y + A5) / den - my;
+      const float err = dx * dx + dy * dy;
+      const float wei = (err < P.limit ? 1.0f : 0.0f);
+      const double xd = x, yd = y;
+      const double p6 = -x * mx, p7 = -y * mx, q6 = -x * my, q7 = -y * my;      // float products, then widened
+      // Y1 = (x, y, 1, 0, 0, 0, p6, p7), Y2 = (0, 0, 0, x, y, 1, q6, q7)
+      const double y1r = pick8(r, xd, yd, 1.0, 0.0, 0.0, 0.0, p6, p7), y2r = pick8(r, 0.0, 0.0, 0.0, xd, yd, 1.0, q6, q7);
+      if (is_m) {
+        const double y1c = pick8(c, xd, yd, 1.0, 0.0, 0.0, 0.0, p6, p7), y2c = pick8(c, 0.0, 0.0, 0.0, xd, yd, 1.0, q6, q7);
+        acc += (y1c * y1r * wei);
+        acc += (y2c * y2r * wei);
+      } else if (is_x) {
+        acc += y1r * mx * wei;
+        acc += y2r * my * wei;
+      }
+    }
+    if (is_m) { s_M[r * 8 + c] = acc; s_M[c * 8 + r] = acc; }
+    if (is_x) s_X[r] = acc;
+    __syncthreads();
+    if (lane == 0) {                                    // cv::solve(M, X, A, DECOMP_CHOLESKY), geomFuncs.cpp:55
+      double L[64], B[8];
+      for (int k = 0; k < 64; k++) L[k] = s_M[k];
+      for (int k = 0; k < 8; k++) B[k] = s_X[k];
+      bool ok = true;
+      for (int i = 0; i < 8 && ok; i++)
+        for (int j = 0; j <= i; j++) {
+          double s = L[i * 8 + j];
+          for (int k = 0; k < j; k++) s -= L[i * 8 + k] * L[j * 8 + k];
+          if (i == j) {
+            if (!(s > 0)) { ok = false; break; }
+            L[i * 8 + i] = sqrt(s);
+          } else {
+            L[i * 8 + j] = s / L[j * 8 + j];
+          }
+        }
+      if (ok) {
+        for (int i = 0; i < 8; i++) {
+          double s = B[i];
+          for (int k = 0; k < i; k++) s -= L[i * 8 + k] * B[k];
+          B[i] = s / L[i * 8 + i];
+        }
+        for (int i = 7; i >= 0; i--) {
+          double s = B[i];
+          for (int k = i + 1; k < 8; k++) s -= L[k * 8 + i] * B[k];
+          B[i] = s / L[i * 8 + i];
+        }
+        for (int k = 0; k < 8; k++) s_A[k] = B[k];
+      }
+    }
+    __syncthreads();
+  }
+  const double A0 = s_A[0], A1 = s_A[1], A2 = s_A[2], A3 = s_A[3], A4 = s_A[4], A5 = s_A[5], A6 = s_A[6], A7 = s_A[7];
+  int numfit = 0;
+  for (int i = lane; i < P.npts; i += 64) {
+    SiftPointD &pt = pts_rw[i];
+    const float x = pt.xpos, y = pt.ypos;
+    const float den = A6 * x + A7 * y + 1.0;
+    const float dx = (A0 * x + A1 * y + A2) / den - pt.match_xpos;
+    const float dy = (A3 * x + A4 * y + A5) / den - pt.match_ypos;
+    const float err = dx * dx + dy * dy;
+    if (err < P.limit) numfit++;
+    pt.match_error = sqrtf(err);
+  }
+  for (int m = 32; m > 0; m >>= 1) numfit += __shfl_xor(numfit, m, 64);
+  if (lane < 8) result[lane] = (float)s_A[lane];
+  if (lane == 0) {
+    result[8] = 1.0f;
+    reinterpret_cast<int *>(result)[9] = numfit;
+  }
+}
+
+}  // namespace
+
+extern "C" int misift_improve_homography(misift_ctx *ctx, void *d_pts, int npts, float *homography, int num_loops,
+                                         float min_score, float max_ambiguity, float thresh, int *num_fit)
+{
+  if (!ctx || !homography || !num_fit || num_loops < 0 || npts < 0) {
+    misift_set_error("misift_improve_homography: invalid argument");
+    return MISIFT_EINVAL;
+  }
+  *num_fit = 0;
+  if (!d_pts) return MISIFT_OK;                                    // geomFuncs.cpp:11-12
+  int rc = misift_ensure_tmp(ctx, 64 * sizeof(float));
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  ImproveArgs P;
+  P.pts = (const SiftPointD *)d_pts;
+  P.npts = npts; P.num_loops = num_loops;
+  P.min_score = min_score; P.max_ambiguity = max_ambiguity; P.limit = thresh * thresh;
+  for (int i = 0; i < 8; i++) P.a0[i] = homography[i] / homography[8];      // float division (geomFuncs.cpp:20-21)
+  float *result = reinterpret_cast<float *>(ctx->d_match_tmp);
+  {
+    LaunchScope ls(ctx, "improve_homography");
+    hipLaunchKernelGGL(improve_homography_kernel, dim3(1), dim3(64), 0, ctx->stream, P, (SiftPointD *)d_pts, result);
+    rc = ls.finish();
+    if (rc) return rc;
+  }
+  float h[10];
+  HIP_TRY(hipMemcpyAsync(h, result, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  memcpy(homography, h, 9 * sizeof(float));
+  memcpy(num_fit, &h[9], sizeof(int));
+  return MISIFT_OK;
+}

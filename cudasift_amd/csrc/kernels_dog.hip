@@ -405,20 +405,12 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
 // Keeping only the current DoG row in registers (no 3-row window, no box minima) leaves the
 // kernel at ~1/2 the registers and ~1/3 the instructions of a full in-register 3x3x3 test.
 // One wavefront's strip/segment of the fused DoG scan (see dog_scan_kernel above for the method).
-// Tap pairs of the three scale pairs, from LDS (re-read every row) or from scalar registers (30 SGPRs: frees the 20
-// VGPRs the double-buffered LDS reads need and the 15 ds_read_b64 + waits per row).
+// Tap pairs of the three scale pairs, re-read from LDS every row.  (Keeping them in scalar registers instead — 30 SGPRs,
+// 140 instead of 168 VGPRs, 4 waves/SIMD within reach — does not work: hipcc folds the SGPR pair straight into
+// v_pk_fma_f32 with op_sel_hi set, and gfx950 reads the LOW dword of an SGPR source for both halves.  r02: wrong blurs.)
 struct LdsTaps {
   const v2f *tk;
   __device__ __forceinline__ Taps2 pair(int p) const { return load_taps2(tk + 5 * p); }
-};
-struct RegTaps {
-  v2f k[NUM_SCAN_PAIRS * 5];
-  __device__ __forceinline__ Taps2 pair(int p) const
-  {
-    Taps2 t;
-    t.k0 = k[5 * p]; t.k1 = k[5 * p + 1]; t.k2 = k[5 * p + 2]; t.k3 = k[5 * p + 3]; t.k4 = k[5 * p + 4];
-    return t;
-  }
 };
 
 template <bool FAST, typename TAPS>
@@ -576,11 +568,8 @@ struct ScanAllGeom {
 #ifndef SCAN_OCC
 #define SCAN_OCC 3
 #endif
-// STAPS: tap pairs in scalar registers instead of LDS; OCC: waves per SIMD the register allocation is held to
-// (tools/valu_rates: a SIMD issues one VALU instruction per 2 cycles only with >= 4 resident wavefronts, one per
-// 8/W cycles with W < 4 — the scan is VALU-issue-bound, so 3 -> 4 wavefronts is worth up to a third).
-template <bool FAST, bool STAPS, int OCC>
-__global__ __launch_bounds__(256, OCC) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
+template <bool FAST>
+__global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
                                                               AllTaps taps, float thresh,
                                                               unsigned *__restrict__ counters,
                                                               unsigned *__restrict__ cand)
@@ -603,29 +592,16 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_all_kernel(const float *__r
   const long long r = item / L.nsegs;
   const int strip = (int)(r % L.nstrips);
   const int frame = (int)(r / L.nstrips);
+  // this wavefront's private copy of its octave's tap pairs
+  if (lane < NUM_SCAN_PAIRS * 5) s_taps[wave][lane] = scan_pair_tap(taps.t[L.octave], lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int q = strip * (OUT_LANES - 2) + lane - 2;
   const int y0 = seg * L.seg_rows;
-  if (STAPS) {
-    RegTaps rt;
-#pragma unroll
-    for (int i = 0; i < NUM_SCAN_PAIRS * 5; i++) {
-      const v2f t = scan_pair_tap(taps.t[L.octave], i);           // wave-uniform kernel-argument loads
-      rt.k[i] = mk2(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.x))),
-                    __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.y))));
-    }
-    scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
-                     min(y0 + L.seg_rows, L.h), rt, thresh, counters + (size_t)frame * CNT_STRIDE,
-                     cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
-  } else {
-    // this wavefront's private copy of its octave's tap pairs
-    if (lane < NUM_SCAN_PAIRS * 5) s_taps[wave][lane] = scan_pair_tap(taps.t[L.octave], lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
-                     min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, counters + (size_t)frame * CNT_STRIDE,
-                     cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
-  }
+  scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
+                   min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, counters + (size_t)frame * CNT_STRIDE,
+                   cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
 }
 
 // ------------------------------------------------------------------- refine
@@ -1043,13 +1019,12 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
   const AllTaps at = pack_taps(taps, P.noct);
   const dim3 grid((unsigned)((items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
   LaunchScope ls(ctx, "dog_scan");
-#define SCAN_LAUNCH(F, S, O) hipLaunchKernelGGL((dog_scan_all_kernel<F, S, O>), grid, dim3(256), 0, ctx->stream, scratch, G, at, \
-                                                thresh, ctx->d_counters, ctx->d_cand)
-  if (!fast) SCAN_LAUNCH(false, false, SCAN_OCC);
-  else if (ctx->scan_variant == 2) SCAN_LAUNCH(true, true, 4);       // taps in SGPRs, 128 VGPRs -> 4 waves/SIMD
-  else if (ctx->scan_variant == 1) SCAN_LAUNCH(true, true, SCAN_OCC);
-  else SCAN_LAUNCH(true, false, SCAN_OCC);
-#undef SCAN_LAUNCH
+  if (fast)
+    hipLaunchKernelGGL(dog_scan_all_kernel<true>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
+                       ctx->d_counters, ctx->d_cand);
+  else
+    hipLaunchKernelGGL(dog_scan_all_kernel<false>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
+                       ctx->d_counters, ctx->d_cand);
   return ls.finish();
 }
 

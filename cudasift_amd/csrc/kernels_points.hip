@@ -26,11 +26,40 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float wave_sum(float v)
+// Wave-wide reductions on the DPP path (quad_perm / row_half_mirror / row_mirror / row_bcast15 / row_bcast31): six
+// full-rate VALU instructions with VALU latency.  The __shfl_xor butterfly they replace compiles to ds_bpermute_b32 —
+// six dependent trips through the LDS crossbar, ~100 cycles each, on the critical path of every keypoint.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v)          // lanes outside ROW_MASK (and invalid sources) receive 0
 {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+#define DPP_QUAD_XOR1 0xB1        // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E        // quad_perm:[2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_BCAST15 0x142     // lane 15 of every row -> all lanes of the next row
+#define DPP_ROW_BCAST31 0x143     // lane 31 -> all lanes of rows 2 and 3
+
+__device__ __forceinline__ float wave_sum(float v)         // sum over the 64 lanes, returned in every lane
+{
+  v += dpp_f<DPP_QUAD_XOR1, 0xf>(v);
+  v += dpp_f<DPP_QUAD_XOR2, 0xf>(v);
+  v += dpp_f<DPP_ROW_HALF_MIRROR, 0xf>(v);
+  v += dpp_f<DPP_ROW_MIRROR, 0xf>(v);                     // every lane: sum of its 16-lane row
+  v += dpp_f<DPP_ROW_BCAST15, 0xa>(v);                    // rows 1, 3 += row 0, 2
+  v += dpp_f<DPP_ROW_BCAST31, 0xc>(v);                    // rows 2, 3 += rows 0 + 1: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// maximum over lanes 0..31 of non-negative values (lanes 32..63 must hold 0), returned in every lane
+__device__ __forceinline__ float wave_max32_nonneg(float v)
+{
+  v = fmaxf(v, dpp_f<DPP_QUAD_XOR1, 0xf>(v));
+  v = fmaxf(v, dpp_f<DPP_QUAD_XOR2, 0xf>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR, 0xf>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_MIRROR, 0xf>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_BCAST15, 0xa>(v));           // row 1 = max(row 0, row 1): lane 31 holds the maximum of 0..31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
 }
 
 // ---------------------------------------------------------------- LDS-staged image patch
@@ -91,6 +120,20 @@ __device__ __forceinline__ void patch_fetch(const float *img, int w, int h, int 
                                             int lane, float (&R)[PATCH_LOADS])
 {
   const PatchLane pl = patch_lane(lane);      // recomputed per keypoint (20 VALU): ten registers less across the main loop
+  if (g.x0 >= 0 && g.y0 >= 0 && g.x0 + PW <= w && g.y0 + PW <= h) {
+    // the whole window lies inside the image (the usual case): no clamps; the five lane offsets r_j*pitch + c_j are
+    // all the vector arithmetic there is — the window origin and the 8-row steps are scalar and ride in the base
+    unsigned lo[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) lo[j] = (__umul24((unsigned)pl.r[j], (unsigned)pitch) + (unsigned)pl.c[j]) * 4u;
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+      const char *base = reinterpret_cast<const char *>(img + (size_t)(g.y0 + 8 * m) * pitch + g.x0);   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 5; j++) R[5 * m + j] = *reinterpret_cast<const float *>(base + lo[j]);
+    }
+    return;
+  }
   unsigned col[5];
 #pragma unroll
   for (int j = 0; j < 5; j++) col[j] = (unsigned)clampi(g.x0 + pl.c[j], 0, w - 1);
@@ -165,17 +208,11 @@ __device__ __forceinline__ OrientResult orient_finish(float *hist, const float2 
     const float v = hist[32 + t];
     pk = (v > hist[32 + x1m] && v >= hist[32 + x1p] ? v : 0.0f);
   }
-  float maxval1 = pk;
-#pragma unroll
-  for (int m = 16; m > 0; m >>= 1) maxval1 = fmaxf(maxval1, __shfl_xor(maxval1, m, 64));
-  maxval1 = __shfl(maxval1, 0, 64);
+  const float maxval1 = wave_max32_nonneg(pk);            // pk >= 0 everywhere, 0 in lanes 32..63
   const unsigned long long b1 = __ballot(lane < 32 && pk == maxval1 && maxval1 > 0.0f);
   const int i1 = b1 ? __ffsll((long long)b1) - 1 : -1;
   const float pk2 = lane == i1 ? 0.0f : pk;
-  float maxval2 = pk2;
-#pragma unroll
-  for (int m = 16; m > 0; m >>= 1) maxval2 = fmaxf(maxval2, __shfl_xor(maxval2, m, 64));
-  maxval2 = __shfl(maxval2, 0, 64);
+  const float maxval2 = wave_max32_nonneg(pk2);
   const unsigned long long b2 = __ballot(lane < 32 && pk2 == maxval2 && maxval2 > 0.0f);
   const int i2 = b2 ? __ffsll((long long)b2) - 1 : -1;
   OrientResult r;
@@ -374,12 +411,32 @@ __global__ __launch_bounds__(256) void orient_kernel(const float *__restrict__ b
 }
 
 // -------------------------------------------------------------- descriptors
+// sin / cos of the descriptor rotation, theta in [0, 2 pi]: the SAME written-out expression as oracle det_sincos()
+// (Cody-Waite reduction by pi/2, cephes minimax kernels as fmaf chains; 1 ulp) — so the sample coordinates, and with
+// them every 8-bit texture weight, are bit-identical to the oracle's; ~25 VALU instead of the ~150 of sinf + cosf.
+__device__ __forceinline__ void det_sincos(float x, float &sn, float &cs)
+{
+  const float kf = rintf(x * 0.636619747f);
+  float r = __builtin_fmaf(kf, -1.57079625f, x);
+  r = __builtin_fmaf(kf, -7.54978942e-08f, r);
+  const float z = r * r;
+  float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+  const float s = __builtin_fmaf(ps * z, r, r);
+  float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+  const float c = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  const int q = (int)kf & 3;
+  const float s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  sn = (q & 2) ? -s1 : s1;
+  cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 __device__ __forceinline__ float fast_atan2(float y, float x)
 {
   const float absx = fabsf(x), absy = fabsf(y);
   const float mx = fmaxf(absx, absy), mn = fminf(absx, absy);
-  if (mx == 0.0f) return 0.0f;
-  const float a = mn / mx;
+  const float a = mx == 0.0f ? 0.0f : mn / mx;         // (0,0) -> angle 0, as a select: no divergent branch
   const float s = a * a;
   float r = ((-0.0464964749f * s + 0.15931422f) * s - 0.327622764f) * s * a + a;
   r = (absy > absx ? 1.57079637f - r : r);
@@ -489,8 +546,8 @@ __device__ __forceinline__ void descr_core(const float *img, int w, int h, int p
   // table slot of sample (tx,y) is (y+2)*20 + tx+2, the footprint of cell (cx,cy) starts at sample (4cx-2, 4cy-2)
   const float *mine = tbl + (lane & 3) * SMP_PLANE + (4 * cy) * SMP_W + 4 * cx;
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
-  const float sina = sinf(theta);
-  const float cosa = cosf(theta);
+  float sina, cosa;
+  det_sincos(theta, sina, cosa);
   const float scale = 12.0f / 16.0f * pscale;
   const float ssina = scale * sina;
   const float scosa = scale * cosa;
@@ -752,41 +809,37 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
 }
 
 // Phase 1 of the descriptor from the staged tile: this lane's 4 of the 256 rotated samples -> the two votes of each
-// (iangf*grad into angle bin angi, angf*grad into bin angi+1) and angi itself; two samples per trip of a rolled loop.
+// (iangf*grad into angle bin angi, angf*grad into bin angi+1) and angi itself.  ONE sample per trip of a rolled loop:
+// four bilinear fetches (8 ds_read2_b32) in flight are what fits beside the prefetched window at 4 waves/SIMD.
 __device__ __forceinline__ void descr_samples_tile(const float *tile, int x0, int y0, bool q8, float px, float py,
                                                    float sina, float cosa, float ssina, float scosa,
                                                    const float *gauss, int lane, float (&vx)[4], float (&vy)[4],
                                                    int (&ang)[4])
 {
-#pragma unroll 1
-  for (int half = 0; half < 2; half++) {
-    float tvx[2], tvy[2];
-    int ta[2];
+  const int tx = lane & 15;
+  const float fx = tx - 7.5f, gx = gauss[tx];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int id = lane + 64 * (2 * half + j);
-      const int tx = id & 15, y = id >> 4;
-      const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
-      const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
-      const float dx = tex2d_tile<PW>(tile, x0, y0, xpos + cosa, ypos + sina, q8) -
-                       tex2d_tile<PW>(tile, x0, y0, xpos - cosa, ypos - sina, q8);
-      const float dy = tex2d_tile<PW>(tile, x0, y0, xpos - sina, ypos + cosa, q8) -
-                       tex2d_tile<PW>(tile, x0, y0, xpos + sina, ypos - cosa, q8);
-      const float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
-      float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
-      const int angi = (int)angf;
-      angf -= angi;
-      tvx[j] = (1.0f - angf) * grad;
-      tvy[j] = angf * grad;
-      ta[j] = angi;
-    }
-    if (half == 0) {
-      vx[0] = tvx[0]; vy[0] = tvy[0]; ang[0] = ta[0];
-      vx[1] = tvx[1]; vy[1] = tvy[1]; ang[1] = ta[1];
-    } else {
-      vx[2] = tvx[0]; vy[2] = tvy[0]; ang[2] = ta[0];
-      vx[3] = tvx[1]; vy[3] = tvy[1]; ang[3] = ta[1];
-    }
+  for (int j = 0; j < 4; j++) { vx[j] = 0.0f; vy[j] = 0.0f; ang[j] = 0; }     // defined before the selects below read them
+#pragma unroll 1
+  for (int j = 0; j < 4; j++) {
+    const int y = (lane >> 4) + 4 * j;
+    const float fy = y - 7.5f;
+    const float xpos = px + fx * scosa - fy * ssina + 0.5f;
+    const float ypos = py + fx * ssina + fy * scosa + 0.5f;
+    const float dx = tex2d_tile<PW>(tile, x0, y0, xpos + cosa, ypos + sina, q8) -
+                     tex2d_tile<PW>(tile, x0, y0, xpos - cosa, ypos - sina, q8);
+    const float dy = tex2d_tile<PW>(tile, x0, y0, xpos - sina, ypos + cosa, q8) -
+                     tex2d_tile<PW>(tile, x0, y0, xpos + sina, ypos - cosa, q8);
+    const float grad = gauss[y] * gx * sqrtf(dx * dx + dy * dy);
+    float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+    const int angi = (int)angf;
+    angf -= angi;
+    const float tvx = (1.0f - angf) * grad, tvy = angf * grad;
+    // the rolled loop cannot index registers dynamically: the trip's results go to their named slot by selects
+    vx[0] = j == 0 ? tvx : vx[0]; vy[0] = j == 0 ? tvy : vy[0]; ang[0] = j == 0 ? angi : ang[0];
+    vx[1] = j == 1 ? tvx : vx[1]; vy[1] = j == 1 ? tvy : vy[1]; ang[1] = j == 1 ? angi : ang[1];
+    vx[2] = j == 2 ? tvx : vx[2]; vy[2] = j == 2 ? tvy : vy[2]; ang[2] = j == 2 ? angi : ang[2];
+    vx[3] = j == 3 ? tvx : vx[3]; vy[3] = j == 3 ? tvy : vy[3]; ang[3] = j == 3 ? angi : ang[3];
   }
 }
 
@@ -937,9 +990,13 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
                                                         SiftPointD *__restrict__ pack_dst,
                                                         unsigned *__restrict__ big_list, unsigned big_stride)
 {
-  __shared__ __attribute__((aligned(16))) float s_buf[WAVES_PER_BLOCK][PATCH_FLOATS];      // window, then vote table
-  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
-  __shared__ float s_park[WAVES_PER_BLOCK][12 * 64];       // votes of a first orientation while the second is sampled
+  // one LDS record per wavefront, so that every access is one lane-offset register plus an immediate offset
+  struct alignas(16) WaveLds {
+    float buf[PATCH_FLOATS];      // window, then vote table
+    float park[12 * 64];          // votes of a first orientation while the second is sampled
+    float gauss[16];
+  };
+  __shared__ WaveLds s_w[WAVES_PER_BLOCK];
   static_assert(PATCH_FLOATS == 4 * SMP_PLANE, "the window and the four vote planes share one buffer");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.y;
@@ -950,9 +1007,9 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
   const int pack_off = pack_dst ? __builtin_amdgcn_readfirstlane(pack_offsets[frame]) : 0;
   const unsigned pack_cnt = pack_dst ? (unsigned)(__builtin_amdgcn_readfirstlane(pack_offsets[frame + 1]) - pack_off) : 0u;
   const bool q8 = Q8;          // compile-time: no per-fetch branch on the weight quantisation
-  float *buf = s_buf[wave];
-  const float *gauss = s_gauss[wave];
-  if (lane < 16) s_gauss[wave][lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
+  float *buf = s_w[wave].buf;
+  const float *gauss = s_w[wave].gauss;
+  if (lane < 16) s_w[wave].gauss[lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
   // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
   if (blockIdx.x == 0 && threadIdx.x == 0) {             // publish the reference's counters (cudaSiftD.cu:14)
     unsigned b = 0;
@@ -970,43 +1027,59 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
   auto ndet = [&](int k) -> int {
     return (int)min(__builtin_amdgcn_readfirstlane(cnt[CNT_DET + k]), (unsigned)max_pts);
   };
-  auto advance = [&](int &o, int &i, int by) -> bool {      // false: past the last keypoint
+  // `lim` = number of keypoints of octave o, carried along with (o, i): the counters are read from memory only when
+  // an octave is exhausted.  (Reading them on every call put a global load + s_waitcnt vmcnt(0) right behind the
+  // window prefetch of the next keypoint — vmcnt retires in order, so every keypoint waited for its successor's
+  // window: r02 SQ counters, a third of the wavefronts' lifetime in s_waitcnt.)
+  auto advance = [&](int &o, int &i, int &lim, int by) -> bool {      // false: past the last keypoint
     i += by;
-    while (o <= P.noct) {
-      const int n = ndet(o);
-      if (i < n) return true;
-      i -= n;
+    while (i >= lim) {
+      i -= lim;
       o++;
+      if (o > P.noct) return false;
+      lim = ndet(o);
     }
-    return false;
+    return true;
   };
   // three-deep software pipeline over this wavefront's keypoints:
   //   Detection record of keypoint n+2 | window of keypoint n+1 (global -> registers) | keypoint n (LDS)
-  int o = 1, i = 0, o1, i1, o2, i2;
-  bool more = advance(o, i, __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave));
+  int o = 1, i = 0, lim = ndet(1), o1, i1, lim1, o2, i2, lim2;
+  bool more = advance(o, i, lim, __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave));
   if (!more) return;
-  o1 = o; i1 = i;
-  bool more1 = advance(o1, i1, stride);
-  o2 = o1; i2 = i1;
-  Detection d = fdet[(size_t)(o - 1) * max_pts + i], d1 = d, d2 = d;
-  if (more1) d1 = fdet[(size_t)(o1 - 1) * max_pts + i1];
-  PatchGeom g = patch_geom(d.xpos, d.ypos, d.scale, P.o[o].w, P.o[o].h), g1 = g;
+  o1 = o; i1 = i; lim1 = lim;
+  bool more1 = advance(o1, i1, lim1, stride);
+  o2 = o1; i2 = i1; lim2 = lim1;
+  // of the keypoints ahead only the first 16 bytes of the record (xpos, ypos, scale: what the window needs) are held;
+  // the full record is (re)loaded when the keypoint becomes current — scalar loads, the line is in the scalar cache
+  auto head = [&](int oo, int ii) -> float4 {
+    const Detection &r = fdet[(size_t)(oo - 1) * max_pts + ii];      // uniform address: scalar loads
+    return make_float4(r.xpos, r.ypos, r.scale, 0.0f);
+  };
+  float4 h0 = head(o, i), h1 = h0, h2 = h0;
+  if (more1) h1 = head(o1, i1);
+  PatchGeom g = patch_geom(h0.x, h0.y, h0.z, P.o[o].w, P.o[o].h), g1 = g;
   float R[PATCH_LOADS];
   if (g.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + P.o[o].img_off, P.o[o].w, P.o[o].h, P.o[o].p, g, lane, R);
   int cur_o = 0;
   unsigned bdet = 0, bdup = 0;                            // segment bases of octave cur_o in the reference layout
   while (more) {
     const float subsampling = P.o[o].subsampling;
+    const Detection d = fdet[(size_t)(o - 1) * max_pts + i];
     if (g.fits) patch_store(buf, lane, R);
     wave_sync();
-    // ---- keypoint n+1: window loads into the registers just drained; keypoint n+2: its record
+    // ---- keypoint n+1: window loads into the registers just drained; keypoint n+2: the head of its record
+    // (lane_i: the lane id behind an opaque barrier, so that the dozen lane-only address terms of the window fetch and
+    //  of the clear below are recomputed here — a few VALU — instead of being hoisted out of the loop and SPILLED: a
+    //  scratch reload is a VMEM operation, and waiting for it means waiting for the whole prefetch in front of it)
+    int lane_i = lane;
+    asm volatile("" : "+v"(lane_i));
     if (more1) {
       const OctaveInfo &L1 = P.o[o1];
-      g1 = patch_geom(d1.xpos, d1.ypos, d1.scale, L1.w, L1.h);
-      if (g1.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + L1.img_off, L1.w, L1.h, L1.p, g1, lane, R);
+      g1 = patch_geom(h1.x, h1.y, h1.z, L1.w, L1.h);
+      if (g1.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + L1.img_off, L1.w, L1.h, L1.p, g1, lane_i, R);
     }
-    const bool more2 = more1 && advance(o2, i2, stride);
-    if (more2) d2 = fdet[(size_t)(o2 - 1) * max_pts + i2];
+    const bool more2 = more1 && advance(o2, i2, lim2, stride);
+    if (more2) h2 = head(o2, i2);
     // ---- keypoint n
     if (o != cur_o) {                                     // octave changed: segment bases (cudaSiftD.cu:1297-1300)
       unsigned b = 0;
@@ -1032,7 +1105,7 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
       int ang[4];
       const float scale = 12.0f / 16.0f * d.scale;
       const int nori = (doA ? 1 : 0) + (doB ? 1 : 0);
-      float *park = s_park[wave] + lane;
+      float *park = s_w[wave].park + lane;
       // sampling: the orientation(s) to do, first then second (ONE copy of the sampling code: rolled loop)
 #pragma unroll 1
       for (int k = 0; k < nori; k++) {
@@ -1045,14 +1118,16 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
           }
         }
         const float theta = 2.0f * 3.1415f / 360.0f * ((k == 0 && doA) ? d.ori1 : d.ori2);
-        const float sina = sinf(theta), cosa = cosf(theta);
+        float sina, cosa;
+        det_sincos(theta, sina, cosa);
         descr_samples_tile(buf, g.x0, g.y0, q8, d.xpos, d.ypos, sina, cosa, scale * sina, scale * cosa, gauss, lane, vx, vy, ang);
       }
       wave_sync();                                        // every lane is done with the window
+      {                                                   // the same 1600 floats become the (all-zero) vote table:
+        float *z = buf + 4 * lane_i;                      // 6 x b128 (1536 floats) + 1 x b32 (64), immediate offsets
 #pragma unroll
-      for (int k = 0; k < 7; k++) {                       // the same 1600 floats become the (all-zero) vote table
-        const int q = lane + 64 * k;
-        if (q < PATCH_FLOATS / 4) *reinterpret_cast<float4 *>(buf + 4 * q) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < 6; k++) *reinterpret_cast<float4 *>(z + 256 * k) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        buf[1536 + lane_i] = 0.0f;
       }
       wave_sync();
       // accumulation: the orientation sampled last first (its votes are in registers), then the parked one
@@ -1074,8 +1149,9 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
       }
     }
     wave_sync();                                          // the buffer is free (and all zero or about to be overwritten)
-    more = more1; o = o1; i = i1; d = d1; g = g1;
-    more1 = more2; o1 = o2; i1 = i2; d1 = d2;
+    more = more1; o = o1; i = i1; g = g1;
+    more1 = more2; o1 = o2; i1 = i2; h1 = h2;
+    (void)lim; (void)lim1;
   }
 }
 
@@ -1125,8 +1201,10 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
 
 // ---- the r01 forms of the two merged-octave kernels: bilinear fetches straight from global memory (no staged
 // tile), 4 waves/SIMD.  Selected with MISIFT_TILE=0 (A/B measurements).
+// 90 VGPRs: 5 waves/SIMD (the kernel is bound by the dependent LDS / shuffle chain of one keypoint per wavefront, so
+// every extra resident wavefront helps)
 template <bool Q8>
-__global__ __launch_bounds__(256) void orient_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
+__global__ __launch_bounds__(256, 5) void orient_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                          unsigned *__restrict__ counters,
                                                          Detection *__restrict__ det, int max_pts, int frac8)
 {

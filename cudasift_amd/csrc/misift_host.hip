@@ -247,8 +247,6 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   }
   ctx->bin_detections = 1;
   if (const char *e = getenv("MISIFT_BIN")) ctx->bin_detections = atoi(e) != 0;
-  ctx->scan_variant = 0;
-  if (const char *e = getenv("MISIFT_SCAN")) ctx->scan_variant = atoi(e);
   ctx->descr_occ = 3;
   if (const char *e = getenv("MISIFT_DESCR_OCC")) ctx->descr_occ = atoi(e);
   ctx->tile_descr = 1;
@@ -256,8 +254,8 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_TILE")) ctx->tile_descr = ctx->tile_orient = atoi(e) != 0;
   if (const char *e = getenv("MISIFT_TILE_DESCR")) ctx->tile_descr = atoi(e) != 0;
   if (const char *e = getenv("MISIFT_TILE_ORIENT")) ctx->tile_orient = atoi(e) != 0;
-  ctx->orient_blocks_per_cu = 4;
-  if (const char *e = getenv("MISIFT_ORIENT_BLOCKS")) ctx->orient_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 4;
+  ctx->orient_blocks_per_cu = 5;          // one round of resident workgroups: orient_all runs 5 waves/SIMD
+  if (const char *e = getenv("MISIFT_ORIENT_BLOCKS")) ctx->orient_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 5;
   ctx->point_blocks_per_cu = 8;
   if (const char *e = getenv("MISIFT_POINT_BLOCKS")) ctx->point_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 8;
   if (const char *e = getenv("MISIFT_STRIP_WAVES")) ctx->strip_waves_per_cu = atoi(e) > 0 ? atoi(e) : 16;
@@ -422,6 +420,19 @@ extern "C" int misift_malloc(size_t bytes, void **out)
   hipError_t e = hipMalloc(out, bytes);
   if (e != hipSuccess) {
     misift_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return MISIFT_ENOMEM;
+  }
+  return MISIFT_OK;
+}
+
+extern "C" int misift_malloc_managed(size_t bytes, void **out)
+{
+  ARG_CHECK(out != nullptr);
+  *out = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMallocManaged(out, bytes, hipMemAttachGlobal);
+  if (e != hipSuccess) {
+    misift_set_error("hipMallocManaged(%zu) failed: %s", bytes, hipGetErrorString(e));
     return MISIFT_ENOMEM;
   }
   return MISIFT_OK;

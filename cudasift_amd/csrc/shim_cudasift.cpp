@@ -39,6 +39,17 @@ static misift_ctx *ctx()
   return g_ctx;
 }
 
+// The reference's two build flavours (cudaSift.h:24-33): separate host / device arrays, or — with -DMANAGEDMEM — ONE
+// managed pointer valid on both sides (cudaSiftH.cu:239-240).  This file is compiled once per flavour
+// (libcudasift.so / libcudasift_managed.so).
+#ifdef MANAGEDMEM
+static inline SiftPoint *dev_ptr(SiftData &d) { return d.m_data; }
+static inline SiftPoint *host_ptr(SiftData &d) { return d.m_data; }
+#else
+static inline SiftPoint *dev_ptr(SiftData &d) { return d.d_data; }
+static inline SiftPoint *host_ptr(SiftData &d) { return d.h_data; }
+#endif
+
 static bool quiet()
 {
   misift_options o;
@@ -198,13 +209,17 @@ void ExtractSift(SiftData &siftData, CudaImage &img, int numOctaves, double init
   auto t0 = std::chrono::steady_clock::now();
   int numPts = 0;
   SAFE(misift_extract(ctx(), img.d_data, img.width, img.height, img.pitch, numOctaves, (float)initBlur, thresh,
-                      lowestScale, scaleUp ? 1 : 0, tempMemory, siftData.d_data, siftData.maxPts, &numPts));
+                      lowestScale, scaleUp ? 1 : 0, tempMemory, dev_ptr(siftData), siftData.maxPts, &numPts));
   siftData.numPts = numPts;
   const double t1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   const bool q = quiet();
   if (!q) printf("SIFT extraction time =        %.2f ms %d\n", t1, siftData.numPts);
+#ifdef MANAGEDMEM
+  SAFE(misift_ctx_sync(ctx()));                        // cudaSiftH.cu:136-137: the host may now read m_data
+#else
   if (siftData.h_data && siftData.numPts > 0)
     SAFE(misift_copy_d2h(ctx(), siftData.h_data, siftData.d_data, sizeof(SiftPoint) * (size_t)siftData.numPts));
+#endif
   const double t2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!q) printf("Incl prefiltering & memcpy =  %.2f ms %d\n\n", t2, siftData.numPts);
 }
@@ -214,6 +229,13 @@ void InitSiftData(SiftData &data, int num, bool host, bool dev)
   data.numPts = 0;
   data.maxPts = num;
   const size_t sz = sizeof(SiftPoint) * (size_t)num;        // size_t: no int overflow (Appendix B #17)
+#ifdef MANAGEDMEM
+  (void)host; (void)dev;
+  ctx();
+  void *p = nullptr;
+  SAFE(misift_malloc_managed(sz, &p));                       // cudaSiftH.cu:239-240
+  data.m_data = (SiftPoint *)p;
+#else
   data.h_data = NULL;
   if (host) data.h_data = (SiftPoint *)malloc(sz);
   data.d_data = NULL;
@@ -223,26 +245,36 @@ void InitSiftData(SiftData &data, int num, bool host, bool dev)
     SAFE(misift_malloc(sz, &p));
     data.d_data = (SiftPoint *)p;
   }
+#endif
 }
 
 void FreeSiftData(SiftData &data)
 {
+#ifdef MANAGEDMEM
+  if (data.m_data != NULL) SAFE(misift_free(data.m_data));   // cudaSiftH.cu:253-254
+  data.m_data = NULL;
+#else
   if (data.d_data != NULL) SAFE(misift_free(data.d_data));
   data.d_data = NULL;
   if (data.h_data != NULL) free(data.h_data);
   data.h_data = NULL;
+#endif
   data.numPts = 0;
   data.maxPts = 0;
 }
 
 void PrintSiftData(SiftData &data)
 {
+#ifdef MANAGEDMEM
+  SiftPoint *h_data = data.m_data;                           // cudaSiftH.cu:268-269
+#else
   SiftPoint *h_data = data.h_data;
   if (data.h_data == NULL) {
     h_data = (SiftPoint *)malloc(sizeof(SiftPoint) * (size_t)data.maxPts);
     if (data.numPts > 0) SAFE(misift_copy_d2h(ctx(), h_data, data.d_data, sizeof(SiftPoint) * (size_t)data.numPts));
     data.h_data = h_data;
   }
+#endif
   for (int i = 0; i < data.numPts; i++) {
     printf("xpos         = %.2f\n", h_data[i].xpos);
     printf("ypos         = %.2f\n", h_data[i].ypos);
@@ -271,10 +303,12 @@ double MatchSiftData(SiftData &data1, SiftData &data2)
 {
   auto t0 = std::chrono::steady_clock::now();
   if (!data1.numPts || !data2.numPts) return 0.0;
-  if (data1.d_data == NULL || data2.d_data == NULL) return 0.0;
-  SAFE(misift_match(ctx(), data1.d_data, data1.numPts, data2.d_data, data2.numPts));
+  if (dev_ptr(data1) == NULL || dev_ptr(data2) == NULL) return 0.0;
+  SAFE(misift_match(ctx(), dev_ptr(data1), data1.numPts, dev_ptr(data2), data2.numPts));   // returns synchronised
+#ifndef MANAGEDMEM
   if (data1.h_data != NULL)      // score, ambiguity, match, match_xpos, match_ypos (matching.cu:1195-1199)
     SAFE(misift_download_fields(ctx(), data1.h_data, data1.d_data, data1.numPts, offsetof(SiftPoint, score), 5));
+#endif
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!quiet()) printf("MatchSiftData time =          %.2f ms\n", ms);
   return ms;
@@ -284,7 +318,24 @@ double FindHomography(SiftData &data, float *homography, int *numMatches, int nu
                       float maxAmbiguity, float thresh)
 {
   auto t0 = std::chrono::steady_clock::now();
-  SAFE(misift_find_homography(ctx(), data.d_data, data.numPts, homography, numMatches, numLoops, minScore,
+  SAFE(misift_find_homography(ctx(), dev_ptr(data), data.numPts, homography, numMatches, numLoops, minScore,
                               maxAmbiguity, thresh));
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Extension: the reference's ImproveHomography (geomFuncs.cpp:6-72) is a HOST function over
+// SiftData.h_data that the caller compiles itself; this is the same computation on the device-resident records
+// (bit-identical result), mirroring match_error back to h_data when there is one.
+int ImproveHomographyGPU(SiftData &data, float *homography, int numLoops, float minScore, float maxAmbiguity,
+                         float thresh)
+{
+  int numfit = 0;
+  if (dev_ptr(data) == NULL) return 0;
+  SAFE(misift_improve_homography(ctx(), dev_ptr(data), data.numPts, homography, numLoops, minScore, maxAmbiguity,
+                                 thresh, &numfit));
+#ifndef MANAGEDMEM
+  if (data.h_data != NULL && data.numPts > 0)
+    SAFE(misift_download_fields(ctx(), data.h_data, data.d_data, data.numPts, offsetof(SiftPoint, match_error), 1));
+#endif
+  return numfit;
 }

@@ -37,7 +37,7 @@ typedef struct {
   int numPts;           // features currently valid
   int maxPts;           // capacity of h_data / d_data
 #ifdef MANAGEDMEM
-  SiftPoint *m_data;    // alternate single-pointer ABI (not built by default)
+  SiftPoint *m_data;    // managed memory: one pointer for host and device (libcudasift_managed.so)
 #else
   SiftPoint *h_data;    // host copy (may be NULL)
   SiftPoint *d_data;    // device copy (HBM)
@@ -77,5 +77,10 @@ double MatchSiftData(SiftData &data1, SiftData &data2);
 double FindHomography(SiftData &data, float *homography, int *numMatches,
                       int numLoops = 1000, float minScore = 0.85f,
                       float maxAmbiguity = 0.95f, float thresh = 5.0f);
+
+// ---- extension (not in the reference header): ImproveHomography of geomFuncs.cpp:6-72 on the device-resident
+// records instead of h_data; same arguments, same result.
+int ImproveHomographyGPU(SiftData &data, float *homography, int numLoops, float minScore,
+                         float maxAmbiguity, float thresh);
 
 #endif // CUDASIFT_H

@@ -321,6 +321,18 @@ int misift_find_homography(misift_ctx *ctx, const void *d_pts, int npts, float *
                            int *num_matches, int num_loops, float min_score,
                            float max_ambiguity, float thresh);
 
+/* ImproveHomography (geomFuncs.cpp:6-72 — a host function over SiftData.h_data in the reference) on device-resident
+ * records: num_loops rounds of least squares over the matches that pass the gates and currently reproject within
+ * `thresh`, then match_error of every record is written (device) and *num_fit = records within thresh.
+ * homography9: in = start (e.g. from misift_find_homography), out = refined, [8] = 1.  Sums in the reference's order:
+ * bit-identical to the reference's result. */
+int misift_improve_homography(misift_ctx *ctx, void *d_pts, int npts, float *homography9, int num_loops,
+                              float min_score, float max_ambiguity, float thresh, int *num_fit);
+
+/* cudaMallocManaged as used by the reference's MANAGEDMEM build flavour (cudaSiftH.cu:239-240): one pointer valid on
+ * host and device (SiftData.m_data). */
+int misift_malloc_managed(size_t bytes, void **out);
+
 /* ------------------------------------------------------------------- timing */
 
 /* TimerGPU (cudautils.h:61-81): event pair on the context stream. */

@@ -46,3 +46,21 @@ EOF
   } | g++ -x c++ -O2 -mavx2 -mfma -fopenmp -shared -fPIC -w -o "$OUT/libmatchref_$N.so" -
   echo "build_ref: built $OUT/libmatchref_$N.so"
 done
+
+# ImproveHomography: the reference's OWN geomFuncs.cpp (host-only C++), compiled where it lies against include/cudaSift.h
+# (same SiftData / SiftPoint layout) and the mini-OpenCV stand-in (OpenCV itself is absent from this image).  Pins
+# orc_improve_homography (tests/test_oracle_cpu.py).  Exported through a C wrapper appended on the fly.
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+{
+  cat "$REF/geomFuncs.cpp"
+  cat <<'EOF2'
+extern "C" int ref_improve_homography(void *pts, int numPts, float *homography, int numLoops, float minScore,
+                                      float maxAmbiguity, float thresh)
+{
+  SiftData d;
+  d.numPts = numPts; d.maxPts = numPts; d.h_data = (SiftPoint *)pts; d.d_data = 0;
+  return ImproveHomography(d, homography, numLoops, minScore, maxAmbiguity, thresh);
+}
+EOF2
+} | g++ -x c++ -O2 -ffp-contract=off -shared -fPIC -w -I"$ROOT/include" -I"$ROOT/cudasift_amd/compat" -o "$OUT/libgeomref.so" -
+echo "build_ref: built $OUT/libgeomref.so"

@@ -77,6 +77,8 @@ def lib():
         L.orc_match_argmax.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
         L.orc_find_homography.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.c_float]
         L.orc_find_homography.restype = C.c_int
+        L.orc_improve_homography.argtypes = [vp, C.c_int, fp, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.orc_improve_homography.restype = C.c_int
         L.orc_stats_get.argtypes = [C.POINTER(OrcStats)]
         L.orc_sizeof_point.restype = C.c_int
         assert L.orc_sizeof_point() == 576
@@ -250,6 +252,15 @@ def find_homography(pts, npts, num_loops=1000, min_score=0.85, max_ambiguity=0.9
     return np.array(list(H), np.float32).reshape(3, 3), nm.value, best
 
 
+def improve_homography(pts, npts, H, num_loops=5, min_score=0.0, max_ambiguity=0.80, thresh=3.0):
+    """ImproveHomography (geomFuncs.cpp:6-72) on a structured SiftPoint array, in place (match_error is written).
+    Returns (H 3x3 float32, numfit)."""
+    h = np.ascontiguousarray(H, np.float32).reshape(9).copy()
+    n = lib().orc_improve_homography(_p(pts), npts, h.ctypes.data_as(C.POINTER(C.c_float)), num_loops, min_score,
+                                     max_ambiguity, thresh)
+    return h.reshape(3, 3), n
+
+
 def srand(seed):
     """Seed the process-wide libc rand() that FindHomography (oracle and HIP host side) draws from."""
     C.CDLL(None).srand(C.c_uint(seed))
@@ -278,6 +289,21 @@ def ref_lib(npts):
     L.ref_npts.restype = C.c_int
     assert L.ref_npts() == npts
     return L
+
+
+def ref_improve_homography(pts, npts, H, num_loops=5, min_score=0.0, max_ambiguity=0.80, thresh=3.0):
+    """The reference's own ImproveHomography (geomFuncs.cpp, built by build_ref.sh into oracle/_ref/libgeomref.so).
+    Returns (H, numfit) or None where the reference tree was absent at build time."""
+    path = os.path.join(HERE, "_ref", "libgeomref.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.ref_improve_homography.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_float]
+    L.ref_improve_homography.restype = C.c_int
+    h = np.ascontiguousarray(H, np.float32).reshape(9).copy()
+    n = L.ref_improve_homography(_p(pts), npts, h.ctypes.data_as(C.POINTER(C.c_float)), num_loops, min_score,
+                                 max_ambiguity, thresh)
+    return h.reshape(3, 3), n
 
 
 def aligned_f32(n, align=32):

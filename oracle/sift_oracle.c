@@ -557,6 +557,33 @@ static inline float fast_atan2(float y, float x)
 }
 float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 
+/* sin and cos of the descriptor's rotation angle theta in [0, 2 pi].  The reference uses the CUDA hardware
+ * approximations __sinf / __cosf (cudaSiftD.cu:331-332, absolute error ~2^-21.4), which no other platform reproduces bit
+ * for bit; any ACCURATE sine is therefore an equally faithful restatement.  This one is written out — Cody-Waite
+ * reduction by pi/2 in two fused steps, the cephes single-precision minimax kernels on [-pi/4, pi/4] as explicit fmaf
+ * chains (max error 1 ulp) — so that the HIP kernels evaluate the IDENTICAL expression (kernels_points.hip
+ * det_sincos): the 1024 sample coordinates of a descriptor then agree bit for bit between the two, and with them
+ * every 8-bit texture weight.  (With libm sinf on one side and ocml sinf on the other, a last-bit difference moved
+ * a weight by 1/256 in ~0.4 % of the descriptors.) */
+static inline void det_sincos(float x, float *sn, float *cs)
+{
+  const float kf = rintf(x * 0.636619747f);                  /* nearest multiple of pi/2 */
+  float r = fmaf(kf, -1.57079625f, x);                       /* pi/2 = 1.57079625 + 7.54978942e-08 (+ ...) */
+  r = fmaf(kf, -7.54978942e-08f, r);
+  const float z = r * r;
+  float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  ps = fmaf(ps, z, -1.6666654611e-1f);
+  const float s = fmaf(ps * z, r, r);
+  float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  pc = fmaf(pc, z, 4.166664568298827e-2f);
+  const float c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)kf & 3;
+  const float s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+void orc_det_sincos(float x, float *sn, float *cs) { det_sincos(x, sn, cs); }
+
 /* ExtractSiftDescriptorsCONSTNew, cudaSiftD.cu:308-417, for points [first,last). */
 void orc_descriptors(const float *img, int w, int h, int pitch, SiftPoint *pts, int first, int last,
                      float subsampling, int fracbits)
@@ -570,8 +597,8 @@ void orc_descriptors(const float *img, int w, int h, int pitch, SiftPoint *pts, 
     long guards = 0, oob = 0;
     for (int i = 0; i < 128; i++) buffer[i] = 0.0f;
     float theta = 2.0f * 3.1415f / 360.0f * p->orientation;
-    float sina = sinf(theta);
-    float cosa = cosf(theta);
+    float sina, cosa;
+    det_sincos(theta, &sina, &cosa);
     float scale = 12.0f / 16.0f * p->scale;
     float ssina = scale * sina;
     float scosa = scale * cosa;
@@ -1067,4 +1094,91 @@ int orc_find_homography(const SiftPoint *pts, int numPts, float *homography, int
   }
   free(validPts);
   return bestLoop;
+}
+
+/* ------------------------------------------------------------------ ImproveHomography
+ * Iterative least-squares refinement of a homography over the stored matches, geomFuncs.cpp:6-72: numLoops times,
+ * accumulate the 8x8 normal equations over the points that pass the score / ambiguity gates AND currently reproject
+ * within `thresh` (weight 1, else 0), solve by Cholesky (cv::solve DECOMP_CHOLESKY; a matrix that is not positive
+ * definite leaves the estimate unchanged); finally write match_error = sqrt(err) for every point and return the
+ * number with err < thresh^2.  Types as in the reference: the estimate A and the sums are double, the point fields
+ * float; `den`, `dx`, `dy`, `err` are float variables assigned from double expressions; the products
+ * -xpos*match_xpos etc. are float products stored in double (geomFuncs.cpp:38-39, :49-50). */
+static int cholesky_solve8(const double *Min, const double *Xin, double *out)
+{
+  double A[64], B[8];
+  memcpy(A, Min, sizeof(A));
+  memcpy(B, Xin, sizeof(B));
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i * 8 + j];
+      for (int k = 0; k < j; k++) s -= A[i * 8 + k] * A[j * 8 + k];
+      if (i == j) {
+        if (!(s > 0)) return 0;
+        A[i * 8 + i] = sqrt(s);
+      } else {
+        A[i * 8 + j] = s / A[j * 8 + j];
+      }
+    }
+  for (int i = 0; i < 8; i++) {
+    double s = B[i];
+    for (int k = 0; k < i; k++) s -= A[i * 8 + k] * B[k];
+    B[i] = s / A[i * 8 + i];
+  }
+  for (int i = 7; i >= 0; i--) {
+    double s = B[i];
+    for (int k = i + 1; k < 8; k++) s -= A[k * 8 + i] * B[k];
+    B[i] = s / A[i * 8 + i];
+  }
+  memcpy(out, B, sizeof(B));
+  return 1;
+}
+
+int orc_improve_homography(SiftPoint *pts, int numPts, float *homography, int numLoops, float minScore,
+                           float maxAmbiguity, float thresh)
+{
+  if (!pts) return 0;
+  const float limit = thresh * thresh;
+  double A[8];
+  for (int i = 0; i < 8; i++) A[i] = homography[i] / homography[8];       /* float division, geomFuncs.cpp:20-21 */
+  for (int loop = 0; loop < numLoops; loop++) {
+    double M[64], X[8], Y[8];
+    memset(M, 0, sizeof(M));
+    memset(X, 0, sizeof(X));
+    for (int i = 0; i < numPts; i++) {
+      const SiftPoint *pt = &pts[i];
+      if (pt->score < minScore || pt->ambiguity > maxAmbiguity) continue;
+      float den = A[6] * pt->xpos + A[7] * pt->ypos + 1.0f;
+      float dx = (A[0] * pt->xpos + A[1] * pt->ypos + A[2]) / den - pt->match_xpos;
+      float dy = (A[3] * pt->xpos + A[4] * pt->ypos + A[5]) / den - pt->match_ypos;
+      float err = dx * dx + dy * dy;
+      float wei = (err < limit ? 1.0f : 0.0f);
+      Y[0] = pt->xpos; Y[1] = pt->ypos; Y[2] = 1.0; Y[3] = Y[4] = Y[5] = 0.0;
+      Y[6] = -pt->xpos * pt->match_xpos;
+      Y[7] = -pt->ypos * pt->match_xpos;
+      for (int c = 0; c < 8; c++)
+        for (int r = 0; r < 8; r++) M[r * 8 + c] += (Y[c] * Y[r] * wei);
+      for (int r = 0; r < 8; r++) X[r] += Y[r] * pt->match_xpos * wei;
+      Y[0] = Y[1] = Y[2] = 0.0; Y[3] = pt->xpos; Y[4] = pt->ypos; Y[5] = 1.0;
+      Y[6] = -pt->xpos * pt->match_ypos;
+      Y[7] = -pt->ypos * pt->match_ypos;
+      for (int c = 0; c < 8; c++)
+        for (int r = 0; r < 8; r++) M[r * 8 + c] += (Y[c] * Y[r] * wei);
+      for (int r = 0; r < 8; r++) X[r] += Y[r] * pt->match_ypos * wei;
+    }
+    cholesky_solve8(M, X, A);                        /* not positive definite: A stays (cv::solve returns false) */
+  }
+  int numfit = 0;
+  for (int i = 0; i < numPts; i++) {
+    SiftPoint *pt = &pts[i];
+    float den = A[6] * pt->xpos + A[7] * pt->ypos + 1.0;
+    float dx = (A[0] * pt->xpos + A[1] * pt->ypos + A[2]) / den - pt->match_xpos;
+    float dy = (A[3] * pt->xpos + A[4] * pt->ypos + A[5]) / den - pt->match_ypos;
+    float err = dx * dx + dy * dy;
+    if (err < limit) numfit++;
+    pt->match_error = sqrtf(err);
+  }
+  for (int i = 0; i < 8; i++) homography[i] = (float)A[i];
+  homography[8] = 1.0f;
+  return numfit;
 }

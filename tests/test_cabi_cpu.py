@@ -98,6 +98,36 @@ def test_headers_are_plain_cpp_and_layout_matches(tmp_path):
     assert out == ["576", "24", "32", "48", "64", "24", "0"]
 
 
+def test_managedmem_flavour_builds_and_exports(tmp_path):
+    """The reference's alternate ABI (cudaSift.h:27-32, -DMANAGEDMEM: SiftData = {numPts, maxPts, m_data}): the header
+    compiles in that mode with the same record layout, libcudasift_managed.so exports the same API, and the
+    reference's unmodified mainSift.cpp + geomFuncs.cpp link against it."""
+    lib = os.path.join(ROOT, "cudasift_amd", "libcudasift_managed.so")
+    assert os.path.exists(lib), "run `make`"
+    syms = subprocess.check_output("nm -D --defined-only %s | c++filt" % lib, shell=True, text=True)
+    for want in ["ExtractSift(SiftData&, CudaImage&, int, double, float, float, bool, float*)",
+                 "InitSiftData(SiftData&, int, bool, bool)", "MatchSiftData(SiftData&, SiftData&)",
+                 "FindHomography(SiftData&, float*, int*, int, float, float, float)",
+                 "ImproveHomographyGPU(SiftData&, float*, int, float, float, float)"]:
+        assert want in syms, want
+    src = tmp_path / "layout.cpp"
+    src.write_text('#include <cstdio>\n#include <cstddef>\n#include "cudaSift.h"\n'
+                   'int main(){ SiftData d; d.m_data = 0; printf("%zu %zu %zu\\n", sizeof(SiftPoint), sizeof(SiftData),'
+                   ' offsetof(SiftData, m_data)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["g++", "-std=c++17", "-DMANAGEDMEM", "-I", INC, str(src), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)], text=True).split() == ["576", "16", "8"]
+    ref = os.environ.get("REF", "/root/reference")
+    if os.path.exists(os.path.join(ref, "mainSift.cpp")):
+        exe2 = tmp_path / "dropin_managed"
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DMANAGEDMEM", "-I", INC, "-I",
+                               os.path.join(ROOT, "cudasift_amd", "compat"), os.path.join(ref, "mainSift.cpp"),
+                               os.path.join(ref, "geomFuncs.cpp"), "-o", str(exe2), "-L",
+                               os.path.join(ROOT, "cudasift_amd"), "-lcudasift_managed", "-lmisift",
+                               "-Wl,-rpath," + os.path.join(ROOT, "cudasift_amd")])
+        assert os.path.exists(exe2)
+
+
 def test_reference_main_compiles_unchanged(tmp_path):
     ref = os.environ.get("REF", "/root/reference")
     if not os.path.exists(os.path.join(ref, "mainSift.cpp")):

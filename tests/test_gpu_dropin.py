@@ -11,6 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "cudasift_dropin")
+BIN_MANAGED = os.path.join(ROOT, "oracle", "_ref", "cudasift_dropin_managed")
 
 
 def write_pgm(path, img):
@@ -19,20 +20,24 @@ def write_pgm(path, img):
         f.write(np.ascontiguousarray(img, np.uint8).tobytes())
 
 
-def test_reference_main_runs_unchanged(tmp_path):
-    if not os.path.exists(BIN):
-        pytest.skip("oracle/_ref/cudasift_dropin not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("flavour", ["default", "managed"])
+def test_reference_main_runs_unchanged(tmp_path, flavour):
+    """default: SiftData = {h_data, d_data}; managed: the reference's -DMANAGEDMEM flavour (cudaSift.h:27-32, one
+    hipMallocManaged pointer m_data read by the host code of mainSift.cpp / geomFuncs.cpp directly)."""
+    exe = BIN if flavour == "default" else BIN_MANAGED
+    if not os.path.exists(exe):
+        pytest.skip("%s not built (needs /root/reference at build time)" % exe)
     z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_pair_u8.npz"))
     os.makedirs(tmp_path / "data")
     write_pgm(tmp_path / "data" / "left.pgm", z["left"])
     write_pgm(tmp_path / "data" / "righ.pgm", z["right"])
     env = dict(os.environ, MISIFT_QUIET="1")
-    r = subprocess.run([BIN, "0", "1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, "0", "1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = r.stdout
     outdir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(outdir):
-        with open(os.path.join(outdir, "dropin_stdout.txt"), "w") as f:
+        with open(os.path.join(outdir, "dropin_stdout%s.txt" % ("" if flavour == "default" else "_managed")), "w") as f:
             f.write(out[-6000:])
     assert "Image size = (1280,960)" in out
     m = re.search(r"Number of original features: (\d+) (\d+)", out)

@@ -736,3 +736,34 @@ def test_extract_batch_scaleup_and_u8(ctx, stereo):
     assert np.array_equal(n, n2)
     for f in range(len(crops)):
         assert _canon(pts[f][:n[f]]) == _canon(pts2[f][:n2[f]])
+
+
+def test_improve_homography_device_vs_oracle(ctx, stereo):
+    """misift_improve_homography (device version of the reference's host-side ImproveHomography, geomFuncs.cpp:6-72)
+    against orc_improve_homography — itself pinned bit for bit to the reference's own geomFuncs.cpp: refined H,
+    inlier count and every match_error identical.  Synthetic matches + the stereo chain of mainSift.cpp:72-78."""
+    from synth import synth_matches
+    for n, seed, loops in ((1500, 1, 5), (333, 2, 8), (20, 3, 2)):
+        pts, Htrue, _ = synth_matches(n, inlier_frac=0.6, seed=seed)
+        H0 = Htrue.copy()
+        H0[0, 2] += 3.0
+        H0[1, 2] -= 2.0
+        ref = pts.copy()
+        Ho, no = orc().improve_homography(ref, n, H0, loops, 0.0, 0.95, 3.0)
+        d = ctx.upload(pts)
+        Hg, ng = ctx.improve_homography(d.ptr, n, H0, loops, 0.0, 0.95, 3.0)
+        got = ctx.download(d, (n,), pts.dtype)
+        record("improve_homography_n%d" % n, numfit_oracle=no, numfit_hip=ng, H_equal=bool(np.array_equal(Ho, Hg)))
+        assert ng == no
+        assert np.array_equal(Ho.view(np.uint32), Hg.view(np.uint32))
+        assert np.array_equal(ref["match_error"].view(np.uint32), got["match_error"].view(np.uint32))
+    a, na, _ = ctx.extract(stereo[0], thresh=4.5)
+    b, nb, _ = ctx.extract(stereo[1], thresh=4.5)
+    m = ctx.match(a, na, b, nb)
+    d = ctx.upload(m)
+    orc().srand(3)
+    H, _ = ctx.find_homography(d.ptr, na, num_loops=10000, min_score=0.0, max_ambiguity=0.80, thresh=5.0)
+    ref = m.copy()
+    Ho, no = orc().improve_homography(ref, na, H, 5, 0.0, 0.80, 3.0)                 # mainSift.cpp:78 arguments
+    Hg, ng = ctx.improve_homography(d.ptr, na, H, 5, 0.0, 0.80, 3.0)
+    assert ng == no and no > 100 and np.array_equal(Ho.view(np.uint32), Hg.view(np.uint32))

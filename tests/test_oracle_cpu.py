@@ -527,3 +527,25 @@ def test_extract_batch_equals_single_calls():
         ref, nref, cref = orc.extract(imgs[f], num_octaves=4, thresh=2.0, max_pts=4096)
         assert nref == n[f] and nref > 50 and np.array_equal(cref, cnt[f])
         assert ref[:nref].tobytes() == pts[f, :nref].tobytes()
+
+
+def test_improve_homography_pinned_against_reference_geomfuncs():
+    """orc_improve_homography against the reference's OWN geomFuncs.cpp (compiled unchanged by oracle/build_ref.sh):
+    the refined homography, the inlier count and every match_error must be bit-identical."""
+    from synth import synth_matches
+    for n, seed, loops in ((1500, 1, 5), (200, 2, 10), (40, 3, 3)):
+        pts, Htrue, inl = synth_matches(n, inlier_frac=0.6, seed=seed, dtype=orc.POINT_DTYPE)
+        H0 = (Htrue * np.float32(1.0)).copy()
+        H0[0, 2] += 3.0                                   # a perturbed start, as FindHomography would hand over
+        H0[1, 2] -= 2.0
+        a = pts.copy()
+        ref = orc.ref_improve_homography(a, n, H0, loops, 0.0, 0.95, 3.0)
+        if ref is None:
+            pytest.skip("oracle/_ref/libgeomref.so not built (reference tree absent)")
+        b = pts.copy()
+        Ho, no = orc.improve_homography(b, n, H0, loops, 0.0, 0.95, 3.0)
+        assert ref[1] == no and no >= 0.5 * inl.sum()
+        assert np.array_equal(ref[0].view(np.uint32), Ho.view(np.uint32))
+        assert np.array_equal(a["match_error"].view(np.uint32), b["match_error"].view(np.uint32))
+        # and it does refine: the true homography's translation is recovered to about a pixel
+        assert abs(Ho[0, 2] - Htrue[0, 2]) < 1.5 and abs(Ho[1, 2] - Htrue[1, 2]) < 1.5
