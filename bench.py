@@ -714,7 +714,8 @@ def main():
                           "keypoints_per_frame": round(kp_per_frame, 1)},
                "validated_frames": validated,
                "validation": ("frames 0..%d of the LAST timed step: counts and every record equal to the oracle (tests/util.py "
-                              "compare_points: identical keypoint set, 1e-4 fields, descriptor cosine >= 1-1e-6)" % (validated - 1))
+                              "compare_points: identical keypoint set; position, scale, orientation, sharpness, edgeness "
+                              "bit-identical; every descriptor element within 1e-6; no outlier budget)" % (validated - 1))
                if validated else "skipped (--no-cpu)",
                "roofline": roofline, "kernels": kernels, "step_ms": step_ms, "match": match, "cpu_baseline": cpu,
                "pcie_inclusive": pcie, "single_frame": latency,

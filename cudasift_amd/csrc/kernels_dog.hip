@@ -653,6 +653,25 @@ __device__ __forceinline__ void dog_patch(const float *img, int w, int h, int pi
 // Full 26-neighbour test + edge test + 3-D quadratic refinement of one candidate whose 3x3x3 DoG
 // neighbourhood is d[plane s..s+2][dy][dx] (cudaSiftD.cu:1337-1360, :1383-1417; same expression order
 // as oracle orc_findpoints()).  Returns false if the candidate is rejected.
+// 2^x as the written-out fmaf chain of oracle det_exp2() (sift_oracle.c): the keypoint scale then agrees bit for bit
+// with the oracle's, and with it everything the orientation / descriptor kernels decide from it.
+__device__ __forceinline__ float det_exp2(float x)
+{
+  const bool tiny = x < -125.0f;
+  x = fminf(x, 126.0f);
+  x = tiny ? 0.0f : x;
+  const float n = rintf(x);
+  const float r = x - n;
+  float p = __builtin_fmaf(1.535336188319500e-4f, r, 1.339887440266574e-3f);
+  p = __builtin_fmaf(p, r, 9.618437357674640e-3f);
+  p = __builtin_fmaf(p, r, 5.550332471162809e-2f);
+  p = __builtin_fmaf(p, r, 2.402264791363012e-1f);
+  p = __builtin_fmaf(p, r, 6.931472028550421e-1f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  const float sc = __builtin_bit_cast(float, ((int)n + 127) << 23);
+  return tiny ? 0.0f : p * sc;
+}
+
 struct Refined { float xpos, ypos, scale, sharpness, edgeness; };
 __device__ __forceinline__ bool refine_math(const float (&d)[3][3][3], int x, int y, int s, float thresh,
                                             float edge_limit, float factor, float lowest_scale,
@@ -706,7 +725,7 @@ __device__ __forceinline__ bool refine_math(const float (&d)[3][3][3], int x, in
   float scm = scmul[0];
 #pragma unroll
   for (int j = 1; j < NUM_SCALES; j++) scm = (s == j) ? scmul[j] : scm;
-  const float sc = scm * exp2f(pds * factor);
+  const float sc = scm * det_exp2(pds * factor);
   if (!(sc >= lowest_scale)) return false;
   out.xpos = x + pdx;
   out.ypos = y + pdy;

@@ -174,6 +174,45 @@ __device__ __forceinline__ float tex2d_tile(const float *tile, int x0, int y0, f
   return v;
 }
 
+// ---------------------------------------------------- written-out elementary functions
+// atan2f / expf as explicit fmaf chains, IDENTICAL to oracle det_atan2() / det_exp() (sift_oracle.c): the orientation
+// histogram takes hard decisions on them (bin of a sample, which bins are peaks), and two libm's that agree to an ulp
+// still flip such a decision once in a few hundred keypoints.  ~1-2 ulp like the CUDA libm the reference calls.
+__device__ __forceinline__ float det_atan2(float y, float x)
+{
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float a = mx == 0.0f ? 0.0f : mn / mx;
+  const bool red = a > 0.414213562f;
+  const float base = red ? 0.785398163f : 0.0f;
+  a = red ? (a - 1.0f) / (a + 1.0f) : a;
+  const float z = a * a;
+  float p = __builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = __builtin_fmaf(p, z, 1.99777106478e-1f);
+  p = __builtin_fmaf(p, z, -3.33329491539e-1f);
+  float r = base + __builtin_fmaf(p * z, a, a);
+  r = ay > ax ? 1.57079637f - r : r;
+  r = x < 0.0f ? 3.14159274f - r : r;
+  return y < 0.0f ? -r : r;
+}
+__device__ __forceinline__ float det_exp(float x)
+{
+  const bool tiny = x < -87.0f;
+  x = fminf(x, 88.0f);
+  x = tiny ? 0.0f : x;
+  const float n = rintf(x * 1.44269504f);
+  float r = __builtin_fmaf(n, -0.693359375f, x);
+  r = __builtin_fmaf(n, 2.12194440e-4f, r);
+  float p = __builtin_fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  const float e = __builtin_fmaf(p * r, r, r) + 1.0f;
+  const float sc = __builtin_bit_cast(float, ((int)n + 127) << 23);
+  return tiny ? 0.0f : e * sc;
+}
+
 // ------------------------------------------------------------- orientation
 struct OrientResult { float ori1, ori2; bool has2; };      // meaningful in lane 0 only
 
@@ -243,7 +282,7 @@ __device__ __forceinline__ OrientResult orient_core(const float *img, int w, int
                                                     float2 *smp, float *tgrid, int lane)
 {
   const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
-  if (lane < 11) gauss[lane] = expf(i2sigma2 * (lane - 5) * (lane - 5));
+  if (lane < 11) gauss[lane] = det_exp(i2sigma2 * (lane - 5) * (lane - 5));
   wave_sync();
   const float xp = xpos - 4.5f;
   const float yp = ypos - 4.5f;
@@ -285,7 +324,7 @@ __device__ __forceinline__ OrientResult orient_core(const float *img, int w, int
         const float *t = tgrid + (yd + 1) * 13 + (xd + 1);
         const float dx = t[1] - t[-1];
         const float dy = t[13] - t[-13];
-        int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+        int bin = (int)(16.0f * det_atan2(dy, dx) / 3.1416f + 16.5f);
         if (bin > 31) bin = 0;
         const float grad = sqrtf(dx * dx + dy * dy);
         smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
@@ -302,7 +341,7 @@ __device__ __forceinline__ OrientResult orient_core(const float *img, int w, int
         const float yf = yp + yd;
         const float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q8) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q8);
         const float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q8) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q8);
-        int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+        int bin = (int)(16.0f * det_atan2(dy, dx) / 3.1416f + 16.5f);
         if (bin > 31) bin = 0;
         const float grad = sqrtf(dx * dx + dy * dy);
         smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
@@ -323,7 +362,7 @@ __device__ __forceinline__ OrientResult orient_core_tile(const float *img, int w
                                                          float *hist, float *gauss, float2 *smp, float *tgrid, int lane)
 {
   const float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * scale * scale);
-  if (lane < 11) gauss[lane] = expf(i2sigma2 * (lane - 5) * (lane - 5));
+  if (lane < 11) gauss[lane] = det_exp(i2sigma2 * (lane - 5) * (lane - 5));
   const float xp = xpos - 4.5f;
   const float yp = ypos - 4.5f;
   bool same = true;
@@ -355,7 +394,7 @@ __device__ __forceinline__ OrientResult orient_core_tile(const float *img, int w
       const float *t = tgrid + (yd + 1) * 13 + (xd + 1);
       const float dx = t[1] - t[-1];
       const float dy = t[13] - t[-13];
-      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+      int bin = (int)(16.0f * det_atan2(dy, dx) / 3.1416f + 16.5f);
       if (bin > 31) bin = 0;
       const float grad = sqrtf(dx * dx + dy * dy);
       smp[tx] = make_float2((float)bin, grad * gauss[xd] * gauss[yd]);
@@ -467,7 +506,7 @@ __device__ __forceinline__ constexpr float spatial_w(int m)      // horf/verf fo
 
 __device__ __forceinline__ void descr_init(float *tbl, float *gauss, int lane)
 {
-  if (lane < 16) gauss[lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
+  if (lane < 16) gauss[lane] = det_exp(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
   for (int i = lane; i < DESCR_TBL; i += 64) tbl[i] = 0.0f;
 }
 
@@ -1009,7 +1048,7 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
   const bool q8 = Q8;          // compile-time: no per-fetch branch on the weight quantisation
   float *buf = s_w[wave].buf;
   const float *gauss = s_w[wave].gauss;
-  if (lane < 16) s_w[wave].gauss[lane] = expf(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
+  if (lane < 16) s_w[wave].gauss[lane] = det_exp(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
   // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
   if (blockIdx.x == 0 && threadIdx.x == 0) {             // publish the reference's counters (cudaSiftD.cu:14)
     unsigned b = 0;

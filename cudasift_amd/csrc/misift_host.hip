@@ -247,7 +247,7 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   }
   ctx->bin_detections = 1;
   if (const char *e = getenv("MISIFT_BIN")) ctx->bin_detections = atoi(e) != 0;
-  ctx->descr_occ = 3;
+  ctx->descr_occ = 4;
   if (const char *e = getenv("MISIFT_DESCR_OCC")) ctx->descr_occ = atoi(e);
   ctx->tile_descr = 1;
   ctx->tile_orient = 0;

@@ -44,9 +44,15 @@
  * fsub(c,fmul(a,b)) -> fma(-a,b,c), multiplies reached through a phi are not
  * fused.  tests/test_oracle_cpu.py::test_contraction_sensitivity runs both modes
  * and bounds what the choice can change (profiles/r02_contraction_sensitivity.json,
- * DESIGN.md section 2).  libm calls (expf, atan2f, sinf, cosf, sqrtf,
- * powf, exp2f) differ from the device versions in the last bits; tests use the
- * tolerances of SURVEY §7.5 for anything downstream of them.
+ * DESIGN.md section 2).  Elementary functions: the reference calls CUDA's
+ * atan2f / exp / __sinf / __cosf / __expf, none of which can be reproduced bit
+ * for bit elsewhere; wherever a HARD decision or an 8-bit texture weight hangs on
+ * one of them (orientation histogram: atan2f, expf; descriptor rotation: sin, cos;
+ * descriptor Gaussian: expf) the oracle uses its own written-out fmaf-chain
+ * versions det_atan2 / det_exp / det_sincos (accurate to ~1-2 ulp), and the HIP
+ * kernels evaluate the identical chains: orientations agree bit for bit.  sqrtf
+ * and the divisions are IEEE-exact on both sides; the keypoint scale uses det_exp2
+ * (and powf(2, s/5) evaluated on the HOST by both sides).
  *
  * Deliberate deviations from the reference: #4 no 32
  * candidates-per-tile cap (overflows are counted in orc_stats), #7 FastAtan2(0,0)
@@ -279,6 +285,29 @@ void orc_laplace(const float *base, int w, int h, int pitch, const float *taps, 
   free(vbuf);
 }
 
+/* 2^x as a written-out fmaf chain (cephes exp2f: split off the nearest integer, degree-6 kernel on [-0.5, 0.5], scale
+ * by 2^n; ~1.5 ulp), IDENTICAL in kernels_dog.hip.  The keypoint scale 2^(s/5) * exp2f(pds/5) (cudaSiftD.cu:1417)
+ * feeds the orientation window's Gaussian and the descriptor's sample spacing, i.e. hard decisions downstream: with
+ * libm exp2f here and ocml exp2f on the GPU the scales differed in the last bit for a few keypoints per frame, and
+ * with them, occasionally, an orientation bin or an 8-bit texture weight. */
+static inline float det_exp2(float x)
+{
+  if (x < -125.0f) return 0.0f;
+  if (x > 126.0f) x = 126.0f;
+  const float n = rintf(x);
+  const float r = x - n;                                    /* exact */
+  float p = fmaf(1.535336188319500e-4f, r, 1.339887440266574e-3f);
+  p = fmaf(p, r, 9.618437357674640e-3f);
+  p = fmaf(p, r, 5.550332471162809e-2f);
+  p = fmaf(p, r, 2.402264791363012e-1f);
+  p = fmaf(p, r, 6.931472028550421e-1f);
+  p = fmaf(p, r, 1.0f);
+  union { float f; int32_t i; } sc;
+  sc.i = ((int32_t)n + 127) << 23;
+  return p * sc.f;
+}
+float orc_det_exp2(float x) { return det_exp2(x); }
+
 /* ------------------------------------------------------------ FindPoints */
 
 /* FindPointsMultiNew, cudaSiftD.cu:1292-1431.  Appends records starting at
@@ -359,7 +388,7 @@ int orc_findpoints(const float *dog, int w, int h, int pitch, float thresh, floa
         }
         float dsum = dot3(dx, pdx, dy, pdy, ds, pds);
         float dval = 0.5f * dsum;
-        float sc = powf(2.0f, (float)s / NUM_SCALES) * exp2f(pds * factor);
+        float sc = powf(2.0f, (float)s / NUM_SCALES) * det_exp2(pds * factor);
         if (!(sc >= lowestScale)) continue;
         if (L->n == L->cap) {
           L->cap = L->cap ? 2 * L->cap : 64;
@@ -441,6 +470,49 @@ float orc_tex2d(const float *img, int w, int h, int pitch, float x, float y, int
   return tex2d(img, w, h, pitch, x, y, fracbits);
 }
 
+/* ---------------------------------------------------- written-out elementary functions
+ * The orientation histogram takes HARD decisions on atan2f (which of 32 bins) and on sums weighted by expf (which bins
+ * are peaks), and the resulting angle positions every descriptor sample against the 8-bit texture-weight grid.  Two
+ * different libm's (glibc here, ocml on the GPU) agree to an ulp, which is enough to flip such a decision once in a
+ * few hundred keypoints.  The reference's own CUDA versions cannot be reproduced bit for bit anywhere else, so the
+ * oracle states them explicitly instead — accurate to ~1-2 ulp like the CUDA libm ones — and kernels_points.hip
+ * evaluates the IDENTICAL fmaf chains: orientations then agree bit for bit and descriptors to summation order. */
+static inline float det_atan2(float y, float x)            /* cephes atanf kernel on [0,1] + octant fix-ups */
+{
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float a = mx == 0.0f ? 0.0f : mn / mx;                   /* atan2f(0,0) = 0 */
+  float base = 0.0f;
+  if (a > 0.414213562f) { base = 0.785398163f; a = (a - 1.0f) / (a + 1.0f); }
+  const float z = a * a;
+  float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = fmaf(p, z, 1.99777106478e-1f);
+  p = fmaf(p, z, -3.33329491539e-1f);
+  float r = base + fmaf(p * z, a, a);
+  r = ay > ax ? 1.57079637f - r : r;
+  r = x < 0.0f ? 3.14159274f - r : r;
+  return y < 0.0f ? -r : r;
+}
+static inline float det_exp(float x)                       /* cephes expf: x = n ln2 + r, degree-5 kernel, scale by 2^n */
+{
+  if (x < -87.0f) return 0.0f;
+  if (x > 88.0f) x = 88.0f;
+  const float n = rintf(x * 1.44269504f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float p = fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  const float e = fmaf(p * r, r, r) + 1.0f;
+  union { float f; int32_t i; } sc;
+  sc.i = ((int32_t)n + 127) << 23;                          /* 2^n, n in [-126, 127] */
+  return e * sc.f;
+}
+float orc_det_atan2(float y, float x) { return det_atan2(y, x); }
+float orc_det_exp(float x) { return det_exp(x); }
+
 /* ----------------------------------------------------------- orientation */
 
 /* ComputeOrientationsCONST, cudaSiftD.cu:972-1057, for points [first,last).
@@ -461,8 +533,13 @@ void orc_orientations(const float *img, int w, int h, int pitch, SiftPoint *pts,
     float hist[64];
     float gauss[11];
     float i2sigma2 = -1.0f / (2.0f * 1.5f * 1.5f * p->scale * p->scale);
-    for (int t = 0; t < 11; t++) gauss[t] = expf(i2sigma2 * (t - 5) * (t - 5));
+    for (int t = 0; t < 11; t++) gauss[t] = det_exp(i2sigma2 * (t - 5) * (t - 5));
     for (int t = 0; t < 64; t++) hist[t] = 0.0f;
+    /* The reference adds the 121 weights with shared-memory atomics (cudaSiftD.cu:1013), i.e. in no defined order; the
+     * order fixed here — samples 0..63 and 64..120 summed separately, in index order, then the two partial sums added —
+     * is the one the HIP kernel's two half-wavefront sums produce, so the histograms agree bit for bit. */
+    float hist2[32];
+    for (int t = 0; t < 32; t++) hist2[t] = 0.0f;
     float xp = p->xpos - 4.5f;
     float yp = p->ypos - 4.5f;
     for (int tx = 0; tx < 121; tx++) {
@@ -472,11 +549,13 @@ void orc_orientations(const float *img, int w, int h, int pitch, SiftPoint *pts,
       float yf = yp + yd;
       float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, fracbits) - tex2d(img, w, h, pitch, xf - 1.0f, yf, fracbits);
       float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, fracbits) - tex2d(img, w, h, pitch, xf, yf - 1.0f, fracbits);
-      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+      int bin = (int)(16.0f * det_atan2(dy, dx) / 3.1416f + 16.5f);
       if (bin > 31) bin = 0;
       float grad = sqrtf(mad(dx, dx, dy * dy));
-      hist[bin] += grad * gauss[xd] * gauss[yd];
+      if (tx < 64) hist[bin] += grad * gauss[xd] * gauss[yd];
+      else hist2[bin] += grad * gauss[xd] * gauss[yd];
     }
+    for (int t = 0; t < 32; t++) hist[t] += hist2[t];
     for (int tx = 0; tx < 32; tx++) {
       int x1m = (tx >= 1 ? tx - 1 : tx + 31), x1p = (tx <= 30 ? tx + 1 : tx - 31);
       int x2m = (tx >= 2 ? tx - 2 : tx + 30), x2p = (tx <= 29 ? tx + 2 : tx - 30);
@@ -589,7 +668,7 @@ void orc_descriptors(const float *img, int w, int h, int pitch, SiftPoint *pts, 
                      float subsampling, int fracbits)
 {
   float gauss[16];
-  for (int t = 0; t < 16; t++) gauss[t] = expf(-(t - 7.5f) * (t - 7.5f) / 128.0f);
+  for (int t = 0; t < 16; t++) gauss[t] = det_exp(-(t - 7.5f) * (t - 7.5f) / 128.0f);
 #pragma omp parallel for schedule(dynamic, 16)
   for (int bx = first; bx < last; bx++) {
     SiftPoint *p = &pts[bx];
