@@ -42,11 +42,12 @@ FLOOR_BYTES_PER_FRAME = 31.6e6
 KERNEL_NAMES = {"lowpass_kernel": "lowpass", "lowpass_down_kernel": "lowpass_down", "scaledown_kernel": "scaledown",
                 "scaledown_tail_kernel": "scaledown", "dog_scan_all_kernel": "dog_scan", "dog_scan_kernel": "dog_scan",
                 "refine_all_kernel": "refine", "orient_all_kernel": "orient_all", "descr_all_kernel": "descr_all",
-                "orient_descr_all_kernel": "orient_descr", "bin_detections_kernel": "bin_detections",
+                "orient_all_gather_kernel": "orient_all", "descr_all_gather_kernel": "descr_all", "descr_big_kernel": "descr_all",
+                "bin_detections_kernel": "bin_detections", "renumber_dups_kernel": "renumber_dups",
                 "laplace_kernel": "laplace", "detect_kernel": "detect", "match_kernel": "match_mfma"}
 import numpy as _np
 RESULT_DTYPE_NP = _np.dtype([("score", "<f4"), ("ambiguity", "<f4"), ("match", "<i4")])     # misift_match_sharded's 12 B/row
-GATHER_KERNELS = ("refine", "orient_all", "descr_all", "orient_descr")      # scattered 8-byte reads, not wide streaming
+GATHER_KERNELS = ("refine", "orient_all", "descr_all")      # scattered 8-byte reads, not wide streaming
 
 
 def octave_pixels(w, h, n):
@@ -519,6 +520,39 @@ def main():
         ach = alg[dom] * B / (dom_ms * 1e-3) / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(min(ach / HBM_PEAK_GBS, 1.0), 4)}
+    # The two scan launches of a step run side by side (fine | coarse levels on two streams), so their summed event time
+    # above over-counts the kernel; timed as ONE launch (same work, MISIFT_SPLIT_TAIL=0 context) it is what a stand-alone
+    # rocprof of the kernel would show.  Both fractions are <= 1 by construction; the summed one is the headline (lower).
+    if dom == "dog_scan" and rank == 0:
+        saved = os.environ.get("MISIFT_SPLIT_TAIL")
+        os.environ["MISIFT_SPLIT_TAIL"] = "0"
+        try:
+            c1 = capi.Context(local_rank, stream.cuda_stream)
+        finally:
+            if saved is None:
+                del os.environ["MISIFT_SPLIT_TAIL"]
+            else:
+                os.environ["MISIFT_SPLIT_TAIL"] = saved
+        c1.set_options(quiet=1)
+        c1.profile_enable(True)
+        for i in range(4):
+            capi.check(capi.lib().misift_extract_batch(c1.h, frames[(i % NB) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
+                                                       INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
+                                                       MAX_PTS, counts), "misift_extract_batch")
+        p1 = c1.profile_read()
+        c1.close()
+        if "dog_scan" in p1 and p1["dog_scan"]["calls"] == 4:
+            ms1 = p1["dog_scan"]["total_ms"] / 4
+            a1 = flops_step / (ms1 * 1e-3) / 1e12
+            roofline["single_launch"] = {"ms": round(ms1, 4), "achieved": round(a1, 2),
+                                         "frac": round(min(a1 / VALU_F32_PEAK_TF, 1.0), 4),
+                                         "note": "all pyramid levels in one launch on one stream (no overlap with the coarse ScaleDowns)"}
+    roofline["issue_model"] = {"waves_per_simd": 3, "cycles_per_valu_per_wave": 8,
+                               "note": "tools/valu_rates (profiles/r02_valu_rates.txt): a wavefront issues one VALU instruction per 8 "
+                                       "cycles, a SIMD one per 2 only with >= 4 resident wavefronts; the scan needs 168 VGPRs = 3 "
+                                       "wavefronts, i.e. 3/4 of the issue rate, and ~317 instructions per 584 flop-lanes of a row "
+                                       "(v_pk_fma/mul/add 176, DPP moves 50, sub/max3 32, rest control): ~0.55 of the nominal peak "
+                                       "is the most this instruction stream can reach"}
     roofline["avg_launch_ms"] = round(dom_ms / dom_launches, 4)
     roofline["launches_per_step"] = dom_launches
     roofline["traffic"] = int((pmc[dom]["read"] + pmc[dom]["write"]) / dom_launches) if pmc and dom in pmc else None

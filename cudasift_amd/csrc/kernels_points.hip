@@ -730,9 +730,18 @@ __device__ __forceinline__ bool flat_to_octave(const FrameCounts &c, int noct, i
 // them): wavefronts that run at the same time now work on neighbouring keypoints.  The order inside a tile stays
 // arbitrary, like the reference's atomic append order (cudaSiftD.cu:1420).
 #define BIN_MAX_TILES 4096
+// total order of two detections of one tile (deterministic mode): y, then x, then scale, then sharpness — by bit pattern
+__device__ __forceinline__ bool det_less(const Detection &a, const Detection &b)
+{
+  if (a.ypos != b.ypos) return a.ypos < b.ypos;
+  if (a.xpos != b.xpos) return a.xpos < b.xpos;
+  if (a.scale != b.scale) return a.scale < b.scale;
+  return a.sharpness < b.sharpness;
+}
+
 __global__ __launch_bounds__(256) void bin_detections_kernel(PyramidInfo P, const unsigned *__restrict__ counters,
                                                              const Detection *__restrict__ in,
-                                                             Detection *__restrict__ out, int max_pts)
+                                                             Detection *__restrict__ out, int max_pts, int total_order)
 {
   __shared__ unsigned s_hist[BIN_MAX_TILES];
   __shared__ unsigned s_part[256];
@@ -777,6 +786,46 @@ __global__ __launch_bounds__(256) void bin_detections_kernel(PyramidInfo P, cons
     const Detection d = src[i];
     dst[atomicAdd(&s_hist[key(d)], 1u)] = d;
   }
+  if (!total_order) return;
+  // deterministic mode: the scatter above left every tile's records contiguous (s_hist[t] is now the END of tile t) but
+  // in atomic order; one thread per tile insertion-sorts its handful of records into the total order of det_less
+  __syncthreads();
+  __threadfence_block();
+  for (int t = tid; t < ntiles; t += 256) {
+    const int end = (int)s_hist[t], beg = t ? (int)s_hist[t - 1] : 0;
+    for (int a = beg + 1; a < end; a++) {
+      const Detection v = dst[a];
+      int b = a - 1;
+      while (b >= beg && det_less(v, dst[b])) { dst[b + 1] = dst[b]; b--; }
+      dst[b + 1] = v;
+    }
+  }
+}
+
+// deterministic mode: orient_all handed out the second-orientation slots with atomicAdd, i.e. in completion order;
+// renumber them in keypoint order (one workgroup per (octave, frame), blocked prefix sum over the has-duplicate flags)
+__global__ __launch_bounds__(256) void renumber_dups_kernel(PyramidInfo P, const unsigned *__restrict__ counters,
+                                                            Detection *__restrict__ det, int max_pts)
+{
+  __shared__ int s_part[256];
+  const int o = blockIdx.x + 1, frame = blockIdx.y, tid = threadIdx.x;
+  const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const int n = (int)min(cnt[CNT_DET + o], (unsigned)max_pts);
+  Detection *d = det + ((size_t)frame * MISIFT_MAX_OCTAVES + (o - 1)) * max_pts;
+  const int per = (n + 255) / 256, beg = min(tid * per, n), end = min(beg + per, n);
+  int local = 0;
+  for (int i = beg; i < end; i++) local += d[i].dupslot >= 0 ? 1 : 0;
+  s_part[tid] = local;
+  __syncthreads();
+  for (int ofs = 1; ofs < 256; ofs <<= 1) {
+    const int v = tid >= ofs ? s_part[tid - ofs] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - local;
+  for (int i = beg; i < end; i++)
+    if (d[i].dupslot >= 0) d[i].dupslot = run++;
 }
 
 template <bool Q8>
@@ -1427,7 +1476,15 @@ int launch_bin_detections(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
 {
   LaunchScope ls(ctx, "bin_detections");
   hipLaunchKernelGGL(bin_detections_kernel, dim3(P.noct, P.nframes), dim3(256), 0, ctx->stream, P, ctx->d_counters,
-                     ctx->d_det, ctx->d_det_sorted, max_pts);
+                     ctx->d_det, ctx->d_det_sorted, max_pts, ctx->opt.deterministic ? 1 : 0);
+  return ls.finish();
+}
+
+int launch_renumber_dups(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
+{
+  LaunchScope ls(ctx, "renumber_dups");
+  hipLaunchKernelGGL(renumber_dups_kernel, dim3(P.noct, P.nframes), dim3(256), 0, ctx->stream, P, ctx->d_counters,
+                     ctx->d_det_sorted, max_pts);
   return ls.finish();
 }
 
@@ -1435,7 +1492,7 @@ int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
 {
   (void)pts;
   LaunchScope ls(ctx, "orient_all");
-  Detection *det = ctx->bin_detections ? ctx->d_det_sorted : ctx->d_det;
+  Detection *det = (ctx->bin_detections || ctx->opt.deterministic) ? ctx->d_det_sorted : ctx->d_det;
   const dim3 grid(points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu), P.nframes);
   if (ctx->tile_orient) LAUNCH_Q8(orient_all_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
   else LAUNCH_Q8(orient_all_gather_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
@@ -1446,7 +1503,7 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
                      const int *pack_offsets, SiftPointD *pack_dst)
 {
   LaunchScope ls(ctx, "descr_all");
-  const Detection *det = ctx->bin_detections ? ctx->d_det_sorted : ctx->d_det;
+  const Detection *det = (ctx->bin_detections || ctx->opt.deterministic) ? ctx->d_det_sorted : ctx->d_det;
   const dim3 grid(points_grid_x(ctx, P.nframes), P.nframes);
   if (ctx->tile_descr) {
     // keypoints too large for the LDS window go to a per-frame list in the (by now idle) candidate buffer

@@ -218,6 +218,7 @@ extern "C" void misift_default_options(misift_options *opt)
   if ((e = getenv("MISIFT_MATCH_EXACT_TOP2"))) opt->match_exact_top2 = atoi(e);
   if ((e = getenv("MISIFT_QUIET"))) opt->quiet = atoi(e);
   if ((e = getenv("MISIFT_FUSED"))) opt->fused = atoi(e);
+  if ((e = getenv("MISIFT_DETERMINISTIC"))) opt->deterministic = atoi(e) != 0;
 }
 
 extern "C" void misift_ctx_destroy(misift_ctx *ctx);
@@ -813,12 +814,17 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     }
     rc = launch_refine_all(ctx, d_scratch, P, tapsv.data(), thresh, 10.0f, 1.0f / NUM_SCALES, max_pts);
     if (rc) return rc;
-    if (ctx->bin_detections) {          // spatial order for the per-keypoint kernels (L1/L2 reuse between neighbours)
-      rc = launch_bin_detections(ctx, P, max_pts);
+    const bool binned = ctx->bin_detections || ctx->opt.deterministic;
+    if (binned) {                       // spatial order for the per-keypoint kernels (L1/L2 reuse between neighbours);
+      rc = launch_bin_detections(ctx, P, max_pts);      // deterministic mode: a total order
       if (rc) return rc;
     }
     rc = launch_orient_all(ctx, d_scratch, P, pts, max_pts);
     if (rc) return rc;
+    if (ctx->opt.deterministic) {       // second-orientation slots in keypoint order instead of atomic order
+      rc = launch_renumber_dups(ctx, P, max_pts);
+      if (rc) return rc;
+    }
     if (ctx->pack_dst) {                // counts and offsets are known as soon as the orientations are: pack while writing
       rc = launch_export_counts_staged(ctx, nframes, num_octaves, max_pts, ctx->pack_counts, ctx->pack_offsets);
       if (rc) return rc;

@@ -57,6 +57,13 @@ typedef struct misift_options {
   int quiet;             /* 1 = C++ shim prints nothing per call              */
   int fused;             /* 1 = fused DoG+extrema kernel (no DoG planes in
                             HBM); 0 = separate laplace / findpoints kernels   */
+  int deterministic;     /* 0 = records in atomic-append order within an octave
+                            segment, like the reference (cudaSiftD.cu:1420,
+                            :1043: run-to-run the SET is equal, the order is
+                            not); 1 = order fixed by the keypoints themselves
+                            (tile, y, x, scale): repeated runs are byte-identical
+                            (fused path; also
+                            MISIFT_DETERMINISTIC=1)                           */
 } misift_options;
 
 /* ------------------------------------------------------------------ runtime */

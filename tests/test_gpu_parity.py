@@ -767,3 +767,34 @@ def test_improve_homography_device_vs_oracle(ctx, stereo):
     Ho, no = orc().improve_homography(ref, na, H, 5, 0.0, 0.80, 3.0)                 # mainSift.cpp:78 arguments
     Hg, ng = ctx.improve_homography(d.ptr, na, H, 5, 0.0, 0.80, 3.0)
     assert ng == no and no > 100 and np.array_equal(Ho.view(np.uint32), Hg.view(np.uint32))
+
+
+def test_deterministic_mode_is_byte_identical_across_runs(ctx):
+    """options.deterministic: the reference appends records with atomics, so only the SET is
+    reproducible run to run; with the switch on the order is fixed by the keypoints themselves — repeated runs and a
+    run on another context return byte-identical arrays, and the set still equals the default mode's and the oracle's."""
+    from cudasift_amd import capi
+    imgs = np.stack([synth_frame(2100 + f, 960, 540) for f in range(3)])
+    base_pts, base_n = ctx.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192)
+    ctx.set_options(deterministic=1)
+    try:
+        runs = [ctx.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192) for _ in range(3)]
+    finally:
+        ctx.set_options(deterministic=0)
+    c2 = capi.Context(0)
+    try:
+        c2.set_options(deterministic=1)
+        runs.append(c2.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192))
+    finally:
+        c2.close()
+    for pts, n in runs:
+        assert np.array_equal(n, base_n)
+    for f in range(len(imgs)):
+        n = int(base_n[f])
+        assert n > 300
+        ref_bytes = runs[0][0][f][:n].tobytes()
+        for pts, _ in runs[1:]:
+            assert pts[f][:n].tobytes() == ref_bytes, "deterministic mode must give identical ORDER, frame %d" % f
+        assert _canon(runs[0][0][f][:n]) == _canon(base_pts[f][:n])          # same set as the default mode
+        o, no, _ = orc().extract(imgs[f], num_octaves=5, thresh=3.0, max_pts=8192)
+        compare_points(o[:no], runs[0][0][f][:n], "deterministic_f%d" % f, record)

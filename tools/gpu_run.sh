@@ -1,11 +1,9 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out
-(timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "extract or orient or timed or pipe or findpoints" > gpurun_out/r02_pytest_m.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02_pytest_m.log); tail -3 gpurun_out/r02_pytest_m.log
-python - <<'PY'
+(timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r02_pytest_n.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02_pytest_n.log); tail -4 gpurun_out/r02_pytest_n.log
+timeout 600 python bench.py > gpurun_out/r02_bench_n.json 2> gpurun_out/r02_bench_n.err; echo "bench rc=$?"; tail -3 gpurun_out/r02_bench_n.err
+python -c "
 import json
-d=json.load(open('gpurun_out/parity_report.json'))
-mo=0; md=0; mc=1; ms=0; no=0
-for k,v in sorted(d.items()):
-    if 'desc_outliers' in v:
-        mo=max(mo,v.get('orient_maxdiff_deg_inliers',0)); md=max(md,v.get('desc_maxabs_same_orient',0)); mc=min(mc,v.get('desc_min_cos_same_orient',1)); ms=max(ms,v.get('scale_relerr_max',0)); no+=v['desc_outliers']+v['orient_outliers']
-print("ALL: orient max deg", mo, "desc maxabs", md, "min cos", mc, "scale relerr", ms, "outliers", no)
-PY
+d=json.load(open('gpurun_out/r02_bench_n.json'))
+print(d['value'], d['ms_per_step'], d['validated_frames'], d['step_ms']); print(json.dumps(d['kernels'])); print(json.dumps(d['roofline'])[:1500]); print(d['cpu_baseline']); print(d['match']['value'], d['match']['roofline']['frac'], d['match'].get('validated_rows'))"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r02 -o s --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --no-cpu --no-pcie --no-latency --no-pmc > $GRAFT_REPO_ROOT/gpurun_out/prof_r02.log 2>&1); ls gpurun_out/prof_r02 | head; head -30 gpurun_out/prof_r02/*kernel_stats.csv 2>/dev/null | cut -c1-200
+bash tools/pmc_pass.sh r02_pmc_traffic "FETCH_SIZE" "WRITE_SIZE" 2>&1 | grep -E "^kernel|descr|orient|refine|dog_scan|lowpass|scaledown|bin_"
