@@ -633,7 +633,7 @@ def main():
     pcie = None
     if rank == 0 and world == 1 and not args.no_pcie:
         torch.cuda.synchronize()
-        nb, nbatches = 16, 12
+        nb, nbatches = 16, 16
         pcie = {"batch_frames": nb, "batches": nbatches, "depth": 3,
                 "note": "misift_pipe: pinned host frames uploaded, valid SiftPoint records packed and downloaded, "
                         "upload/compute/read-back overlapped; never `value`"}
@@ -655,10 +655,13 @@ def main():
                     tot += pipe.collect(host_recs.ptr, nb * 4096)[1]
                 return tot
             prun(3)
-            tp0 = time.perf_counter()
-            tot = prun(nbatches)
-            pdt = time.perf_counter() - tp0
-            pcie[key] = round(nb * nbatches / pdt, 1)
+            best = None
+            for _ in range(2):                      # short measurement on a shared host: best of two
+                tp0 = time.perf_counter()
+                tot = prun(nbatches)
+                pdt = time.perf_counter() - tp0
+                best = pdt if best is None else min(best, pdt)
+            pcie[key] = round(nb * nbatches / best, 1)
             pcie["records_per_frame"] = round(tot / (nb * nbatches), 1)
             pipe.close()
             src.free()
