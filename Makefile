@@ -13,7 +13,7 @@ HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_
             $(CSRC)/multigpu.hip
 HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
-all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so cudasift_amd/libcudasift_managed.so oracle dropin build/pmc_calib build/valu_rates
+all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so cudasift_amd/libcudasift_managed.so oracle dropin build/pmc_calib build/valu_rates build/scan_rates
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
 	@mkdir -p $(BUILD)
@@ -34,6 +34,11 @@ build/pmc_calib: tools/pmc_calib.hip
 build/valu_rates: tools/valu_rates.hip
 	@mkdir -p $(BUILD)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
+
+# the instruction stream of one dog_scan row in isolation (why the scan stops where it does)
+build/scan_rates: tools/scan_rates.hip
+	@mkdir -p $(BUILD)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o $@ $<
 
 # the MANAGEDMEM flavour of the drop-in API (cudaSift.h:27-32: SiftData holds ONE managed pointer, m_data)
 cudasift_amd/libcudasift_managed.so: $(CSRC)/shim_cudasift.cpp include/cudaSift.h include/cudaImage.h include/misift.h cudasift_amd/libmisift.so

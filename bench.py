@@ -121,6 +121,8 @@ def pmc_child():
             ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), None,
             MAX_PTS, cnts.data_ptr(), cnts[B:].data_ptr(), packed.data_ptr()), "misift_extract_batch_packed_async")
         torch.cuda.synchronize()
+    for c in ctxs[1:]:
+        c.close()
     ctx.close()
 
 
@@ -301,6 +303,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--batches", type=int, default=NUM_BATCHES, help="distinct batches per rank to rotate through")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="contexts (own stream, staging and scratch arena each) the steps rotate over = batches in flight on the "
+                         "GPU.  4 measures ~8 %% more frames/s (profiles/r02_bench_contexts4.json) but every kernel's duration is "
+                         "then stretched by its neighbours, so the per-kernel roofline is quoted on the default, 1")
     ap.add_argument("--match-n", type=int, default=100000)
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg AND the oracle self-validation")
@@ -333,8 +339,15 @@ def main():
 
     B, NB = args.frames_per_gpu, max(1, args.batches)
     stream = torch.cuda.current_stream()
+    # One context = one in-order pipeline (stream, counters, candidate lists, detection staging).  The steps rotate over
+    # NCTX of them, each with its own scratch arena, so that NCTX batches are in flight: the HBM-bound front end of one
+    # batch, the VALU-bound kernels of another and the launch tails of a third share the GPU.
+    NCTX = 1 if args.unfused else max(1, args.contexts)      # the dense path shares one record array
     ctx = capi.Context(local_rank, stream.cuda_stream)
-    ctx.set_options(quiet=1, fused=0 if args.unfused else 1)
+    ctx_streams = [stream] + [torch.cuda.Stream(device=device) for _ in range(NCTX - 1)]
+    ctxs = [ctx] + [capi.Context(local_rank, st.cuda_stream) for st in ctx_streams[1:]]
+    for c in ctxs:
+        c.set_options(quiet=1, fused=0 if args.unfused else 1)
 
     # the data-path communicator lives behind the C-ABI (RCCL over xGMI): rank 0 makes the id, torch ships it
     comm = None
@@ -350,7 +363,8 @@ def main():
     frames = torch.empty((NB * B, H, W), dtype=torch.float32, device=device)
     gen_frames_torch(torch, NB * B, rank * NB * B, device, out=frames)
     S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
-    scratch = torch.empty((B * S,), dtype=torch.float32, device=device)
+    scratches = [torch.empty((B * S,), dtype=torch.float32, device=device) for _ in range(NCTX)]
+    scratch = scratches[0]
     pts = torch.zeros((B * MAX_PTS * 576,), dtype=torch.uint8, device=device) if args.unfused else None
     counts = (C.c_int * B)()
     torch.cuda.synchronize()
@@ -361,7 +375,8 @@ def main():
     # rank 0 (misift_gather_post / misift_gather_complete on the communicator's own stream), overlapping the
     # extraction of the batches queued behind it.  Every batch's read-back/gather completes before the closing
     # barrier: nothing is skipped, only overlapped.
-    NSLOT, LAG = 3, 2
+    LAG = NCTX + 1                      # the host completes batch k-LAG: NCTX batches stay queued on the GPU
+    NSLOT = LAG + 1
     REC_CAP = MAX_PTS                   # mainSift.cpp:58-67 capacity (32768 records per frame)
     packed = [torch.empty((B * REC_CAP * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
     cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(NSLOT)]
@@ -373,19 +388,21 @@ def main():
     def enqueue(k):
         slot = k % NSLOT
         b0 = (k % NB) * B
+        ci = k % NCTX
         capi.check(capi.lib().misift_extract_batch_packed_async(
-            ctx.h, frames[b0].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(),
+            ctxs[ci].h, frames[b0].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0,
+            scratches[ci].data_ptr(),
             pts.data_ptr() if args.unfused else None,      # merged-octave path writes the packed array directly
             REC_CAP, cnts[slot].data_ptr(), cnts[slot][B:].data_ptr(), packed[slot].data_ptr()),
             "misift_extract_batch_packed_async")
         if comm is not None:
-            comm.gather_post(slot, cnts[slot].data_ptr(), B, packed[slot].data_ptr())
+            comm.gather_post(slot, cnts[slot].data_ptr(), B, packed[slot].data_ptr(), ctx=ctxs[ci])
         else:
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(ctx_streams[ci])
             done_ev[slot] = ev
         e = torch.cuda.Event(enable_timing=True)
-        e.record()
+        e.record(ctx_streams[ci])
         step_ev.append(e)
 
     def complete(k):
@@ -437,11 +454,13 @@ def main():
     fps = world * B * args.steps / dt
     # distribution of the pipelined loop's steps on the GPU timeline (median + p10/p90)
     step_ms = None
-    if rank == 0 and len(step_ev) >= 3:
-        d = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(len(step_ev) - 1)])
+    if rank == 0 and len(step_ev) >= NCTX + 2:
+        # step k and step k+NCTX end on the same stream: that interval / NCTX is the loop's period seen from one context
+        d = np.array([step_ev[i].elapsed_time(step_ev[i + NCTX]) / NCTX for i in range(len(step_ev) - NCTX)])
         step_ms = {"p10": round(float(np.percentile(d, 10)), 4), "p50": round(float(np.percentile(d, 50)), 4),
                    "p90": round(float(np.percentile(d, 90)), 4), "samples": int(len(d)),
-                   "note": "HIP-event interval between consecutive steps of the timed, pipelined loop"}
+                   "note": "HIP-event interval between the ends of steps k and k+contexts (same stream) / contexts, "
+                           "over the timed, pipelined loop"}
 
     # ---------------- the timed loop's LAST step, kept for the self-validation below
     last_slot, last_b0 = last_k % NSLOT, (last_k % NB) * B
@@ -452,15 +471,35 @@ def main():
     # ---------------- per-kernel durations (HIP events on the launch stream) for the roofline
     if pts is None:
         pts = torch.zeros((B * MAX_PTS * 576,), dtype=torch.uint8, device=device)
+    # (a) with more than one context: in the timed configuration (the same rotation, every context records its own kernels)
+    prof, psteps = None, 5 * NCTX
+    if NCTX > 1:
+        for c in ctxs:
+            c.profile_reset()
+            c.profile_enable(True)
+        for k in range(psteps):
+            enqueue(last_k + 1 + k)
+        torch.cuda.synchronize()
+        prof = {}
+        for c in ctxs:
+            for name, p in c.profile_read().items():
+                e = prof.setdefault(name, {"total_ms": 0.0, "calls": 0})
+                e["total_ms"] += p["total_ms"]
+                e["calls"] += p["calls"]
+            c.profile_enable(False)
+        step_ev.clear()
+    # (b) every kernel alone on the GPU: one context, one batch at a time
     ctx.profile_reset()
     ctx.profile_enable(True)
-    psteps = 5
-    for i in range(psteps):
+    asteps = 5
+    for i in range(asteps):
         capi.check(capi.lib().misift_extract_batch(ctx.h, frames[(i % NB) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
                                                    INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
                                                    MAX_PTS, counts), "misift_extract_batch")
-    prof = ctx.profile_read()
+    prof_alone = ctx.profile_read()
     ctx.profile_enable(False)
+    if prof is None:
+        prof, psteps = prof_alone, asteps
     alg = algorithmic_bytes_per_frame()
     N = octave_pixels(W, H, NUM_OCTAVES)
     if "lowpass_down" in prof:
@@ -472,6 +511,8 @@ def main():
     for name, p in prof.items():
         per_step_ms = p["total_ms"] / psteps
         e = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": p["calls"] // psteps}
+        if NCTX > 1 and name in prof_alone:
+            e["alone_ms_per_step"] = round(prof_alone[name]["total_ms"] / asteps, 4)
         if name in alg:
             e["alg_GBps"] = round(alg[name] * B / (per_step_ms * 1e-3) / 1e9, 1)
         kernels[name] = e
@@ -547,12 +588,21 @@ def main():
             roofline["single_launch"] = {"ms": round(ms1, 4), "achieved": round(a1, 2),
                                          "frac": round(min(a1 / VALU_F32_PEAK_TF, 1.0), 4),
                                          "note": "all pyramid levels in one launch on one stream (no overlap with the coarse ScaleDowns)"}
-    roofline["issue_model"] = {"waves_per_simd": 3, "cycles_per_valu_per_wave": 8,
-                               "note": "tools/valu_rates (profiles/r02_valu_rates.txt): a wavefront issues one VALU instruction per 8 "
-                                       "cycles, a SIMD one per 2 only with >= 4 resident wavefronts; the scan needs 168 VGPRs = 3 "
-                                       "wavefronts, i.e. 3/4 of the issue rate, and ~317 instructions per 584 flop-lanes of a row "
-                                       "(v_pk_fma/mul/add 176, DPP moves 50, sub/max3 32, rest control): ~0.55 of the nominal peak "
-                                       "is the most this instruction stream can reach"}
+    if dom == "dog_scan" and "alone_ms_per_step" in kernels[dom]:      # only with --contexts > 1
+        ams = kernels[dom]["alone_ms_per_step"]
+        aa = flops_step / (ams * 1e-3) / 1e12
+        roofline["alone"] = {"ms_per_step": ams, "achieved": round(aa, 2), "frac": round(min(aa / VALU_F32_PEAK_TF, 1.0), 4),
+                             "note": "one batch at a time on one context (nothing else on the GPU); launch durations summed"}
+    roofline["issue_model"] = {
+        "cycles_per_wave64_instruction_per_simd": {"v_fma/mul/add/sub_f32, v_add_u32": 2.85, "v_pk_fma/mul/add_f32": 4.45,
+                                                   "DPP moves, v_max3, cvt, floor, integer mul/shift-add, v_cndmask": 4.7,
+                                                   "transcendentals": 8.5},
+        "note": "tools/valu_rates, tools/scan_rates (profiles/r02_valu_rates.txt, r02_scan_rates.txt; whole-kernel times): "
+                "a SIMD is saturated from 2-3 resident wavefronts on, occupancy beyond that buys nothing.  One scan row is 96 "
+                "v_pk_fma + 24 v_pk_mul + 56 v_pk_add + 48 DPP moves + 20 v_sub + 10 v_max3 = ~1085 cycles for 35.1 kflop "
+                "executed (isolated: 1085 measured), i.e. 0.50 of 64 flop/cycle/SIMD is the ceiling of this instruction "
+                "stream before halo lanes, segment prologues and the extremum tests; the kernel runs at ~0.88 of its own "
+                "instruction-issue bound (SQ_INSTS_VALU x cost / SIMD cycles)"}
     roofline["avg_launch_ms"] = round(dom_ms / dom_launches, 4)
     roofline["launches_per_step"] = dom_launches
     roofline["traffic"] = int((pmc[dom]["read"] + pmc[dom]["write"]) / dom_launches) if pmc and dom in pmc else None
@@ -565,10 +615,11 @@ def main():
         if k == "scaledown" and split:
             continue      # runs beside the fine-level scan on a second stream: its duration says nothing about HBM
         if k in kernels:
-            a = alg[k] * B / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
-            hbm_kernels[k] = {"alg_GBps": round(a, 1), "alg_frac": round(a / HBM_PEAK_GBS, 4)}
+            kms = kernels[k].get("alone_ms_per_step", kernels[k]["ms_per_step"])     # bandwidth of the kernel ALONE on the GPU
+            a = alg[k] * B / (kms * 1e-3) / 1e9
+            hbm_kernels[k] = {"ms_per_step": kms, "alg_GBps": round(a, 1), "alg_frac": round(a / HBM_PEAK_GBS, 4)}
             if pmc and k in pmc:
-                t = (pmc[k]["read"] + pmc[k]["write"]) / (kernels[k]["ms_per_step"] * 1e-3) / 1e9
+                t = (pmc[k]["read"] + pmc[k]["write"]) / (kms * 1e-3) / 1e9
                 hbm_kernels[k]["traffic_GBps"] = round(t, 1)
                 hbm_kernels[k]["traffic_frac"] = round(t / HBM_PEAK_GBS, 4)
     roofline["hbm_bound_kernels"] = hbm_kernels
@@ -746,7 +797,9 @@ def main():
                                       "(%d distinct frames per GPU; BASELINE config 4: 512 frames over 8 GPUs), ExtractSift "
                                       "5 octaves initBlur 1.0 thresh 3.0 maxPts 32768, frames resident in HBM, count read-back%s"
                                       % (B, NB, NB * B, " + RCCL gather of SiftData to rank 0 (misift_gather_*)" if comm else ""),
-                          "frames_per_gpu": B, "distinct_frames_per_gpu": NB * B,
+                          "frames_per_gpu": B, "distinct_frames_per_gpu": NB * B, "contexts": NCTX,
+                          "contexts_note": "the steps rotate over this many misift contexts per GPU (own stream, staging and "
+                                           "scratch arena each): that many batches are in flight on the GPU",
                           "path": "unfused" if args.unfused else "fused dog+detect",
                           "keypoints_per_frame": round(kp_per_frame, 1)},
                "validated_frames": validated,
@@ -756,15 +809,21 @@ def main():
                if validated else "skipped (--no-cpu)",
                "roofline": roofline, "kernels": kernels, "step_ms": step_ms, "match": match, "cpu_baseline": cpu,
                "pcie_inclusive": pcie, "single_frame": latency,
-               "kernels_note": "per-kernel times are HIP-event durations on the launch stream from 5 profiled synchronous "
-                               "steps; dog_scan runs as two launches per step (fine levels on the context stream, the coarse "
-                               "ScaleDowns + coarse levels beside it on a second stream) whose durations overlap, so the "
-                               "per-kernel times add up to more than the step"}
+               "kernels_note": "ms_per_step = HIP-event durations on the launch stream(s) over 5 profiled steps in the timed "
+                               "configuration; dog_scan runs as two launches per step (fine levels on the context stream, the "
+                               "coarse ScaleDowns + coarse levels beside it on a second stream) whose durations overlap, so the "
+                               "per-kernel times add up to more than the step.  With --contexts > 1 kernels of several batches "
+                               "share the GPU, every duration is stretched by its neighbours (they add up to ~contexts x the "
+                               "step) and alone_ms_per_step gives the same kernels with one batch at a time on one context"}
         print(json.dumps(out))
     if comm is not None:
         comm.close()
     if world > 1:
         dist.destroy_process_group()
+    for c in ctxs[1:]:
+        c.close()
+    for c in ctxs[1:]:
+        c.close()
     ctx.close()
 
 

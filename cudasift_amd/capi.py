@@ -471,8 +471,9 @@ class Comm:
     def barrier(self):
         check(lib().misift_comm_barrier(self.h), "misift_comm_barrier")
 
-    def gather_post(self, slot, d_counts, nframes, d_packed):
-        check(lib().misift_gather_post(self.ctx.h, self.h, slot, d_counts, nframes, d_packed), "misift_gather_post")
+    def gather_post(self, slot, d_counts, nframes, d_packed, ctx=None):
+        """ctx: the context (of the communicator's device) whose stream produced the buffers; default = the communicator's own."""
+        check(lib().misift_gather_post((ctx or self.ctx).h, self.h, slot, d_counts, nframes, d_packed), "misift_gather_post")
 
     def gather_complete(self, slot, nframes, root=0, d_recv=None, capacity_records=0):
         """Returns (all_counts [size, nframes] int32, rank offsets [size+1] in records)."""

@@ -413,6 +413,139 @@ struct LdsTaps {
   __device__ __forceinline__ Taps2 pair(int p) const { return load_taps2(tk + 5 * p); }
 };
 
+#ifndef SCAN_RING
+#define SCAN_RING 1
+#endif
+#ifndef SCAN_DO_TEST
+#define SCAN_DO_TEST 1
+#endif
+#ifndef SCAN_TAP_PREFETCH
+#define SCAN_TAP_PREFETCH (!SCAN_RING)
+#endif
+struct ScanRowCtx {
+  int width, height, q;
+  bool tester;
+  float thresh;
+  unsigned *cnt, *list;
+  unsigned cand_cap;
+  int octave;
+};
+// One row of the scan from the centre row `c` and the four vertical pair sums p1..p4 of its 9-row window.
+template <typename TAPS>
+__device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx &g, const float4 c, const float4 p1,
+                                         const float4 p2, const float4 p3, const float4 p4, const int y)
+{
+  const bool tester = g.tester;
+  const int q = g.q;
+  const float thresh = g.thresh;
+  unsigned *const cnt = g.cnt, *const list = g.list;
+  const unsigned cand_cap = g.cand_cap;
+  const int octave = g.octave;
+  // Only blurs 1..6 are computed here: they give the five centre DoG planes d[0..4] (= reference planes
+  // 1..5), which is all the necessary condition below needs; the outermost planes 0 and 6 (blurs 0 and 7)
+  // are evaluated only for the survivors, by refine.  A quarter of the blur work of the dense path is saved.
+  // The six blurs are computed as three scale pairs (see blur_pair); the tap pairs of the next scale pair
+  // are fetched from LDS while the current one is computed.
+  float4 d[NUM_SCALES];
+#if SCAN_TAP_PREFETCH
+  Taps2 tcur = taps_src.pair(0), tnext = taps_src.pair(1);
+  __builtin_amdgcn_sched_barrier(0);
+  const Pair4 b0 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 1, 2
+  tcur = tnext;
+  asm volatile("" ::: "memory");                                 // re-read from LDS: do not pin tap pairs across the row loop
+  tnext = taps_src.pair(2);
+  __builtin_amdgcn_sched_barrier(0);
+  d[0] = make_float4(b0.x.y - b0.x.x, b0.y.y - b0.y.x, b0.z.y - b0.z.x, b0.w.y - b0.w.x);
+  const Pair4 b1 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 3, 4
+  tcur = tnext;
+  __builtin_amdgcn_sched_barrier(0);
+  d[1] = make_float4(b1.x.x - b0.x.y, b1.y.x - b0.y.y, b1.z.x - b0.z.y, b1.w.x - b0.w.y);
+  d[2] = make_float4(b1.x.y - b1.x.x, b1.y.y - b1.y.x, b1.z.y - b1.z.x, b1.w.y - b1.w.x);
+  const Pair4 b2 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 5, 6
+#else
+  // one set of tap pairs at a time (10 registers instead of 20): with four wavefronts per SIMD the LDS latency of the
+  // re-read hides under the other wavefronts
+  Taps2 tcur = taps_src.pair(0);
+  __builtin_amdgcn_sched_barrier(0);
+  const Pair4 b0 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 1, 2
+  asm volatile("" ::: "memory");
+  tcur = taps_src.pair(1);
+  __builtin_amdgcn_sched_barrier(0);
+  d[0] = make_float4(b0.x.y - b0.x.x, b0.y.y - b0.y.x, b0.z.y - b0.z.x, b0.w.y - b0.w.x);
+  const Pair4 b1 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 3, 4
+  asm volatile("" ::: "memory");
+  tcur = taps_src.pair(2);
+  __builtin_amdgcn_sched_barrier(0);
+  d[1] = make_float4(b1.x.x - b0.x.y, b1.y.x - b0.y.y, b1.z.x - b0.z.y, b1.w.x - b0.w.y);
+  d[2] = make_float4(b1.x.y - b1.x.x, b1.y.y - b1.y.x, b1.z.y - b1.z.x, b1.w.y - b1.w.x);
+  const Pair4 b2 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 5, 6
+#endif
+  d[3] = make_float4(b2.x.x - b1.x.y, b2.y.x - b1.y.y, b2.z.x - b1.z.y, b2.w.x - b1.w.y);
+  d[4] = make_float4(b2.x.y - b2.x.x, b2.y.y - b2.y.x, b2.z.y - b2.z.x, b2.w.y - b2.w.x);
+  float amax = 0.0f;
+#pragma unroll
+  for (int p = 0; p < NUM_SCALES; p++)
+    amax = max3f(max3f(amax, fabsf(d[p].x), fabsf(d[p].y)), fabsf(d[p].z), fabsf(d[p].w));   // two v_max3_f32 per plane
+  // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
+  // (tester lanes only: the halo lanes' blurs see zeros beyond the wavefront and would trip the test in every row —
+  //  with them masked, 99 % of the finest level's rows of a typical frame skip the extremum tests)
+  if (!SCAN_DO_TEST) {                           // register-pressure probe only (tools/kres.sh -DSCAN_DO_TEST=0)
+    if (__any(tester && amax > thresh)) {
+#pragma unroll
+      for (int p = 0; p < NUM_SCALES; p++) reinterpret_cast<float4 *>(list)[p * 64 + (q & 63)] = d[p];
+    }
+  } else if (y >= 1 && y <= g.height - 2 && __any(tester && amax > thresh)) {
+    unsigned mask = 0;
+#pragma unroll
+    for (int s = 0; s < NUM_SCALES; s++) {
+      // in-row neighbourhood of centre plane d[s]: columns x-1, x, x+1 of d[s-1], d[s], d[s+1] (where available)
+      float lo[4], hi[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+#pragma unroll
+      for (int dp = -1; dp <= 1; dp += 2) {
+        if (s + dp < 0 || s + dp >= NUM_SCALES) continue;
+        const float4 e = d[s + dp];
+        const float v[6] = {lane_from_left(e.w), e.x, e.y, e.z, e.w, lane_from_right(e.x)};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          lo[i] = fminf(lo[i], min3f(v[i], v[i + 1], v[i + 2]));
+          hi[i] = fmaxf(hi[i], max3f(v[i], v[i + 1], v[i + 2]));
+        }
+      }
+      const float4 c = d[s];
+      const float v[6] = {lane_from_left(c.w), c.x, c.y, c.z, c.w, lane_from_right(c.x)};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float nmax = max3f(hi[i], v[i], v[i + 2]);
+        const float nmin = min3f(lo[i], v[i], v[i + 2]);
+        const float cv = v[i + 1];
+        const bool pre = (cv > thresh && cv > nmax) || (cv < -thresh && cv < nmin);
+        mask |= (pre ? 1u : 0u) << (5 * i + s);
+      }
+      __builtin_amdgcn_sched_barrier(0);         // one scale at a time: the rare path must not set the register budget
+    }
+    // columns 0 and width-1 can never hold an extremum either
+    if (!tester) mask = 0;
+    if (4 * q == 0) mask &= ~31u;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (4 * q + i >= g.width - 1) mask &= ~(31u << (5 * i));
+    if (mask) {
+      const unsigned n = __popc(mask);
+      unsigned idx = atomicAdd(&cnt[CNT_CAND + octave], n);
+      while (mask) {
+        const int b = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const unsigned code = (unsigned)(4 * q + b / 5) | ((unsigned)y << 14) | ((unsigned)(b % 5) << 28);
+        if (idx < cand_cap) list[idx] = code;
+        else atomicAdd(&cnt[CNT_CANDOVF], 1u);
+        idx++;
+      }
+    }
+  }
+}
+
 template <bool FAST, typename TAPS>
 __device__ __forceinline__ void scan_strip(const float *img, int width, int height, int pitch, int q, int lane,
                                            int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
@@ -420,6 +553,7 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
 {
   struct { int width, height, pitch; } g = {width, height, pitch};
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
+  const ScanRowCtx rc = {width, height, q, tester, thresh, cnt, list, cand_cap, octave};
   const QuadCol qc = make_quadcol(q, g.width);
   auto ld = [&](int y) -> float4 {
     return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
@@ -433,84 +567,7 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
     // re-read the taps from LDS every row instead of pinning 80 VGPRs across the loop
     asm volatile("" ::: "memory");
     const float4 c = r4, p1 = add4p(r3, r5), p2 = add4p(r2, r6), p3 = add4p(r1, r7), p4 = add4p(r0, r8);
-    // Only blurs 1..6 are computed here: they give the five centre DoG planes d[0..4] (= reference planes
-    // 1..5), which is all the necessary condition below needs; the outermost planes 0 and 6 (blurs 0 and 7)
-    // are evaluated only for the survivors, by refine.  A quarter of the blur work of the dense path is saved.
-    // The six blurs are computed as three scale pairs (see blur_pair); the tap pairs of the next scale pair
-    // are fetched from LDS while the current one is computed.
-    float4 d[NUM_SCALES];
-    Taps2 tcur = taps_src.pair(0), tnext = taps_src.pair(1);
-    __builtin_amdgcn_sched_barrier(0);
-    const Pair4 b0 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 1, 2
-    tcur = tnext;
-    asm volatile("" ::: "memory");                                 // re-read from LDS: do not pin tap pairs across the row loop
-    tnext = taps_src.pair(2);
-    __builtin_amdgcn_sched_barrier(0);
-    d[0] = make_float4(b0.x.y - b0.x.x, b0.y.y - b0.y.x, b0.z.y - b0.z.x, b0.w.y - b0.w.x);
-    const Pair4 b1 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 3, 4
-    tcur = tnext;
-    __builtin_amdgcn_sched_barrier(0);
-    d[1] = make_float4(b1.x.x - b0.x.y, b1.y.x - b0.y.y, b1.z.x - b0.z.y, b1.w.x - b0.w.y);
-    d[2] = make_float4(b1.x.y - b1.x.x, b1.y.y - b1.y.x, b1.z.y - b1.z.x, b1.w.y - b1.w.x);
-    const Pair4 b2 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 5, 6
-    d[3] = make_float4(b2.x.x - b1.x.y, b2.y.x - b1.y.y, b2.z.x - b1.z.y, b2.w.x - b1.w.y);
-    d[4] = make_float4(b2.x.y - b2.x.x, b2.y.y - b2.y.x, b2.z.y - b2.z.x, b2.w.y - b2.w.x);
-    float amax = 0.0f;
-#pragma unroll
-    for (int p = 0; p < NUM_SCALES; p++)
-      amax = max3f(max3f(amax, fabsf(d[p].x), fabsf(d[p].y)), fabsf(d[p].z), fabsf(d[p].w));   // two v_max3_f32 per plane
-    // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
-    // (tester lanes only: the halo lanes' blurs see zeros beyond the wavefront and would trip the test in every row —
-    //  with them masked, 99 % of the finest level's rows of a typical frame skip the extremum tests)
-    if (y >= 1 && y <= g.height - 2 && __any(tester && amax > thresh)) {
-      unsigned mask = 0;
-#pragma unroll
-      for (int s = 0; s < NUM_SCALES; s++) {
-        // in-row neighbourhood of centre plane d[s]: columns x-1, x, x+1 of d[s-1], d[s], d[s+1] (where available)
-        float lo[4], hi[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) { lo[i] = INFINITY; hi[i] = -INFINITY; }
-#pragma unroll
-        for (int dp = -1; dp <= 1; dp += 2) {
-          if (s + dp < 0 || s + dp >= NUM_SCALES) continue;
-          const float4 e = d[s + dp];
-          const float v[6] = {lane_from_left(e.w), e.x, e.y, e.z, e.w, lane_from_right(e.x)};
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            lo[i] = fminf(lo[i], min3f(v[i], v[i + 1], v[i + 2]));
-            hi[i] = fmaxf(hi[i], max3f(v[i], v[i + 1], v[i + 2]));
-          }
-        }
-        const float4 c = d[s];
-        const float v[6] = {lane_from_left(c.w), c.x, c.y, c.z, c.w, lane_from_right(c.x)};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const float nmax = max3f(hi[i], v[i], v[i + 2]);
-          const float nmin = min3f(lo[i], v[i], v[i + 2]);
-          const float cv = v[i + 1];
-          const bool pre = (cv > thresh && cv > nmax) || (cv < -thresh && cv < nmin);
-          mask |= (pre ? 1u : 0u) << (5 * i + s);
-        }
-      }
-      // columns 0 and width-1 can never hold an extremum either
-      if (!tester) mask = 0;
-      if (4 * q == 0) mask &= ~31u;
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (4 * q + i >= g.width - 1) mask &= ~(31u << (5 * i));
-      if (mask) {
-        const unsigned n = __popc(mask);
-        unsigned idx = atomicAdd(&cnt[CNT_CAND + octave], n);
-        while (mask) {
-          const int b = __ffs(mask) - 1;
-          mask &= mask - 1;
-          const unsigned code = (unsigned)(4 * q + b / 5) | ((unsigned)y << 14) | ((unsigned)(b % 5) << 28);
-          if (idx < cand_cap) list[idx] = code;
-          else atomicAdd(&cnt[CNT_CANDOVF], 1u);
-          idx++;
-        }
-      }
-    }
+    scan_row(taps_src, rc, c, p1, p2, p3, p4, y);
   };
   int y = y0;
 #if SCAN_UNROLL3
@@ -531,6 +588,68 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
   }
 }
 
+#ifndef SCAN_RING
+#define SCAN_RING 1
+#endif
+#define RING_ROWS 9
+#define RING_FLOAT4S (RING_ROWS * 64)            // per wavefront: 9 rows x 64 lanes x 16 B = 9 KiB
+// The same scan with the 9-row window in LDS instead of 36 VGPRs: every lane parks its quad of each incoming row in a
+// ring of nine slots (its own 16 bytes of each slot: no other lane ever reads them, so no barriers) and re-reads the
+// nine quads at the start of a row.  That is what brings the kernel from 168 to <= 128 registers = from 3 to 4
+// wavefronts per SIMD, and the issue rate of a SIMD is min(waves, 4) / 8 instructions per cycle.  The row
+// loop is unrolled nine times so that every slot is an immediate offset of the ds_read_b128 / ds_write_b128.
+template <bool FAST, typename TAPS>
+__device__ __forceinline__ void scan_strip_ring(const float *img, int width, int height, int pitch, int q, int lane,
+                                                int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
+                                                unsigned *list, unsigned cand_cap, int octave, bool al, float4 *mine)
+{
+  struct { int width, height, pitch; } g = {width, height, pitch};
+  const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
+  const ScanRowCtx rc = {width, height, q, tester, thresh, cnt, list, cand_cap, octave};
+  const QuadCol qc = make_quadcol(q, g.width);
+  auto ld = [&](int y) -> float4 {
+    return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
+  };
+#pragma unroll
+  for (int k = 0; k < RING_ROWS; k++) mine[k * 64] = ld(y0 - 4 + k);          // slot k = row y0 - 4 + k
+  float4 n = ld(y0 + 5);                                                      // one row ahead, in registers
+  // one row: o0..o8 = slots (in float4 units) of rows y-4 .. y+4
+  auto row = [&](const int o0, const int o1, const int o2, const int o3, const int o4, const int o5, const int o6,
+                 const int o7, const int o8, const int y) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    const float4 p4 = add4p(mine[o0], mine[o8]), p3 = add4p(mine[o1], mine[o7]), p2 = add4p(mine[o2], mine[o6]),
+                 p1 = add4p(mine[o3], mine[o5]), c = mine[o4];
+    scan_row(taps_src, rc, c, p1, p2, p3, p4, y);
+    asm volatile("" ::: "memory");
+    const float4 nn = ld(y + 6);               // next prefetch first, then park the row that has arrived:
+    mine[o0] = n;                              // row y+5 takes the slot of row y-4
+    n = nn;
+  };
+#define RING_SLOT(J, K) ((((J) + (K)) % RING_ROWS) * 64)
+#define RING_STEP(J)                                                                                                  \
+  row(RING_SLOT(J, 0), RING_SLOT(J, 1), RING_SLOT(J, 2), RING_SLOT(J, 3), RING_SLOT(J, 4), RING_SLOT(J, 5),            \
+      RING_SLOT(J, 6), RING_SLOT(J, 7), RING_SLOT(J, 8), y + (J))
+  int y = y0;
+  for (; y + RING_ROWS - 1 < y1; y += RING_ROWS) {
+    RING_STEP(0); RING_STEP(1); RING_STEP(2); RING_STEP(3); RING_STEP(4); RING_STEP(5); RING_STEP(6); RING_STEP(7);
+    RING_STEP(8);
+  }
+  // the last rows of the segment (fewer than nine): same thing with the ring phase in a scalar register
+  int ph = 0;
+  for (; y < y1; y++) {
+    int o[RING_ROWS];
+#pragma unroll
+    for (int k = 0; k < RING_ROWS; k++) {
+      const int t = ph + k;
+      o[k] = __builtin_amdgcn_readfirstlane((t >= RING_ROWS ? t - RING_ROWS : t) * 64);
+    }
+    row(o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], y);
+    ph = ph + 1 == RING_ROWS ? 0 : ph + 1;
+  }
+#undef RING_STEP
+#undef RING_SLOT
+}
+
 template <bool FAST, int OCC>
 __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restrict__ base, StripGeom g,
                                                             LaplaceTaps taps, float thresh, int octave,
@@ -546,9 +665,17 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
   // lanes 0,63: blur halo; lanes 1,62: DoG column-neighbour halo; lanes 2..61 test their quads
   const int q = it.strip * (OUT_LANES - 2) + lane - 2;
   const int y0 = it.seg * g.seg_rows;
+#if SCAN_RING
+  __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
+  scan_strip_ring<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
+                        min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh,
+                        counters + (size_t)it.frame * CNT_STRIDE, cand + (size_t)it.frame * cand_cap, cand_cap, octave,
+                        aligned != 0, &s_win[threadIdx.x >> 6][lane]);
+#else
   scan_strip<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
                    min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh, counters + (size_t)it.frame * CNT_STRIDE,
                    cand + (size_t)it.frame * cand_cap, cand_cap, octave, aligned != 0);
+#endif
 }
 
 // ---- merged-octave scan: ONE launch walks the strips of every pyramid level of every frame.
@@ -566,7 +693,7 @@ struct ScanAllGeom {
 };
 
 #ifndef SCAN_OCC
-#define SCAN_OCC 3
+#define SCAN_OCC (SCAN_RING ? 4 : 3)
 #endif
 template <bool FAST>
 __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
@@ -599,9 +726,17 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int q = strip * (OUT_LANES - 2) + lane - 2;
   const int y0 = seg * L.seg_rows;
+#if SCAN_RING
+  __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
+  scan_strip_ring<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
+                        min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, counters + (size_t)frame * CNT_STRIDE,
+                        cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true,
+                        &s_win[wave][lane]);
+#else
   scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
                    min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, counters + (size_t)frame * CNT_STRIDE,
                    cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
+#endif
 }
 
 // ------------------------------------------------------------------- refine
@@ -1025,9 +1160,15 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
     long long want = (target + (long long)P.nframes * S.nstrips - 1) / ((long long)P.nframes * S.nstrips);
     if (want < 1) want = 1;
     int seg = (int)((L.h + want - 1) / want);
+#if SCAN_RING
+    seg = (seg + RING_ROWS - 1) / RING_ROWS * RING_ROWS;     // whole turns of the nine-row ring
+    if (seg < 2 * RING_ROWS) seg = 2 * RING_ROWS;
+    if (seg > 14 * RING_ROWS) seg = 14 * RING_ROWS;
+#else
     seg = (seg + 7) / 8 * 8;
     if (seg < 16) seg = 16;
     if (seg > 128) seg = 128;
+#endif
     S.seg_rows = seg;
     S.nsegs = (L.h + seg - 1) / seg;
     S.item_begin = items;

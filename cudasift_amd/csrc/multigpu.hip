@@ -134,7 +134,7 @@ static int comm_finish_create(misift_ctx *ctx, ncclComm_t nc, bool owns, misift_
   c->ctx = ctx; c->nccl = nc; c->owns_nccl = owns;
   c->rank = 0; c->nranks = 1; c->stream = nullptr;
   c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0;
-  c->slots.resize(4);
+  c->slots.resize(MISIFT_GATHER_SLOTS);
   for (GatherSlot &s : c->slots) { memset(&s, 0, sizeof(s)); }
   *out = c;                                           // from here on misift_comm_destroy cleans up after a failure
   NCCL_TRY(g_rccl.CommCount(nc, &c->nranks));
@@ -211,7 +211,7 @@ extern "C" int misift_comm_barrier(misift_comm *c)
 extern "C" int misift_gather_post(misift_ctx *ctx, misift_comm *c, int slot, const int *d_counts, int nframes,
                                   const void *d_packed)
 {
-  MG_CHECK(ctx && c && c->ctx == ctx && d_counts && d_packed && nframes >= 1);
+  MG_CHECK(ctx && c && c->ctx->device == ctx->device && d_counts && d_packed && nframes >= 1);
   MG_CHECK(slot >= 0 && slot < (int)c->slots.size());
   GatherSlot &s = c->slots[slot];
   s.d_counts = d_counts; s.d_packed = d_packed; s.nframes = nframes;

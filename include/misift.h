@@ -299,8 +299,10 @@ int misift_comm_barrier(misift_comm *comm);        /* all ranks have arrived (ho
 
 /* BASELINE config 4 — gather of SiftData on `root`, pipelined under the next batches' extraction.
  *   misift_gather_post      right after misift_extract_batch_packed_async: remembers that batch's device buffers
- *                           (d_counts[nframes], d_packed) in `slot` (0..3) and marks the point on the context stream
- *                           where they are complete.  Returns at once.
+ *                           (d_counts[nframes], d_packed) in `slot` (0..MISIFT_GATHER_SLOTS-1) and marks the point on
+ *                           the stream of `ctx` where they are complete; `ctx` is the context that extracted the batch —
+ *                           the communicator's own or any other context of the same device (several contexts per GPU
+ *                           keep several batches in flight).  Returns at once.
  *   misift_gather_complete  on the communicator's own high-priority stream: all-gather of the per-frame counts
  *                           (nframes ints per rank, the same nframes on every rank), then ONE point-to-point message
  *                           per sender carrying exactly its valid 576-byte records (xGMI is a full mesh: 7 senders use
@@ -308,6 +310,7 @@ int misift_comm_barrier(misift_comm *comm);        /* all ranks have arrived (ho
  *                           frame's candidate list overflowed, no records); on the root the records of rank r land at
  *                           d_recv + h_rank_offsets[r] records (h_rank_offsets: nranks+1 entries, host, optional).
  *                           Blocks the host until the transfer is done: the slot's buffers may be reused. */
+#define MISIFT_GATHER_SLOTS 8
 int misift_gather_post(misift_ctx *ctx, misift_comm *comm, int slot, const int *d_counts, int nframes,
                        const void *d_packed);
 int misift_gather_complete(misift_comm *comm, int slot, int root, int *h_all_counts, void *d_recv,

@@ -130,27 +130,36 @@ int main()
   hipEvent_t t0, t1;
   CHECK(hipEventCreate(&t0));
   CHECK(hipEventCreate(&t1));
-  printf("device: %s, %d CUs, clock %d MHz (attribute); cycles are per wave64 instruction per SIMD at the attribute clock\n",
-         prop.gcnArchName, cus, clk_khz / 1000);
-  printf("shader cycles (s_memtime) per wave64 instruction per SIMD, W waves per SIMD on every SIMD of the chip; MHz = s_memtime / s_memrealtime (100 MHz)\n");
-  printf("%-22s %10s %10s %10s %8s\n", "instruction", "1 wave", "2 waves", "4 waves", "MHz(4w)");
+  printf("device: %s, %d CUs, clock %d MHz (attribute)\n", prop.gcnArchName, cus, clk_khz / 1000);
+  printf("shader cycles per wave64 instruction per SIMD with W wavefronts per SIMD on every SIMD of the chip (one workgroup of 256*W\n"
+         "threads per CU).  Cycles = whole-kernel time (HIP events) x shader clock / (instructions per wavefront x W); the shader clock\n"
+         "is s_memtime / s_memrealtime (100 MHz) of the same launch.  [wave0] = the same quantity from the s_memtime interval of\n"
+         "wavefront 0 alone / W: the issue arbiter favours the oldest wavefront, so wavefront 0 runs at its single-wavefront speed\n"
+         "whatever W is and finishes early -- that column is NOT a throughput (it is what r02's first table mistook for one).\n");
+  printf("%-22s %8s %8s %8s %8s %8s   %8s %8s\n", "instruction", "W=1", "W=2", "W=3", "W=4", "MHz(4)", "[wave0]1", "[wave0]4");
   for (auto &k : e) {
     printf("%-22s", k.name);
-    for (int w = 1; w <= 4; w *= 2) {
+    double w0[5] = {0, 0, 0, 0, 0}, mhz4 = 0;
+    for (int w = 1; w <= 4; w++) {
       const int threads = 64 * 4 * w;            // w waves per SIMD, one workgroup per CU
       hipLaunchKernelGGL(k.fn, dim3(cus), dim3(threads), 0, 0, out, 64);
       CHECK(hipDeviceSynchronize());
+      const int iters = ITER * 4;
       CHECK(hipEventRecord(t0));
-      hipLaunchKernelGGL(k.fn, dim3(cus), dim3(threads), 0, 0, out, ITER);
+      hipLaunchKernelGGL(k.fn, dim3(cus), dim3(threads), 0, 0, out, iters);
       CHECK(hipEventRecord(t1));
       CHECK(hipEventSynchronize(t1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, t0, t1));
       unsigned long long tc[2];
       CHECK(hipMemcpy(tc, (char *)out + 32, sizeof(tc), hipMemcpyDeviceToHost));
-      const double instr_per_simd = (double)ITER * k.per_iter * w;
-      printf(" %10.2f", (double)tc[0] / instr_per_simd);
-      if (w == 4) printf(" %8.0f", 100.0 * (double)tc[0] / (double)tc[1]);
+      const double mhz = 100.0 * (double)tc[0] / (double)tc[1];
+      const double instr_per_simd = (double)iters * k.per_iter * w;
+      printf(" %8.2f", ms * 1e-3 * mhz * 1e6 / instr_per_simd);
+      w0[w] = (double)tc[0] / instr_per_simd;
+      if (w == 4) mhz4 = mhz;
     }
-    printf("\n");
+    printf(" %8.0f   %8.2f %8.2f\n", mhz4, w0[1], w0[4]);
   }
   return 0;
 }
