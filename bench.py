@@ -815,7 +815,8 @@ def main():
                                "per-kernel times add up to more than the step.  With --contexts > 1 kernels of several batches "
                                "share the GPU, every duration is stretched by its neighbours (they add up to ~contexts x the "
                                "step) and alone_ms_per_step gives the same kernels with one batch at a time on one context"}
-        print(json.dumps(out))
+        C.CDLL(None).fflush(None)          # RCCL's version banner sits in the C stdio buffer: get it out first,
+        print(json.dumps(out), flush=True)  # the JSON line is the LAST line of stdout
     if comm is not None:
         comm.close()
     if world > 1:

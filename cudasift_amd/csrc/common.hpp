@@ -190,11 +190,24 @@ template <bool INTERIOR = false>
 __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch, float x, float y, bool frac8)
 {
   float xb = x - 0.5f, yb = y - 0.5f;
-  float fx = floorf(xb), fy = floorf(yb);
-  float a = xb - fx, b = yb - fy;
-  if (frac8) {          // a * 256 is exact, so the fused form rounds exactly like the oracle's mul + add
-    a = floorf(__builtin_fmaf(a, 256.0f, 0.5f)) * (1.0f / 256.0f);
-    b = floorf(__builtin_fmaf(b, 256.0f, 0.5f)) * (1.0f / 256.0f);
+  float fx = 0.0f, fy = 0.0f, a, b;
+  int ix = 0, iy = 0;
+  if (INTERIOR) {
+    // coordinates >= 1: v_fract_f32 is xb - floor(xb) exactly, and the floor feeds only the integer conversion
+    // (v_cvt_flr_i32_f32): two instructions per coordinate instead of floor + subtract + convert
+    a = __builtin_amdgcn_fractf(xb); b = __builtin_amdgcn_fractf(yb);
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(xb));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(yb));
+  } else {
+    fx = floorf(xb); fy = floorf(yb);
+    a = xb - fx; b = yb - fy;
+  }
+  if (frac8) {
+    // 256 x the oracle's weights rintf(a * 256) / 256: adding and subtracting 1.5 * 2^23 rounds to the nearest integer,
+    // ties to even, in two full-rate instructions (floor-based rounding: three, one of them quarter rate).  The blend
+    // below runs on the 256 x weights and is scaled by 2^-16 at the end: powers of two, so every rounding is the same.
+    a = __builtin_fmaf(a, 256.0f, 12582912.0f) - 12582912.0f;
+    b = __builtin_fmaf(b, 256.0f, 12582912.0f) - 12582912.0f;
   }
   float t00, t10, t01, t11;
   // Addresses are 32-bit BYTE offsets from the level's base pointer (wave-uniform: an SGPR pair), so each texel-pair
@@ -203,7 +216,6 @@ __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch
   // kernels are VALU-issue-bound, and this was a third of their sampling loop).  A pyramid level is < 2^31 bytes.
   const char *base = reinterpret_cast<const char *>(img);
   if (INTERIOR) {
-    const int ix = (int)fx, iy = (int)fy;
     const unsigned off = (__umul24((unsigned)iy, (unsigned)pitch) + (unsigned)ix) * 4u;      // v_mad_u32_u24: rows, pitch < 2^24
     const Pair2 r0 = *reinterpret_cast<const Pair2 *>(base + off);
     const Pair2 r1 = *reinterpret_cast<const Pair2 *>(base + (off + (unsigned)pitch * 4u));
@@ -211,7 +223,7 @@ __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch
   } else {
     fx = fminf(fmaxf(fx, -2.0f), (float)w);
     fy = fminf(fmaxf(fy, -2.0f), (float)h);
-    const int ix = (int)fx, iy = (int)fy;
+    ix = (int)fx; iy = (int)fy;
     const int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
     const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
     // The two texels of a row are adjacent except at the clamped image edges: fetch them with ONE 8-byte load at
@@ -223,11 +235,13 @@ __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch
     t00 = lo0 ? r0.a : r0.b; t10 = hi1 ? r0.b : r0.a;
     t01 = lo0 ? r1.a : r1.b; t11 = hi1 ? r1.b : r1.a;
   }
-  const float ia = 1.0f - a, ib = 1.0f - b;
+  const float one = frac8 ? 256.0f : 1.0f;
+  const float ia = one - a, ib = one - b;
   float v = (ia * ib) * t00;
   v = __builtin_fmaf(a * ib, t10, v);
   v = __builtin_fmaf(ia * b, t01, v);
   v = __builtin_fmaf(a * b, t11, v);
+  if (frac8) v *= 1.0f / 65536.0f;
   return v;
 }
 

@@ -482,10 +482,11 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
 #endif
   d[3] = make_float4(b2.x.x - b1.x.y, b2.y.x - b1.y.y, b2.z.x - b1.z.y, b2.w.x - b1.w.y);
   d[4] = make_float4(b2.x.y - b2.x.x, b2.y.y - b2.y.x, b2.z.y - b2.z.x, b2.w.y - b2.w.x);
-  float amax = 0.0f;
+  // |v| maximum of every plane (two instructions each), then of the row
+  float am[NUM_SCALES];
 #pragma unroll
-  for (int p = 0; p < NUM_SCALES; p++)
-    amax = max3f(max3f(amax, fabsf(d[p].x), fabsf(d[p].y)), fabsf(d[p].z), fabsf(d[p].w));   // two v_max3_f32 per plane
+  for (int p = 0; p < NUM_SCALES; p++) am[p] = fmaxf(max3f(fabsf(d[p].x), fabsf(d[p].y), fabsf(d[p].z)), fabsf(d[p].w));
+  const float amax = max3f(max3f(am[0], am[1], am[2]), am[3], am[4]);
   // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
   // (tester lanes only: the halo lanes' blurs see zeros beyond the wavefront and would trip the test in every row —
   //  with them masked, 99 % of the finest level's rows of a typical frame skip the extremum tests)
@@ -498,6 +499,9 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
     unsigned mask = 0;
 #pragma unroll
     for (int s = 0; s < NUM_SCALES; s++) {
+      // a row that trips the threshold usually does so in one or two planes only: the others are skipped wave-uniformly
+      // (every VALU instruction costs the SIMD 3-5 cycles whatever it does; the tests were 15 % of the kernel's time)
+      if (!__any(tester && am[s] > thresh)) continue;
       // in-row neighbourhood of centre plane d[s]: columns x-1, x, x+1 of d[s-1], d[s], d[s+1] (where available)
       float lo[4], hi[4];
 #pragma unroll
@@ -523,7 +527,6 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
         const bool pre = (cv > thresh && cv > nmax) || (cv < -thresh && cv < nmin);
         mask |= (pre ? 1u : 0u) << (5 * i + s);
       }
-      __builtin_amdgcn_sched_barrier(0);         // one scale at a time: the rare path must not set the register budget
     }
     // columns 0 and width-1 can never hold an extremum either
     if (!tester) mask = 0;

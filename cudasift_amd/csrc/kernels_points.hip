@@ -154,24 +154,39 @@ __device__ __forceinline__ void patch_store(float *tile, int lane, const float (
 
 // tex2d() on a staged tile of row stride TW whose element [0][0] is texel (x0, y0): same operation sequence, the
 // clamp-to-edge addressing is already in the tile's contents.
+#ifndef TILE_FRACT
+#define TILE_FRACT 1
+#endif
 template <int TW>
 __device__ __forceinline__ float tex2d_tile(const float *tile, int x0, int y0, float x, float y, bool frac8)
 {
   const float xb = x - 0.5f, yb = y - 0.5f;
+#if TILE_FRACT
+  // v_fract_f32 = xb - floor(xb) exactly (it differs from the subtraction only for xb in (-3e-8, 0), where the
+  // subtraction rounds up to 1.0: a coordinate no sample of a window inside the image can have), and the floor then
+  // feeds nothing but the integer conversion (v_cvt_flr_i32_f32): two instructions per coordinate instead of three
+  float a = __builtin_amdgcn_fractf(xb), b = __builtin_amdgcn_fractf(yb);
+  int ifx, ify;                                   // (int)floorf(.) in one instruction; the compiler does not form it
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ifx) : "v"(xb));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ify) : "v"(yb));
+#else
   const float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
-  if (frac8) {
-    a = floorf(__builtin_fmaf(a, 256.0f, 0.5f)) * (1.0f / 256.0f);
-    b = floorf(__builtin_fmaf(b, 256.0f, 0.5f)) * (1.0f / 256.0f);
+  const int ifx = (int)fx, ify = (int)fy;
+#endif
+  if (frac8) {                                    // 256 x the weights, ties to even: see tex2d() in common.hpp
+    a = __builtin_fmaf(a, 256.0f, 12582912.0f) - 12582912.0f;
+    b = __builtin_fmaf(b, 256.0f, 12582912.0f) - 12582912.0f;
   }
-  const float *p = tile + (__mul24((int)fy - y0, TW) + ((int)fx - x0));
+  const float *p = tile + (__mul24(ify - y0, TW) + (ifx - x0));
   const float t00 = p[0], t10 = p[1], t01 = p[TW], t11 = p[TW + 1];
-  const float ia = 1.0f - a, ib = 1.0f - b;
+  const float one = frac8 ? 256.0f : 1.0f;
+  const float ia = one - a, ib = one - b;
   float v = (ia * ib) * t00;
   v = __builtin_fmaf(a * ib, t10, v);
   v = __builtin_fmaf(ia * b, t01, v);
   v = __builtin_fmaf(a * b, t11, v);
-  return v;
+  return frac8 ? v * (1.0f / 65536.0f) : v;
 }
 
 // ---------------------------------------------------- written-out elementary functions

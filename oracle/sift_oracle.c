@@ -446,8 +446,10 @@ static inline float tex2d(const float *img, int w, int h, int pitch, float x, fl
   float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
   if (fracbits == 8) {
-    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
-    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+    /* 8 fractional bits, round to nearest, ties to even (CUDA documents the 1.8 fixed-point format of the filter
+     * weights, not how the fraction is rounded into it; nearest-even is one add and one subtract on the GPU) */
+    a = rintf(a * 256.0f) * (1.0f / 256.0f);
+    b = rintf(b * 256.0f) * (1.0f / 256.0f);
   }
   /* clamp in float first so far-away coordinates cannot overflow the int cast */
   fx = fminf(fmaxf(fx, -2.0f), (float)w);
