@@ -914,6 +914,7 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
 // Phase 1 of the descriptor from the staged tile: this lane's 4 of the 256 rotated samples -> the two votes of each
 // (iangf*grad into angle bin angi, angf*grad into bin angi+1) and angi itself.  ONE sample per trip of a rolled loop:
 // four bilinear fetches (8 ds_read2_b32) in flight are what fits beside the prefetched window at 4 waves/SIMD.
+template <bool UNROLL>
 __device__ __forceinline__ void descr_samples_tile(const float *tile, int x0, int y0, bool q8, float px, float py,
                                                    float sina, float cosa, float ssina, float scosa,
                                                    const float *gauss, int lane, float (&vx)[4], float (&vy)[4],
@@ -923,6 +924,25 @@ __device__ __forceinline__ void descr_samples_tile(const float *tile, int x0, in
   const float fx = tx - 7.5f, gx = gauss[tx];
 #pragma unroll
   for (int j = 0; j < 4; j++) { vx[j] = 0.0f; vy[j] = 0.0f; ang[j] = 0; }     // defined before the selects below read them
+  if (UNROLL) {                                    // registers to spare (3 wavefronts per SIMD): no selects, no loop
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int y = (lane >> 4) + 4 * j;
+      const float fy = y - 7.5f;
+      const float xpos = px + fx * scosa - fy * ssina + 0.5f;
+      const float ypos = py + fx * ssina + fy * scosa + 0.5f;
+      const float dx = tex2d_tile<PW>(tile, x0, y0, xpos + cosa, ypos + sina, q8) -
+                       tex2d_tile<PW>(tile, x0, y0, xpos - cosa, ypos - sina, q8);
+      const float dy = tex2d_tile<PW>(tile, x0, y0, xpos - sina, ypos + cosa, q8) -
+                       tex2d_tile<PW>(tile, x0, y0, xpos + sina, ypos - cosa, q8);
+      const float grad = gauss[y] * gx * sqrtf(dx * dx + dy * dy);
+      float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+      const int angi = (int)angf;
+      angf -= angi;
+      vx[j] = (1.0f - angf) * grad; vy[j] = angf * grad; ang[j] = angi;
+    }
+    return;
+  }
 #pragma unroll 1
   for (int j = 0; j < 4; j++) {
     const int y = (lane >> 4) + 4 * j;
@@ -1073,8 +1093,9 @@ __device__ __forceinline__ void descr_write(SiftPointD *sift, SiftPointD *pack_d
 
 // descr_all_kernel — the default descriptor kernel.  One wavefront per keypoint; ONE 6.4 KB LDS buffer per wavefront
 // that is first the keypoint's 40x40 image window and then, once all samples are taken, the 4-plane vote table
-// (1600 floats either way) — so LDS never limits the occupancy and the kernel runs at the 4 waves/SIMD the VALU issue
-// rate needs (tools/valu_rates: a wavefront issues one VALU instruction per 8 cycles, a SIMD one per 2).
+// (1600 floats either way) — so LDS never limits the occupancy.  The kernel is bound by VALU instruction issue
+// (tools/valu_rates: 2.85 cycles per plain fp32 op, 4.4-4.7 for everything else, per SIMD from 2-3 wavefronts on); the
+// fourth wavefront per SIMD only covers the LDS round trips between the phases.
 //   per keypoint:  window (registers, prefetched) -> LDS | samples of the 1st and, if there is one, the 2nd orientation
 //                  (votes stay in registers) | clear | votes -> table -> footprints -> normalise -> record, once per
 //                  orientation.
@@ -1084,6 +1105,9 @@ __device__ __forceinline__ void descr_write(SiftPointD *sift, SiftPointD *pack_d
 #define DESCR_OCC 4
 #endif
 #define CNT_BIG 48            // counter slot: keypoints deferred to descr_big_kernel
+#ifndef DESCR_UNROLL_SAMPLES
+#define DESCR_UNROLL_SAMPLES 1
+#endif
 template <bool Q8, int OCC>
 __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                         unsigned *__restrict__ counters,
@@ -1223,7 +1247,7 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
         const float theta = 2.0f * 3.1415f / 360.0f * ((k == 0 && doA) ? d.ori1 : d.ori2);
         float sina, cosa;
         det_sincos(theta, sina, cosa);
-        descr_samples_tile(buf, g.x0, g.y0, q8, d.xpos, d.ypos, sina, cosa, scale * sina, scale * cosa, gauss, lane, vx, vy, ang);
+        descr_samples_tile<DESCR_UNROLL_SAMPLES>(buf, g.x0, g.y0, q8, d.xpos, d.ypos, sina, cosa, scale * sina, scale * cosa, gauss, lane, vx, vy, ang);
       }
       wave_sync();                                        // every lane is done with the window
       {                                                   // the same 1600 floats become the (all-zero) vote table:

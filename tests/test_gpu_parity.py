@@ -716,6 +716,46 @@ def test_timed_path_16x1080p_packed_async_vs_oracle(ctx):
         assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(recs2[offs[f]:offs[f + 1]]), f
 
 
+def test_three_contexts_in_flight_equal_one_context(ctx):
+    """`bench.py --contexts K` / INTEGRATION.md section 5: one context per batch in flight.  Three contexts (own stream,
+    staging and scratch arena each) get six batches queued round-robin with nothing synchronising in between — their
+    kernels share the GPU — and every batch must come out exactly as from one context working alone."""
+    from cudasift_amd import capi
+    B, mp, K, NBATCH = 4, 8192, 3, 6
+    frames = np.stack([synth_frame(7100 + f) for f in range(2 * B)])
+    d = [ctx.upload(frames[:B]), ctx.upload(frames[B:])]
+    S = 4 * capi.scratch_floats(1920, 1080, 5, False) * B
+    ref = []
+    scratch0 = capi.DevBuf(S)
+    for k in range(2):
+        ref.append(_packed_async_1080p(ctx, d[k], B, scratch0, ctx.zeros(4 * (2 * B + 1)), ctx.zeros(576 * mp * B), mp))
+    cs = [capi.Context(0) for _ in range(K)]
+    try:
+        scr = [capi.DevBuf(S) for _ in range(K)]
+        cnts = [ctx.zeros(4 * (2 * B + 1)) for _ in range(NBATCH)]
+        packs = [ctx.upload(np.full(576 * mp * B, 0xA5, np.uint8)) for _ in range(NBATCH)]
+        ctx.sync()
+        for k in range(NBATCH):                       # queue everything, then wait once
+            c = cs[k % K]
+            capi.check(capi.lib().misift_extract_batch_packed_async(
+                c.h, d[k % 2].ptr, B, 1080 * 1920, 1920, 1080, 1920, 5, 1.0, 3.0, 0.0, scr[k % K].ptr, None, mp,
+                cnts[k].ptr, cnts[k].ptr + 4 * B, packs[k].ptr), "misift_extract_batch_packed_async")
+        for c in cs:
+            c.sync()
+        for k in range(NBATCH):
+            ci = ctx.download(cnts[k], (2 * B + 1,), np.int32)
+            counts, offs = ci[:B], ci[B:]
+            rcounts, roffs, rrecs, _ = ref[k % 2]
+            assert np.array_equal(counts, rcounts) and np.array_equal(offs, roffs), (k, counts, rcounts)
+            recs = ctx.download(packs[k], (int(offs[B]),), capi.POINT_DTYPE)
+            for f in range(B):
+                assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(rrecs[roffs[f]:roffs[f + 1]]), (k, f)
+        record("contexts_in_flight", contexts=K, batches=NBATCH, keypoints=int(sum(int(r[0].sum()) for r in ref)))
+    finally:
+        for c in cs:
+            c.close()
+
+
 def test_extract_batch_scaleup_and_u8(ctx, stereo):
     """misift_extract_batch_ex: the scaleUp path over a BATCH (the reference applies it per call, cudaSiftH.cu:118-132),
     fp32 and 8-bit frames — every frame against the oracle's scaleUp extraction."""

@@ -1,3 +1,2 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python tools/ab.py "X=1" "X=2"
+python tools/cliff.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02_cliff_before.txt
