@@ -121,8 +121,6 @@ def pmc_child():
             ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), None,
             MAX_PTS, cnts.data_ptr(), cnts[B:].data_ptr(), packed.data_ptr()), "misift_extract_batch_packed_async")
         torch.cuda.synchronize()
-    for c in ctxs[1:]:
-        c.close()
     ctx.close()
 
 
@@ -821,8 +819,6 @@ def main():
         comm.close()
     if world > 1:
         dist.destroy_process_group()
-    for c in ctxs[1:]:
-        c.close()
     for c in ctxs[1:]:
         c.close()
     ctx.close()
