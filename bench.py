@@ -112,15 +112,20 @@ def pmc_child():
     B = int(os.environ.get("BENCH_PMC_FRAMES", "64"))
     ctx = capi.Context(0, torch.cuda.current_stream().cuda_stream)
     ctx.set_options(quiet=1)
-    frames = gen_frames_torch(torch, B, 0, device)
+    nsteps = int(os.environ.get("BENCH_CHILD_STEPS", "4"))
+    pipelined = os.environ.get("BENCH_CHILD_PIPELINED", "0") == "1"      # trace pass: queued back to back like the timed loop
+    nb = 4 if pipelined else 1       # distinct batches to rotate over: the 256 MB Infinity Cache must not serve the input
+    frames = gen_frames_torch(torch, nb * B, 0, device)
     scratch = torch.empty((B * capi.scratch_floats(W, H, NUM_OCTAVES, False),), dtype=torch.float32, device=device)
     packed = torch.empty((B * MAX_PTS * 576,), dtype=torch.uint8, device=device)
     cnts = torch.zeros((2 * B + 1,), dtype=torch.int32, device=device)
-    for _ in range(4):
+    for it in range(nsteps):
         capi.check(capi.lib().misift_extract_batch_packed_async(
-            ctx.h, frames.data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), None,
+            ctx.h, frames[(it % nb) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), None,
             MAX_PTS, cnts.data_ptr(), cnts[B:].data_ptr(), packed.data_ptr()), "misift_extract_batch_packed_async")
-        torch.cuda.synchronize()
+        if not pipelined:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
     ctx.close()
 
 
@@ -176,6 +181,50 @@ def collect_pmc(frames_per_launch, gather_read_factor, timeout_s=240):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return res, None
+
+
+def collect_trace(frames_per_launch, steps=30, skip=5, timeout_s=240, extra_env=None):
+    """Kernel durations as rocprofv3 itself sees them: ONE `rocprofv3 --kernel-trace` pass (no counters) over a child run
+    of `steps` back-to-back calls of the timed entry point; the first `skip` launches of every kernel are warm-up.
+    Returns {kernel: {"ms_per_step": summed launch durations of a step, "launches_per_step": n}} or (None, reason).  (The library's own HIP-event
+    pairs bracket every launch with two markers on the stream and read 6-17 % longer than the dispatch itself.)"""
+    import collections
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="bench_trace_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_FRAMES=str(frames_per_launch), BENCH_CHILD_STEPS=str(steps),
+               BENCH_CHILD_PIPELINED="1")
+    env.update(extra_env or {})
+    env.pop("RANK", None)
+    try:
+        cmd = [exe, "--kernel-trace", "-d", tmp, "-o", "t", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child"]
+        p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            return None, "rocprofv3 --kernel-trace failed (rc %d): %s" % (p.returncode, p.stdout.decode(errors="replace")[-300:])
+        per = collections.defaultdict(list)
+        with open(files[0]) as f:
+            for r in csv.DictReader(f):
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+                if k in KERNEL_NAMES:
+                    per[KERNEL_NAMES[k]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        res = {}
+        for k, v in per.items():
+            v.sort()
+            lps = max(1, int(round(len(v) / float(steps))))
+            d = [(b - a) * 1e-6 for a, b in v[skip * lps:]]
+            if d:
+                res[k] = {"ms_per_step": sum(d) * lps / len(d), "launches_per_step": lps, "launches": len(d)}
+        return res, None
+    except Exception as e:                                   # noqa: BLE001 — the bench line must still come out
+        return None, "kernel trace failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 # ------------------------------------------------------------------------------------------------ matcher leg
@@ -469,35 +518,34 @@ def main():
     # ---------------- per-kernel durations (HIP events on the launch stream) for the roofline
     if pts is None:
         pts = torch.zeros((B * MAX_PTS * 576,), dtype=torch.uint8, device=device)
-    # (a) with more than one context: in the timed configuration (the same rotation, every context records its own kernels)
-    prof, psteps = None, 5 * NCTX
+    # (a) in the timed configuration: the same pipelined rotation (nothing synchronises between the steps, so the GPU stays
+    #     at the clocks of the timed loop), every context recording its own kernels
+    psteps = 10 * NCTX
+    for c in ctxs:
+        c.profile_reset()
+        c.profile_enable(True)
+    for k in range(psteps):
+        enqueue(last_k + 1 + k)
+    torch.cuda.synchronize()
+    prof = {}
+    for c in ctxs:
+        for name, p in c.profile_read().items():
+            e = prof.setdefault(name, {"total_ms": 0.0, "calls": 0})
+            e["total_ms"] += p["total_ms"]
+            e["calls"] += p["calls"]
+        c.profile_enable(False)
+    step_ev.clear()
+    # (b) with more than one context also every kernel alone on the GPU: one context, one batch at a time
+    prof_alone, asteps = {}, 5
     if NCTX > 1:
-        for c in ctxs:
-            c.profile_reset()
-            c.profile_enable(True)
-        for k in range(psteps):
-            enqueue(last_k + 1 + k)
-        torch.cuda.synchronize()
-        prof = {}
-        for c in ctxs:
-            for name, p in c.profile_read().items():
-                e = prof.setdefault(name, {"total_ms": 0.0, "calls": 0})
-                e["total_ms"] += p["total_ms"]
-                e["calls"] += p["calls"]
-            c.profile_enable(False)
-        step_ev.clear()
-    # (b) every kernel alone on the GPU: one context, one batch at a time
-    ctx.profile_reset()
-    ctx.profile_enable(True)
-    asteps = 5
-    for i in range(asteps):
-        capi.check(capi.lib().misift_extract_batch(ctx.h, frames[(i % NB) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
-                                                   INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
-                                                   MAX_PTS, counts), "misift_extract_batch")
-    prof_alone = ctx.profile_read()
-    ctx.profile_enable(False)
-    if prof is None:
-        prof, psteps = prof_alone, asteps
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for i in range(asteps):
+            capi.check(capi.lib().misift_extract_batch(ctx.h, frames[(i % NB) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
+                                                       INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
+                                                       MAX_PTS, counts), "misift_extract_batch")
+        prof_alone = ctx.profile_read()
+        ctx.profile_enable(False)
     alg = algorithmic_bytes_per_frame()
     N = octave_pixels(W, H, NUM_OCTAVES)
     if "lowpass_down" in prof:
@@ -541,6 +589,23 @@ def main():
     # ---------------- roofline of the dominant kernel: dog_scan is fp32-VALU-bound (its 60 B/px of algorithmic
     # traffic never reach HBM), so its roof is the vector peak and the fraction is <= 1 by construction
     dom = "dog_scan" if "dog_scan" in kernels else max((k for k in kernels if k in alg), key=lambda k: kernels[k]["ms_per_step"])
+    # Launch durations as rocprofv3 reports them (one --kernel-trace pass over a pipelined child run of the same entry
+    # point).  The HIP-event pairs above bracket every launch with two stream markers and read 6-17 % longer than the
+    # dispatch; the roofline uses the dispatch durations (what `rocprofv3 --stats` of this command shows), the event
+    # figure stays in the table as hip_event_ms_per_step.
+    trace, trace_note = None, "not collected (N > 1, --no-pmc or --contexts > 1): HIP-event durations"
+    if rank == 0 and world == 1 and NCTX == 1 and not args.no_pmc and not args.unfused:
+        torch.cuda.synchronize()
+        trace, trace_note = collect_trace(B)
+        if trace is not None:
+            trace_note = ("rocprofv3 --kernel-trace over a child run of 30 back-to-back steps of the timed entry point (first 5 "
+                          "dropped), collected live in this run")
+            for k, e in trace.items():
+                if k in kernels:
+                    kernels[k]["hip_event_ms_per_step"] = kernels[k]["ms_per_step"]
+                    kernels[k]["ms_per_step"] = round(e["ms_per_step"], 4)
+                    if k in alg:
+                        kernels[k]["alg_GBps"] = round(alg[k] * B / (e["ms_per_step"] * 1e-3) / 1e9, 1)
     dom_ms = kernels[dom]["ms_per_step"]
     dom_launches = max(1, kernels[dom]["launches_per_step"])
     if dom == "dog_scan":
@@ -574,15 +639,23 @@ def main():
                 os.environ["MISIFT_SPLIT_TAIL"] = saved
         c1.set_options(quiet=1)
         c1.profile_enable(True)
-        for i in range(4):
-            capi.check(capi.lib().misift_extract_batch(c1.h, frames[(i % NB) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES,
-                                                       INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), pts.data_ptr(),
-                                                       MAX_PTS, counts), "misift_extract_batch")
+        n1 = 8
+        for i in range(n1):                       # queued back to back like the timed loop (no host sync in between)
+            capi.check(capi.lib().misift_extract_batch_packed_async(
+                c1.h, frames[(i % NB) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0,
+                scratch.data_ptr(), None, REC_CAP, cnts[0].data_ptr(), cnts[0][B:].data_ptr(), packed[0].data_ptr()),
+                "misift_extract_batch_packed_async")
+        torch.cuda.synchronize()
         p1 = c1.profile_read()
         c1.close()
-        if "dog_scan" in p1 and p1["dog_scan"]["calls"] == 4:
-            ms1 = p1["dog_scan"]["total_ms"] / 4
+        if "dog_scan" in p1 and p1["dog_scan"]["calls"] == n1:
+            ms1 = p1["dog_scan"]["total_ms"] / n1
             a1 = flops_step / (ms1 * 1e-3) / 1e12
+            if trace is not None:                 # the same from dispatch durations (rocprofv3 --kernel-trace, MISIFT_SPLIT_TAIL=0 child)
+                t1, _ = collect_trace(B, extra_env={"MISIFT_SPLIT_TAIL": "0"})
+                if t1 and "dog_scan" in t1 and t1["dog_scan"]["launches_per_step"] == 1:
+                    ms1 = t1["dog_scan"]["ms_per_step"]
+                    a1 = flops_step / (ms1 * 1e-3) / 1e12
             roofline["single_launch"] = {"ms": round(ms1, 4), "achieved": round(a1, 2),
                                          "frac": round(min(a1 / VALU_F32_PEAK_TF, 1.0), 4),
                                          "note": "all pyramid levels in one launch on one stream (no overlap with the coarse ScaleDowns)"}
@@ -602,6 +675,7 @@ def main():
                 "stream before halo lanes, segment prologues and the extremum tests; the kernel runs at ~0.88 of its own "
                 "instruction-issue bound (SQ_INSTS_VALU x cost / SIMD cycles)"}
     roofline["avg_launch_ms"] = round(dom_ms / dom_launches, 4)
+    roofline["duration_source"] = trace_note
     roofline["launches_per_step"] = dom_launches
     roofline["traffic"] = int((pmc[dom]["read"] + pmc[dom]["write"]) / dom_launches) if pmc and dom in pmc else None
     roofline["traffic_note"] = pmc_note
@@ -807,8 +881,8 @@ def main():
                if validated else "skipped (--no-cpu)",
                "roofline": roofline, "kernels": kernels, "step_ms": step_ms, "match": match, "cpu_baseline": cpu,
                "pcie_inclusive": pcie, "single_frame": latency,
-               "kernels_note": "ms_per_step = HIP-event durations on the launch stream(s) over 5 profiled steps in the timed "
-                               "configuration; dog_scan runs as two launches per step (fine levels on the context stream, the "
+               "kernels_note": "ms_per_step = HIP-event durations on the launch stream(s) over 10 more steps of the same "
+                               "pipelined loop (per context) with the library's per-kernel events switched on; dog_scan runs as two launches per step (fine levels on the context stream, the "
                                "coarse ScaleDowns + coarse levels beside it on a second stream) whose durations overlap, so the "
                                "per-kernel times add up to more than the step.  With --contexts > 1 kernels of several batches "
                                "share the GPU, every duration is stretched by its neighbours (they add up to ~contexts x the "
