@@ -598,8 +598,9 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
 #define RING_FLOAT4S (RING_ROWS * 64)            // per wavefront: 9 rows x 64 lanes x 16 B = 9 KiB
 // The same scan with the 9-row window in LDS instead of 36 VGPRs: every lane parks its quad of each incoming row in a
 // ring of nine slots (its own 16 bytes of each slot: no other lane ever reads them, so no barriers) and re-reads the
-// nine quads at the start of a row.  That is what brings the kernel from 168 to <= 128 registers = from 3 to 4
-// wavefronts per SIMD, and the issue rate of a SIMD is min(waves, 4) / 8 instructions per cycle.  The row
+// nine quads at the start of a row.  168 -> <= 128 registers (3 -> 4 wavefronts per SIMD) — which, measured, buys
+// nothing by itself: the kernel is bound by VALU instruction issue and a SIMD is saturated from 2-3 wavefronts on
+// (DESIGN.md section 4).  What it does save is the register rotation of the window (-3.4 % instructions).  The row
 // loop is unrolled nine times so that every slot is an immediate offset of the ds_read_b128 / ds_write_b128.
 template <bool FAST, typename TAPS>
 __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int height, int pitch, int q, int lane,

@@ -43,3 +43,38 @@ def test_dog_scan_flop_model():
     N = b.octave_pixels(1920, 1080, 5)
     assert abs(146 * sum(N) * 64 - 25.8e9) < 0.05e9                         # 25.8 GFLOP per 64-frame step
     assert b.FLOOR_BYTES_PER_FRAME < 54.2e6 < b.ALG_BYTES_PER_FRAME          # floor < measured r01 traffic < algorithmic
+
+
+def test_kernel_trace_parsing(tmp_path, monkeypatch):
+    """collect_trace(): per-kernel dispatch durations from a rocprofv3 kernel-trace CSV — warm-up launches dropped,
+    two launches per step summed, unknown kernels ignored.  (rocprofv3 itself is faked: no GPU here.)"""
+    import bench
+    steps, skip = 6, 2
+    rows = ["Kind,Agent_Id,Queue_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,End_Timestamp"]
+    t = 1000
+    for s in range(steps):
+        dur = 900000 if s < skip else 300000                 # warm-up launches are slow
+        for name in ("void dog_scan_all_kernel<true>(float const*, ScanAllGeom)", "void dog_scan_all_kernel<true>(float const*, ScanAllGeom)",
+                     "void descr_all_kernel<true, 4>(float const*)", "void at::native::elementwise_kernel<128>(int)"):
+            rows.append('"KERNEL_DISPATCH",1,1,1,"%s",1,%d,%d' % (name, t, t + dur))
+            t += dur + 50
+
+    class P:
+        returncode = 0
+        stdout = b""
+
+    def fake_run(cmd, **kw):
+        d = cmd[cmd.index("-d") + 1]
+        import os
+        os.makedirs(os.path.join(d, "host"), exist_ok=True)
+        open(os.path.join(d, "host", "t_kernel_trace.csv"), "w").write("\n".join(rows) + "\n")
+        assert kw["env"]["BENCH_CHILD_PIPELINED"] == "1" and kw["env"]["BENCH_CHILD_STEPS"] == str(steps)
+        return P()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: True)
+    res, note = bench.collect_trace(64, steps=steps, skip=skip)
+    assert note is None
+    assert res["dog_scan"]["launches_per_step"] == 2 and abs(res["dog_scan"]["ms_per_step"] - 0.6) < 1e-9
+    assert res["descr_all"]["launches_per_step"] == 1 and abs(res["descr_all"]["ms_per_step"] - 0.3) < 1e-9
+    assert set(res) == {"dog_scan", "descr_all"}
