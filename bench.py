@@ -365,6 +365,12 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC traffic passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    # HIP multiplexes a process's streams onto 4 hardware queues unless told otherwise, and a stream that shares a
+    # queue with the extraction stream runs BEHIND the batches queued there: the gather's communication stream then
+    # completes batch k-2 only after batch k, the host cannot run ahead and the pipeline loses its depth (1 rank through
+    # the communicator: 41 k instead of 51 k frames/s; the host-fed pipe wanders between 16 k and 24 k).  Must be set
+    # before the HIP runtime initialises, i.e. before torch is imported; a caller's own setting wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.pmc_child:
         return pmc_child()
 
@@ -462,12 +468,21 @@ def main():
             c = cnts[slot][:B].cpu().numpy()
         return c[None, :]
 
+    host_t = {"enqueue": 0.0, "complete": 0.0}
+    trace_host = os.environ.get("BENCH_TRACE") == "1"     # developer aid: where the host spends the pipelined loop
+
     def run(k0, nsteps):
         last = None
         for k in range(k0, k0 + nsteps):
+            ta = time.perf_counter()
             enqueue(k)
+            tb = time.perf_counter()
             if k - k0 >= LAG:
                 last = complete(k - LAG)
+            if trace_host:
+                host_t["enqueue"] += tb - ta
+                host_t["complete"] += time.perf_counter() - tb
+            if k - k0 >= LAG:
                 if (last < 0).any():
                     raise RuntimeError("candidate list overflow in the bench workload")
         for k in range(max(k0, k0 + nsteps - LAG), k0 + nsteps):
@@ -499,6 +514,10 @@ def main():
         dt = float(tmax.item())
     ms_per_step = 1e3 * dt / args.steps
     fps = world * B * args.steps / dt
+    if trace_host and rank == 0:
+        print("host time per step: enqueue %.3f ms, complete %.3f ms (incl. warm-up); step %.3f ms"
+              % (1e3 * host_t["enqueue"] / (args.steps + args.warmup), 1e3 * host_t["complete"] / (args.steps + args.warmup),
+                 ms_per_step), file=sys.stderr)
     # distribution of the pipelined loop's steps on the GPU timeline (median + p10/p90)
     step_ms = None
     if rank == 0 and len(step_ev) >= NCTX + 2:

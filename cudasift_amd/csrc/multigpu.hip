@@ -14,6 +14,7 @@
 // gather is ONE message per sender (7 senders -> 7 distinct links into the root), never a ring of padded blocks.
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include <rccl/rccl.h>      // types and prototypes only; every call goes through the table below
@@ -116,6 +117,8 @@ struct misift_comm {
   std::vector<GatherSlot> slots;
 };
 
+
+
 extern "C" int misift_comm_unique_id(void *id128)
 {
   MG_CHECK(id128 != nullptr);
@@ -196,9 +199,10 @@ extern "C" int misift_comm_barrier(misift_comm *c)
   MG_CHECK(c != nullptr);
   HIP_TRY(hipSetDevice(c->ctx->device));
   // an all-gather of one int per rank on the communication stream, then a host wait: every rank has arrived
-  if (c->cap_frames < 1) {
-    HIP_TRY(hipMalloc((void **)&c->d_all_counts, sizeof(int) * (size_t)c->nranks * 64));
-    HIP_TRY(hipHostMalloc((void **)&c->h_all_counts, sizeof(int) * (size_t)c->nranks * 64, hipHostMallocDefault));
+  if (c->cap_frames < 1) {                              // (a failed attempt leaves what it did allocate for the next one)
+    if (!c->d_all_counts) HIP_TRY(hipMalloc((void **)&c->d_all_counts, sizeof(int) * (size_t)c->nranks * 64));
+    if (!c->h_all_counts)
+      HIP_TRY(hipHostMalloc((void **)&c->h_all_counts, sizeof(int) * (size_t)c->nranks * 64, hipHostMallocDefault));
     HIP_TRY(hipMemsetAsync(c->d_all_counts, 0, sizeof(int) * (size_t)c->nranks * 64, c->stream));
     c->cap_frames = 64;
   }
@@ -241,7 +245,10 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
   }
   HIP_TRY(hipStreamWaitEvent(c->stream, s.ready, 0));
   // 1. per-frame counts of every rank (nframes ints per rank; every rank must post the same nframes)
-  NCCL_TRY(g_rccl.AllGather(s.d_counts, c->d_all_counts, (size_t)nf, ncclInt32, c->nccl, c->stream));
+  if (nr == 1)           // nothing to gather: a plain copy
+    HIP_TRY(hipMemcpyAsync(c->d_all_counts, s.d_counts, sizeof(int) * (size_t)nf, hipMemcpyDeviceToDevice, c->stream));
+  else
+    NCCL_TRY(g_rccl.AllGather(s.d_counts, c->d_all_counts, (size_t)nf, ncclInt32, c->nccl, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_all_counts, c->d_all_counts, sizeof(int) * (size_t)nr * nf, hipMemcpyDeviceToHost,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));          // the message sizes must be known on the host (NCCL API)
@@ -255,35 +262,31 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
     off[r + 1] = off[r] + nrec[r];
   }
   if (h_rank_offsets) memcpy(h_rank_offsets, off.data(), sizeof(size_t) * ((size_t)nr + 1));
-  int rc = MISIFT_OK;
-  if (c->rank == root) {
-    if (d_recv && off[nr] > capacity_records) {
-      // still take part in the exchange (the peers are already committed to their sends) but into nothing:
-      // report instead.  Peers cannot be told, so this is fatal for the caller's sizing, not for the job.
-      misift_set_error("misift_gather_complete: %zu records but room for %zu", off[nr], capacity_records);
-      rc = MISIFT_ENOMEM;
-    }
+  // Room on the root?  Every rank knows every count and passes the SAME capacity_records (the root's), so every rank
+  // takes the same decision and nobody waits for a message that is never posted.
+  if (off[nr] > capacity_records) {
+    misift_set_error("misift_gather_complete: %zu records but room for %zu on the root", off[nr], capacity_records);
+    s.posted = false;
+    return MISIFT_ENOMEM;
   }
   // 2. ONE point-to-point message per sender with exactly its valid bytes (xGMI: distinct links into the root)
-  if (rc == MISIFT_OK || c->rank != root) {
-    NCCL_TRY(g_rccl.GroupStart());
-    if (c->rank == root) {
-      for (int r = 0; r < nr; r++) {
-        if (r == root || nrec[r] == 0) continue;
-        NCCL_TRY(g_rccl.Recv((char *)d_recv + off[r] * sizeof(SiftPointD), nrec[r] * sizeof(SiftPointD), ncclUint8, r,
-                             c->nccl, c->stream));
-      }
-    } else if (nrec[c->rank]) {
-      NCCL_TRY(g_rccl.Send(s.d_packed, nrec[c->rank] * sizeof(SiftPointD), ncclUint8, root, c->nccl, c->stream));
+  NCCL_TRY(g_rccl.GroupStart());
+  if (c->rank == root) {
+    for (int r = 0; r < nr; r++) {
+      if (r == root || nrec[r] == 0) continue;
+      NCCL_TRY(g_rccl.Recv((char *)d_recv + off[r] * sizeof(SiftPointD), nrec[r] * sizeof(SiftPointD), ncclUint8, r,
+                           c->nccl, c->stream));
     }
-    NCCL_TRY(g_rccl.GroupEnd());
-    if (c->rank == root && d_recv && nrec[root])
-      HIP_TRY(hipMemcpyAsync((char *)d_recv + off[root] * sizeof(SiftPointD), s.d_packed, nrec[root] * sizeof(SiftPointD),
-                             hipMemcpyDeviceToDevice, c->stream));
+  } else if (nrec[c->rank]) {
+    NCCL_TRY(g_rccl.Send(s.d_packed, nrec[c->rank] * sizeof(SiftPointD), ncclUint8, root, c->nccl, c->stream));
   }
+  NCCL_TRY(g_rccl.GroupEnd());
+  if (c->rank == root && d_recv && nrec[root])
+    HIP_TRY(hipMemcpyAsync((char *)d_recv + off[root] * sizeof(SiftPointD), s.d_packed, nrec[root] * sizeof(SiftPointD),
+                           hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));          // the slot's buffers are free again when this returns
   s.posted = false;
-  return rc;
+  return MISIFT_OK;
 }
 
 // ------------------------------------------------------------------ config 5: row-block matcher

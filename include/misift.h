@@ -309,6 +309,9 @@ int misift_comm_barrier(misift_comm *comm);        /* all ranks have arrived (ho
  *                           7 distinct links into the root).  h_all_counts[nranks*nframes] (host, every rank; -1 = that
  *                           frame's candidate list overflowed, no records); on the root the records of rank r land at
  *                           d_recv + h_rank_offsets[r] records (h_rank_offsets: nranks+1 entries, host, optional).
+ *                           capacity_records = room at d_recv on the root, in records; pass the SAME value on every
+ *                           rank: all ranks see all counts, so all of them return MISIFT_ENOMEM without exchanging
+ *                           anything when the records do not fit (no rank is left waiting for a message).
  *                           Blocks the host until the transfer is done: the slot's buffers may be reused. */
 #define MISIFT_GATHER_SLOTS 8
 int misift_gather_post(misift_ctx *ctx, misift_comm *comm, int slot, const int *d_counts, int nframes,

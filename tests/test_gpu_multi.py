@@ -56,6 +56,15 @@ def _rank_body(capi, rank, world, uid, frames_of, mp, out, errs):
         counts, offs = comm.gather_complete(2 % nslot, B, 0, recv.ptr if recv else None, mp * B * world)
         results.append((2, counts, offs, c.download(recv, (int(offs[-1]),), capi.POINT_DTYPE) if rank == 0 else None))
         comm.barrier()
+        # ---- too little room on the root: every rank says so (same decision everywhere, nothing is exchanged, nobody hangs)
+        cnt, packed = _extract_packed(capi, c, frames_of(rank * 10), mp, keep)
+        comm.gather_post(0, cnt.ptr, B, packed.ptr)
+        try:
+            comm.gather_complete(0, B, 0, recv.ptr if recv else None, 7)
+            raise AssertionError("capacity overflow not reported")
+        except RuntimeError as e:
+            assert "room for 7" in str(e), e
+        comm.barrier()
         # ---- matcher: row blocks of set 1, shards of set 2
         n1, n2 = 512 * world, 384 * world
         p1 = descriptors_to_points(synth_descriptors(n1, 31), capi.POINT_DTYPE)
