@@ -847,6 +847,12 @@ def main():
         ref, nref, cref = orc.extract_batch(host, NUM_OCTAVES, INIT_BLUR, THRESH, max_pts=8192, outer_threads=outer,
                                             inner_threads=inner)
         cdt = time.perf_counter() - tc0
+        cpu_frames = ncpu
+        if world == 1 and cdt < 10.0:              # the contract asks for 10-30 s of CPU work: time the sample a second time
+            tc1 = time.perf_counter()
+            orc.extract_batch(host, NUM_OCTAVES, INIT_BLUR, THRESH, max_pts=8192, outer_threads=outer, inner_threads=inner)
+            cdt += time.perf_counter() - tc1
+            cpu_frames += ncpu
         nval = min(ncpu, B)
         for f in range(nval):
             got = last_recs[last_offs[f]:last_offs[f + 1]]
@@ -856,10 +862,11 @@ def main():
             compare_points(ref[f, :nref[f]], got, "bench_validate_f%d" % f)              # raises AssertionError on mismatch
         validated = nval
         if world == 1:
-            cpu = {"value": round(ncpu / cdt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            cpu = {"value": round(cpu_frames / cdt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
                    "threads": "%d frames in parallel x %d threads each" % (outer, inner),
-                   "sample": "%d of the same synthetic 1920x1080 frames (%.1f s), oracle/sift_oracle.c: one frame per OpenMP "
-                             "thread + OpenMP inside every stage (OpenCV cv::SIFT is not installed on this image)" % (ncpu, cdt),
+                   "sample": "%d extractions of %d of the same synthetic 1920x1080 frames (%.1f s), oracle/sift_oracle.c: one frame "
+                             "per OpenMP thread + OpenMP inside every stage (OpenCV cv::SIFT is not installed on this image)"
+                             % (cpu_frames, ncpu, cdt),
                    "keypoints_per_frame": round(float(np.mean(nref)), 1)}
             # matcher CPU baseline: the reference's OWN AVX2/OpenMP routine MatchC3 (match.cu:102-130, built from the
             # reference tree into oracle/_ref by oracle/build_ref.sh) on its own 16384 x 16384 problem

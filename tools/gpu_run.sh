@@ -1,7 +1,5 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_multi.py -x -q -m gpu > gpurun_out/pytest_multi.log 2>&1; grep -E "passed|failed|error|Error" gpurun_out/pytest_multi.log | tail -3
-for m in "--selftest-dist" "--selftest-dist --contexts 4"; do
-BENCH_TRACE=1 timeout 300 python bench.py --no-pmc --no-match --no-cpu --no-latency --steps 100 --warmup 10 $m 2> gpurun_out/t.err | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$m', d['value'], d['ms_per_step'], d['pcie_inclusive']['frames_per_s_u8'], d['pcie_inclusive']['frames_per_s_f32'])"
-grep "host time" gpurun_out/t.err
+for q in 8 16; do
+echo "GPU_MAX_HW_QUEUES=$q"
+GPU_MAX_HW_QUEUES=$q python tools/two_ctx.py 1 2 3 4 6 2>&1 | grep -v amdgpu.ids | cut -c1-60
 done
