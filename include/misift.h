@@ -62,8 +62,10 @@ typedef struct misift_options {
                             :1043: run-to-run the SET is equal, the order is
                             not); 1 = order fixed by the keypoints themselves
                             (tile, y, x, scale): repeated runs are byte-identical
-                            (fused path; also
-                            MISIFT_DETERMINISTIC=1)                           */
+                            (also MISIFT_DETERMINISTIC=1).
+                            Applies to the fused path; the dense kernels
+                            (fused = 0, or the automatic exact re-run after a
+                            candidate-list overflow) keep the append order     */
 } misift_options;
 
 /* ------------------------------------------------------------------ runtime */

@@ -679,9 +679,15 @@ def test_timed_path_16x1080p_packed_async_vs_oracle(ctx):
     scratch = capi.DevBuf(4 * capi.scratch_floats(1920, 1080, 5, False) * B)
     cnt = ctx.zeros(4 * (2 * B + 1))
     packed = ctx.upload(np.full(576 * mp * B, 0xA5, np.uint8))          # dirty: every byte of every record must be written
-    counts, offs, recs, counters = _packed_async_1080p(ctx, d, B, scratch, cnt, packed, mp)
+    was_fused = ctx.get_options().fused
+    ctx.set_options(fused=1)              # the timed path IS the merged-octave path (a MISIFT_FUSED=0 run of the suite included)
+    try:
+        counts, offs, recs, counters = _packed_async_1080p(ctx, d, B, scratch, cnt, packed, mp)
+    finally:
+        ctx.set_options(fused=was_fused)
     prof_ctx = capi.Context(0)
     try:                                                                  # the premise: this batch does take two scan launches
+        prof_ctx.set_options(fused=1)
         prof_ctx.profile_enable(True)
         _packed_async_1080p(prof_ctx, d, B, scratch, cnt, ctx.zeros(576 * mp * B), mp)
         assert prof_ctx.profile_read()["dog_scan"]["calls"] == 2
@@ -705,6 +711,7 @@ def test_timed_path_16x1080p_packed_async_vs_oracle(ctx):
         else:
             os.environ["MISIFT_SPLIT_TAIL"] = saved
     try:
+        c2.set_options(fused=1)
         packed2 = c2.upload(np.full(576 * mp * B, 0x5A, np.uint8))
         c2.profile_enable(True)
         counts2, offs2, recs2, counters2 = _packed_async_1080p(c2, d, B, scratch, cnt, packed2, mp)
@@ -727,10 +734,17 @@ def test_three_contexts_in_flight_equal_one_context(ctx):
     S = 4 * capi.scratch_floats(1920, 1080, 5, False) * B
     ref = []
     scratch0 = capi.DevBuf(S)
-    for k in range(2):
-        ref.append(_packed_async_1080p(ctx, d[k], B, scratch0, ctx.zeros(4 * (2 * B + 1)), ctx.zeros(576 * mp * B), mp))
+    was_fused = ctx.get_options().fused
+    ctx.set_options(fused=1)
+    try:
+        for k in range(2):
+            ref.append(_packed_async_1080p(ctx, d[k], B, scratch0, ctx.zeros(4 * (2 * B + 1)), ctx.zeros(576 * mp * B), mp))
+    finally:
+        ctx.set_options(fused=was_fused)
     cs = [capi.Context(0) for _ in range(K)]
     try:
+        for c in cs:
+            c.set_options(fused=1)
         scr = [capi.DevBuf(S) for _ in range(K)]
         cnts = [ctx.zeros(4 * (2 * B + 1)) for _ in range(NBATCH)]
         packs = [ctx.upload(np.full(576 * mp * B, 0xA5, np.uint8)) for _ in range(NBATCH)]
@@ -816,14 +830,15 @@ def test_deterministic_mode_is_byte_identical_across_runs(ctx):
     from cudasift_amd import capi
     imgs = np.stack([synth_frame(2100 + f, 960, 540) for f in range(3)])
     base_pts, base_n = ctx.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192)
-    ctx.set_options(deterministic=1)
+    was_fused = ctx.get_options().fused
+    ctx.set_options(deterministic=1, fused=1)        # the order is fixed where the merged-octave path bins its detections
     try:
         runs = [ctx.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192) for _ in range(3)]
     finally:
-        ctx.set_options(deterministic=0)
+        ctx.set_options(deterministic=0, fused=was_fused)
     c2 = capi.Context(0)
     try:
-        c2.set_options(deterministic=1)
+        c2.set_options(deterministic=1, fused=1)
         runs.append(c2.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192))
     finally:
         c2.close()
