@@ -355,6 +355,7 @@ int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride
                  int nframes, float subsampling, int octave, SiftPointD *pts, int max_pts);
 int launch_rescale(misift_ctx *ctx, SiftPointD *pts, int npts, float scale);
 int launch_rescale_batch(misift_ctx *ctx, SiftPointD *pts, int max_pts, int nframes, int num_octaves, float scale);
+int launch_sort_segments(misift_ctx *ctx, SiftPointD *pts, int max_pts, int nframes, int num_octaves);
 int launch_bin_detections(misift_ctx *ctx, const PyramidInfo &P, int max_pts);
 int launch_renumber_dups(misift_ctx *ctx, const PyramidInfo &P, int max_pts);
 int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts);

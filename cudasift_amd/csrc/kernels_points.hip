@@ -1474,6 +1474,63 @@ __global__ void rescale_batch_kernel(SiftPointD *pts, int max_pts, const unsigne
   }
 }
 
+// ---- deterministic record order on the DENSE path (options.deterministic with fused = 0, or the exact re-run after a
+// candidate-list overflow): every segment of the reference layout — detections of octave o, then its second
+// orientations — is sorted by (ypos, xpos, scale, orientation).  Rank by counting (a segment holds a few thousand
+// records at most and this path is rare), keys staged through LDS, records scattered into a scratch copy.
+__device__ __forceinline__ bool sort_key_less(const float4 a, const float4 b)
+{
+  if (a.x != b.x) return a.x < b.x;
+  if (a.y != b.y) return a.y < b.y;
+  if (a.z != b.z) return a.z < b.z;
+  return a.w < b.w;
+}
+__global__ __launch_bounds__(256) void sort_segments_kernel(const SiftPointD *__restrict__ pts, SiftPointD *__restrict__ tmp,
+                                                            const unsigned *__restrict__ counters, int max_pts)
+{
+  __shared__ float4 s_key[256];
+  const int frame = blockIdx.z, seg = blockIdx.y, o = seg / 2 + 1;
+  const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const int lo = (int)min(cnt[2 * o - 1 + (seg & 1)], (unsigned)max_pts), hi = (int)min(cnt[2 * o + (seg & 1)], (unsigned)max_pts);
+  const SiftPointD *P = pts + (size_t)frame * max_pts;
+  SiftPointD *T = tmp + (size_t)frame * max_pts;
+  for (int base = lo + blockIdx.x * 256; base < hi; base += gridDim.x * 256) {     // block-uniform trip count
+    const int i = base + threadIdx.x;
+    const bool live = i < hi;
+    float4 ki = make_float4(0, 0, 0, 0);
+    if (live) ki = make_float4(P[i].ypos, P[i].xpos, P[i].scale, P[i].orientation);
+    int rank = 0;
+    for (int t0 = lo; t0 < hi; t0 += 256) {
+      const int j = t0 + threadIdx.x;
+      __syncthreads();
+      if (j < hi) s_key[threadIdx.x] = make_float4(P[j].ypos, P[j].xpos, P[j].scale, P[j].orientation);
+      __syncthreads();
+      const int m = min(256, hi - t0);
+      for (int k = 0; k < m; k++) {
+        const float4 kj = s_key[k];
+        const bool eq = kj.x == ki.x && kj.y == ki.y && kj.z == ki.z && kj.w == ki.w;
+        rank += (sort_key_less(kj, ki) || (eq && t0 + k < i)) ? 1 : 0;
+      }
+    }
+    if (live) {
+      const float4 *src = reinterpret_cast<const float4 *>(&P[i]);
+      float4 *dst = reinterpret_cast<float4 *>(&T[lo + rank]);
+#pragma unroll 4
+      for (int q = 0; q < (int)(sizeof(SiftPointD) / 16); q++) dst[q] = src[q];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void sort_copy_back_kernel(SiftPointD *__restrict__ pts, const SiftPointD *__restrict__ tmp,
+                                                             const unsigned *__restrict__ counters, int max_pts, int last_slot)
+{
+  const int frame = blockIdx.y;
+  const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const size_t n = (size_t)min(cnt[last_slot], (unsigned)max_pts) * (sizeof(SiftPointD) / 16);
+  float4 *dst = reinterpret_cast<float4 *>(pts + (size_t)frame * max_pts);
+  const float4 *src = reinterpret_cast<const float4 *>(tmp + (size_t)frame * max_pts);
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) dst[q] = src[q];
+}
+
 // ------------------------------------------------------------- host wrappers
 static inline int points_grid_x(misift_ctx *ctx, int nframes, int blocks_per_cu = 0)
 {
@@ -1568,6 +1625,20 @@ int launch_rescale_batch(misift_ctx *ctx, SiftPointD *pts, int max_pts, int nfra
   const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
   hipLaunchKernelGGL(rescale_batch_kernel, dim3(16, nframes), dim3(256), 0, ctx->stream, pts, max_pts, ctx->d_counters,
                      slot, scale);
+  return ls.finish();
+}
+
+// options.deterministic on the dense path: see sort_segments_kernel
+int launch_sort_segments(misift_ctx *ctx, SiftPointD *pts, int max_pts, int nframes, int num_octaves)
+{
+  int rc = misift_ensure_tmp(ctx, sizeof(SiftPointD) * (size_t)nframes * max_pts);
+  if (rc) return rc;
+  LaunchScope ls(ctx, "sort_segments");
+  SiftPointD *tmp = reinterpret_cast<SiftPointD *>(ctx->d_match_tmp);
+  hipLaunchKernelGGL(sort_segments_kernel, dim3(8, 2 * num_octaves, nframes), dim3(256), 0, ctx->stream, pts, tmp,
+                     ctx->d_counters, max_pts);
+  hipLaunchKernelGGL(sort_copy_back_kernel, dim3(64, nframes), dim3(256), 0, ctx->stream, pts, tmp, ctx->d_counters, max_pts,
+                     2 * num_octaves + 1);
   return ls.finish();
 }
 

@@ -851,6 +851,10 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     rc = launch_descr(ctx, L.img, SS, L.w, L.h, L.p, nframes, subsampling, o, pts, max_pts);
     if (rc) return rc;
   }
+  if (ctx->opt.deterministic) {                     // dense path: order fixed after the fact, segment by segment
+    rc = launch_sort_segments(ctx, pts, max_pts, nframes, num_octaves);
+    if (rc) return rc;
+  }
   if (scale_up) return launch_rescale_batch(ctx, pts, max_pts, nframes, num_octaves, 0.5f);      // cudaSiftH.cu:130
   return MISIFT_OK;
 }

@@ -63,9 +63,10 @@ typedef struct misift_options {
                             not); 1 = order fixed by the keypoints themselves
                             (tile, y, x, scale): repeated runs are byte-identical
                             (also MISIFT_DETERMINISTIC=1).
-                            Applies to the fused path; the dense kernels
-                            (fused = 0, or the automatic exact re-run after a
-                            candidate-list overflow) keep the append order     */
+                            The fused path orders by (tile, y, x, scale); the
+                            dense kernels (fused = 0, or the automatic exact
+                            re-run after a candidate-list overflow) sort every
+                            segment by (y, x, scale, orientation) afterwards   */
 } misift_options;
 
 /* ------------------------------------------------------------------ runtime */

@@ -573,9 +573,14 @@ def test_candidate_overflow_falls_back_to_dense_kernels(ctx):
     sc = capi.DevBuf(4 * capi.scratch_floats(256, 256, 3, False))
     pts = ctx.zeros(576 * 32768)
     cnt = ctx.zeros(4)
-    capi.check(capi.lib().misift_extract_batch_async(ctx.h, d.ptr, 1, 256 * 256, 256, 256, 256, 3, 1.0, 0.05, 0.0,
-                                                     sc.ptr, pts.ptr, 32768, cnt.ptr), "misift_extract_batch_async")
-    ctx.sync()
+    was_fused = ctx.get_options().fused
+    ctx.set_options(fused=1)                  # (a MISIFT_FUSED=0 run of the suite starts on the dense kernels)
+    try:
+        capi.check(capi.lib().misift_extract_batch_async(ctx.h, d.ptr, 1, 256 * 256, 256, 256, 256, 3, 1.0, 0.05, 0.0,
+                                                         sc.ptr, pts.ptr, 32768, cnt.ptr), "misift_extract_batch_async")
+        ctx.sync()
+    finally:
+        ctx.set_options(fused=was_fused)
     assert ctx.download(cnt, (1,), np.int32)[0] == -1
 
 
@@ -823,22 +828,25 @@ def test_improve_homography_device_vs_oracle(ctx, stereo):
     assert ng == no and no > 100 and np.array_equal(Ho.view(np.uint32), Hg.view(np.uint32))
 
 
-def test_deterministic_mode_is_byte_identical_across_runs(ctx):
+@pytest.mark.parametrize("fused", [1, 0])
+def test_deterministic_mode_is_byte_identical_across_runs(ctx, fused):
     """options.deterministic: the reference appends records with atomics, so only the SET is
     reproducible run to run; with the switch on the order is fixed by the keypoints themselves — repeated runs and a
-    run on another context return byte-identical arrays, and the set still equals the default mode's and the oracle's."""
+    run on another context return byte-identical arrays, and the set still equals the default mode's and the oracle's.
+    fused = 1: the merged-octave path (total order where it bins its detections); fused = 0: the dense kernels (also the
+    exact re-run after a candidate-list overflow), every segment sorted after the fact."""
     from cudasift_amd import capi
     imgs = np.stack([synth_frame(2100 + f, 960, 540) for f in range(3)])
     base_pts, base_n = ctx.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192)
     was_fused = ctx.get_options().fused
-    ctx.set_options(deterministic=1, fused=1)        # the order is fixed where the merged-octave path bins its detections
+    ctx.set_options(deterministic=1, fused=fused)
     try:
         runs = [ctx.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192) for _ in range(3)]
     finally:
         ctx.set_options(deterministic=0, fused=was_fused)
     c2 = capi.Context(0)
     try:
-        c2.set_options(deterministic=1, fused=1)
+        c2.set_options(deterministic=1, fused=fused)
         runs.append(c2.extract_batch(imgs, num_octaves=5, thresh=3.0, max_pts=8192))
     finally:
         c2.close()
@@ -852,4 +860,4 @@ def test_deterministic_mode_is_byte_identical_across_runs(ctx):
             assert pts[f][:n].tobytes() == ref_bytes, "deterministic mode must give identical ORDER, frame %d" % f
         assert _canon(runs[0][0][f][:n]) == _canon(base_pts[f][:n])          # same set as the default mode
         o, no, _ = orc().extract(imgs[f], num_octaves=5, thresh=3.0, max_pts=8192)
-        compare_points(o[:no], runs[0][0][f][:n], "deterministic_f%d" % f, record)
+        compare_points(o[:no], runs[0][0][f][:n], "deterministic_fused%d_f%d" % (fused, f), record)
