@@ -888,10 +888,26 @@ int orc_extract(const float *img, int width, int height, int pitch, int numOctav
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#ifdef __GLIBC__
+#include <malloc.h>
+#endif
 void orc_extract_batch(const float *imgs, int nframes, int width, int height, int numOctaves, float initBlur,
                        float thresh, float lowestScale, SiftPoint *pts, int maxPts, int fracbits, int *numPts,
                        unsigned int *counters17, int outer_threads, int inner_threads)
 {
+#ifdef __GLIBC__
+  /* An extraction allocates and frees ~100 work buffers of megabytes each.  glibc serves those with mmap / munmap by
+   * default, and with a frame on every core the page faults and the TLB shoot-downs of the unmaps serialise the whole
+   * machine (256 cores: 47 frames/s, 0.18 per core, against 3.2 per core for 8 frames on 8 cores).  Keep the blocks in
+   * the per-thread heaps instead: after the first frame of a thread nothing is mapped or unmapped any more. */
+  static int tuned = 0;
+  if (!tuned) {
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+    tuned = 1;
+  }
+#endif
 #ifdef _OPENMP
   const int levels_saved = omp_get_max_active_levels();
   omp_set_max_active_levels(2);
