@@ -38,7 +38,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "liboracle.so")
+        path = os.environ.get("ORACLE_LIB") or os.path.join(HERE, "liboracle.so")     # ORACLE_LIB: the sanitizer flavour (make -C oracle asan)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
