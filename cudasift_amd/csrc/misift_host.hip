@@ -168,18 +168,47 @@ struct CtxFull {
 };
 static CtxExtra *extra(misift_ctx *ctx) { return &reinterpret_cast<CtxFull *>(ctx)->x; }
 
-extern "C" int misift_device_count(void)
+// MISIFT_DEVICES="2,3" (SURVEY section 5): device i of this library = HIP device list[i], the others do not exist for
+// it — like HIP_VISIBLE_DEVICES but for libmisift.so only (a process that shares the GPUs with another runtime keeps
+// its own numbering).  Unset or empty: every HIP device, identity.  Read once.
+static const std::vector<int> &device_map(void)
 {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-  return n;
+  static std::vector<int> m;
+  static bool init = false;
+  if (!init) {
+    init = true;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    const char *e = getenv("MISIFT_DEVICES");
+    if (e && *e) {
+      for (const char *p = e; *p;) {
+        char *end = nullptr;
+        const long d = strtol(p, &end, 10);
+        if (end == p) break;
+        if (d >= 0 && d < n) m.push_back((int)d);
+        p = (*end == ',') ? end + 1 : end;
+        if (*end && *end != ',') break;
+      }
+    } else {
+      for (int i = 0; i < n; i++) m.push_back(i);
+    }
+  }
+  return m;
 }
+static int physical_device(int logical)
+{
+  const std::vector<int> &m = device_map();
+  return (logical >= 0 && logical < (int)m.size()) ? m[(size_t)logical] : -1;
+}
+
+extern "C" int misift_device_count(void) { return (int)device_map().size(); }
 
 extern "C" int misift_device_info(int device, char *name, int name_len, int *mem_clock_khz, int *bus_width_bits,
                                   size_t *total_mem_bytes, int *num_cus, int *lds_bytes_per_block)
 {
+  ARG_CHECK(physical_device(device) >= 0);
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  HIP_TRY(hipGetDeviceProperties(&prop, physical_device(device)));
   if (name && name_len > 0) {
     // ROCm 7.2 leaves prop.name empty for some Instinct parts: fall back to the ISA name
     if (prop.name[0]) snprintf(name, name_len, "%s", prop.name);
@@ -195,9 +224,9 @@ extern "C" int misift_device_info(int device, char *name, int name_len, int *mem
 
 extern "C" int misift_device_arch(int device, char *arch, int arch_len)
 {
-  ARG_CHECK(arch && arch_len > 0);
+  ARG_CHECK(arch && arch_len > 0 && physical_device(device) >= 0);
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  HIP_TRY(hipGetDeviceProperties(&prop, physical_device(device)));
   snprintf(arch, arch_len, "%s", prop.gcnArchName);
   return MISIFT_OK;
 }
@@ -279,6 +308,7 @@ extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
     return MISIFT_ENODEV;
   }
   if (device < 0 || device >= n) device = n - 1;      // like InitCuda: clamp (cudaSiftH.cu:27)
+  device = physical_device(device);                   // MISIFT_DEVICES: from here on the HIP device number
   HIP_TRY(hipSetDevice(device));
   CtxFull *f = new CtxFull();
   misift_ctx *ctx = &f->c;

@@ -861,3 +861,34 @@ def test_deterministic_mode_is_byte_identical_across_runs(ctx, fused):
         assert _canon(runs[0][0][f][:n]) == _canon(base_pts[f][:n])          # same set as the default mode
         o, no, _ = orc().extract(imgs[f], num_octaves=5, thresh=3.0, max_pts=8192)
         compare_points(o[:no], runs[0][0][f][:n], "deterministic_fused%d_f%d" % (fused, f), record)
+
+
+def test_misift_devices_env():
+    """MISIFT_DEVICES: the library's own device list.  "0" leaves one device that works; an index the box
+    does not have leaves none and misift_ctx_create says so (read once per process: subprocesses)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np\n"
+            "from cudasift_amd import capi\n"
+            "n = capi.device_count()\n"
+            "print('count', n)\n"
+            "try:\n"
+            "    c = capi.Context(0)\n"
+            "    pts, k, _ = c.extract(np.random.default_rng(1).random((64, 64), np.float32) * 255, num_octaves=2, thresh=1.0, max_pts=512)\n"
+            "    print('ctx ok', k >= 0)\n"
+            "    c.close()\n"
+            "except capi.MisiftError as e:\n"
+            "    print('ctx failed', e)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for val in ("0", "63", ""):
+        env = dict(os.environ, PYTHONPATH=root)
+        if val:
+            env["MISIFT_DEVICES"] = val
+        else:
+            env.pop("MISIFT_DEVICES", None)
+        outs[val] = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300).stdout
+    assert "count 1" in outs["0"] and "ctx ok True" in outs["0"], outs
+    assert "count 0" in outs["63"] and "ctx failed" in outs["63"] and "no HIP device visible" in outs["63"], outs
+    assert "ctx ok True" in outs[""], outs
