@@ -63,9 +63,10 @@ __device__ __forceinline__ float wave_max32_nonneg(float v)
 }
 
 // ---------------------------------------------------------------- LDS-staged image patch
-// rocprof (r01): orient_all / descr_all were bound by the L1's one-cache-line-per-clock lookup rate — every one of a
-// descriptor's 2048 texel-pair gathers (338 for an orientation) is its own L1 lookup, and the L1 is shared by the
-// CU's four SIMDs.  The patch a keypoint samples is small and square, so it is now fetched ONCE with row-contiguous
+// r01 read orient_all / descr_all as bound by the L1's one-cache-line-per-clock lookup rate (every one of a
+// descriptor's 2048 texel-pair gathers, 338 for an orientation, is its own L1 lookup); the r02 instruction-cost
+// measurements say they are bound by VALU instruction issue, and what the window buys is the
+// address arithmetic and clamping of the gathers.  The patch a keypoint samples is small and square: it is fetched ONCE with row-contiguous
 // loads (13 dwordx2 per lane for the descriptor's 40x40 window, 4 dwords for the orientation's 16x16: ~15x fewer
 // lookups), parked in a wave-private LDS tile with clamp-to-edge already applied (so border keypoints need no
 // selects either), and all bilinear fetches read the tile: one address, two ds_read2_b32 (offsets {0,1} and
