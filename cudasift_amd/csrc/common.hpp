@@ -100,6 +100,19 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb)
   return base + i;
 }
 
+// The same dot product where the reference writes it as ONE expression k4*c + k3*p1 + ... (LowPassBlock,
+// cudaSiftD.cu:2001-2005, :2022-2026): a contracting compiler fuses the LEFT product of `a*b + c*d` and rounds the
+// right one (oracle/sift_oracle.c conv9_expr; bit-identical to the reference source built with -ffp-contract=fast).
+__device__ __forceinline__ float conv9_expr(const float k0, const float k1, const float k2, const float k3,
+                                            const float k4, float c, float p1, float p2, float p3, float p4)
+{
+  float s = __builtin_fmaf(k0, c, k1 * p1);
+  s = __builtin_fmaf(k2, p2, s);
+  s = __builtin_fmaf(k3, p3, s);
+  s = __builtin_fmaf(k4, p4, s);
+  return s;
+}
+
 // Symmetric 9-tap dot product: centre tap first, then outward (explicit fmaf chain;
 // arithmetic contract shared with oracle/sift_oracle.c conv9()).
 __device__ __forceinline__ float conv9(const float k0, const float k1, const float k2, const float k3,

@@ -13,7 +13,10 @@
 // input row is read once per segment and every output row written once.
 // HBM-bound: algorithmic bytes are 8 B/px (lowpass) and 5 B/px of input (scaledown).
 //
-// Arithmetic is the explicit fmaf chain of oracle/sift_oracle.c (bit-identical).
+// Arithmetic is the explicit fmaf chain of oracle/sift_oracle.c (bit-identical).  Since r03 the chains of LowPass and
+// ScaleDown follow what a contracting compiler makes of the reference's single-expression sums (left product fused,
+// right product rounded: conv9_expr) — pinned bit for bit by the reference's own kernels compiled that way and run on
+// the CPU SIMT emulator (oracle/_ref/libcudasift_refemul_fast.so, tests/test_refemul_cpu.py).
 #include "common.hpp"
 
 #define WAVES_PER_BLOCK 4
@@ -86,10 +89,10 @@ __global__ __launch_bounds__(256, 4) void lowpass_kernel(const SRC *__restrict__
     const float4 l = quad_from_left(c);
     const float4 r = quad_from_right(c);
     float4 h;
-    h.x = conv9(k0, k1, k2, k3, k4, c.x, c.y + l.w, c.z + l.z, c.w + l.y, r.x + l.x);
-    h.y = conv9(k0, k1, k2, k3, k4, c.y, c.z + c.x, c.w + l.w, r.x + l.z, r.y + l.y);
-    h.z = conv9(k0, k1, k2, k3, k4, c.z, c.w + c.y, r.x + c.x, r.y + l.w, r.z + l.z);
-    h.w = conv9(k0, k1, k2, k3, k4, c.w, r.x + c.z, r.y + c.y, r.z + c.x, r.w + l.w);
+    h.x = conv9_expr(k0, k1, k2, k3, k4, c.x, c.y + l.w, c.z + l.z, c.w + l.y, r.x + l.x);
+    h.y = conv9_expr(k0, k1, k2, k3, k4, c.y, c.z + c.x, c.w + l.w, r.x + l.z, r.y + l.y);
+    h.z = conv9_expr(k0, k1, k2, k3, k4, c.z, c.w + c.y, r.x + c.x, r.y + l.w, r.z + l.z);
+    h.w = conv9_expr(k0, k1, k2, k3, k4, c.w, r.x + c.z, r.y + c.y, r.z + c.x, r.w + l.w);
     return h;
   };
   auto hrow = [&](int y) -> float4 { return hfilt(ldraw(y)); };
@@ -106,10 +109,10 @@ __global__ __launch_bounds__(256, 4) void lowpass_kernel(const SRC *__restrict__
     raw = raw1;
     raw1 = rawnext;
     float4 o;
-    o.x = conv9(k0, k1, k2, k3, k4, w4.x, w3.x + w5.x, w2.x + w6.x, w1.x + w7.x, w0.x + w8.x);
-    o.y = conv9(k0, k1, k2, k3, k4, w4.y, w3.y + w5.y, w2.y + w6.y, w1.y + w7.y, w0.y + w8.y);
-    o.z = conv9(k0, k1, k2, k3, k4, w4.z, w3.z + w5.z, w2.z + w6.z, w1.z + w7.z, w0.z + w8.z);
-    o.w = conv9(k0, k1, k2, k3, k4, w4.w, w3.w + w5.w, w2.w + w6.w, w1.w + w7.w, w0.w + w8.w);
+    o.x = conv9_expr(k0, k1, k2, k3, k4, w4.x, w3.x + w5.x, w2.x + w6.x, w1.x + w7.x, w0.x + w8.x);
+    o.y = conv9_expr(k0, k1, k2, k3, k4, w4.y, w3.y + w5.y, w2.y + w6.y, w1.y + w7.y, w0.y + w8.y);
+    o.z = conv9_expr(k0, k1, k2, k3, k4, w4.z, w3.z + w5.z, w2.z + w6.z, w1.z + w7.z, w0.z + w8.z);
+    o.w = conv9_expr(k0, k1, k2, k3, k4, w4.w, w3.w + w5.w, w2.w + w6.w, w1.w + w7.w, w0.w + w8.w);
     if (writer) {
       if (FAST) *reinterpret_cast<float4 *>(out + (size_t)y * dpitch + 4 * q) = o;
       else store_quad(out + (size_t)y * dpitch, q, g.width, dal, o);
@@ -157,10 +160,10 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
     const float4 l = quad_from_left(c);
     const float4 r = quad_from_right(c);
     float4 h;
-    h.x = conv9(k0, k1, k2, k3, k4, c.x, c.y + l.w, c.z + l.z, c.w + l.y, r.x + l.x);
-    h.y = conv9(k0, k1, k2, k3, k4, c.y, c.z + c.x, c.w + l.w, r.x + l.z, r.y + l.y);
-    h.z = conv9(k0, k1, k2, k3, k4, c.z, c.w + c.y, r.x + c.x, r.y + l.w, r.z + l.z);
-    h.w = conv9(k0, k1, k2, k3, k4, c.w, r.x + c.z, r.y + c.y, r.z + c.x, r.w + l.w);
+    h.x = conv9_expr(k0, k1, k2, k3, k4, c.x, c.y + l.w, c.z + l.z, c.w + l.y, r.x + l.x);
+    h.y = conv9_expr(k0, k1, k2, k3, k4, c.y, c.z + c.x, c.w + l.w, r.x + l.z, r.y + l.y);
+    h.z = conv9_expr(k0, k1, k2, k3, k4, c.z, c.w + c.y, r.x + c.x, r.y + l.w, r.z + l.z);
+    h.w = conv9_expr(k0, k1, k2, k3, k4, c.w, r.x + c.z, r.y + c.y, r.z + c.x, r.w + l.w);
     return h;
   };
   auto hrow = [&](int y) -> float4 { return hfilt(ldraw(y)); };
@@ -172,13 +175,12 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
     if (last_quad) rx = o.w;
     float2 h;
     float s;
-    s = d0 * (lz + o.z);  s = __builtin_fmaf(d1, lw + o.y, s);  h.x = __builtin_fmaf(d2, o.x, s);
-    s = d0 * (o.x + rx);  s = __builtin_fmaf(d1, o.y + o.w, s); h.y = __builtin_fmaf(d2, o.z, s);
+    s = __builtin_fmaf(d0, lz + o.z, d1 * (lw + o.y));  h.x = __builtin_fmaf(d2, o.x, s);
+    s = __builtin_fmaf(d0, o.x + rx, d1 * (o.y + o.w)); h.y = __builtin_fmaf(d2, o.z, s);
     return h;
   };
   auto vcomb = [&](float a0, float a1, float a2, float a3, float a4) -> float {
-    float s = d2 * a2;
-    s = __builtin_fmaf(d0, a0 + a4, s);
+    float s = __builtin_fmaf(d2, a2, d0 * (a0 + a4));
     s = __builtin_fmaf(d1, a1 + a3, s);
     return s;
   };
@@ -204,10 +206,10 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
     raw = raw1;
     raw1 = rawnext;
     float4 o;
-    o.x = conv9(k0, k1, k2, k3, k4, w4.x, w3.x + w5.x, w2.x + w6.x, w1.x + w7.x, w0.x + w8.x);
-    o.y = conv9(k0, k1, k2, k3, k4, w4.y, w3.y + w5.y, w2.y + w6.y, w1.y + w7.y, w0.y + w8.y);
-    o.z = conv9(k0, k1, k2, k3, k4, w4.z, w3.z + w5.z, w2.z + w6.z, w1.z + w7.z, w0.z + w8.z);
-    o.w = conv9(k0, k1, k2, k3, k4, w4.w, w3.w + w5.w, w2.w + w6.w, w1.w + w7.w, w0.w + w8.w);
+    o.x = conv9_expr(k0, k1, k2, k3, k4, w4.x, w3.x + w5.x, w2.x + w6.x, w1.x + w7.x, w0.x + w8.x);
+    o.y = conv9_expr(k0, k1, k2, k3, k4, w4.y, w3.y + w5.y, w2.y + w6.y, w1.y + w7.y, w0.y + w8.y);
+    o.z = conv9_expr(k0, k1, k2, k3, k4, w4.z, w3.z + w5.z, w2.z + w6.z, w1.z + w7.z, w0.z + w8.z);
+    o.w = conv9_expr(k0, k1, k2, k3, k4, w4.w, w3.w + w5.w, w2.w + w6.w, w1.w + w7.w, w0.w + w8.w);
     if (writer && y >= y0 && y < y1) *reinterpret_cast<float4 *>(out + (size_t)y * dpitch + 4 * q) = o;
     const float2 hd = hdec(o);
     a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = hd;
@@ -255,15 +257,14 @@ __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict_
     const float rx = lane_from_right(A.x);                             // px 8q+8
     float4 h;
     float s;
-    s = k0 * (lz + A.z);  s = __builtin_fmaf(k1, lw + A.y, s);  h.x = __builtin_fmaf(k2, A.x, s);
-    s = k0 * (A.x + B.x); s = __builtin_fmaf(k1, A.y + A.w, s); h.y = __builtin_fmaf(k2, A.z, s);
-    s = k0 * (A.z + B.z); s = __builtin_fmaf(k1, A.w + B.y, s); h.z = __builtin_fmaf(k2, B.x, s);
-    s = k0 * (B.x + rx);  s = __builtin_fmaf(k1, B.y + B.w, s); h.w = __builtin_fmaf(k2, B.z, s);
+    s = __builtin_fmaf(k0, lz + A.z, k1 * (lw + A.y));  h.x = __builtin_fmaf(k2, A.x, s);
+    s = __builtin_fmaf(k0, A.x + B.x, k1 * (A.y + A.w)); h.y = __builtin_fmaf(k2, A.z, s);
+    s = __builtin_fmaf(k0, A.z + B.z, k1 * (A.w + B.y)); h.z = __builtin_fmaf(k2, B.x, s);
+    s = __builtin_fmaf(k0, B.x + rx, k1 * (B.y + B.w)); h.w = __builtin_fmaf(k2, B.z, s);
     return h;
   };
   auto vcomb = [&](float a0, float a1, float a2, float a3, float a4) -> float {
-    float s = k2 * a2;
-    s = __builtin_fmaf(k0, a0 + a4, s);
+    float s = __builtin_fmaf(k2, a2, k0 * (a0 + a4));
     s = __builtin_fmaf(k1, a1 + a3, s);
     return s;
   };

@@ -64,3 +64,46 @@ extern "C" int ref_improve_homography(void *pts, int numPts, float *homography, 
 EOF2
 } | g++ -x c++ -O2 -ffp-contract=off -shared -fPIC -w -I"$ROOT/include" -I"$ROOT/cudasift_amd/compat" -o "$OUT/libgeomref.so" -
 echo "build_ref: built $OUT/libgeomref.so"
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's OWN extraction + matching code on a CPU SIMT emulator (VERDICT r2 "pin the extraction oracle").
+# cudaImage.cu, cudaSiftH.cu (which #includes cudaSiftD.cu: all 25 kernels) and matching.cu are compiled where
+# they lie, with oracle/simt_emul.h force-included as the "CUDA toolkit".  The only textual changes, applied in the
+# pipe, are the two rewrites of oracle/launch_rewrite.sed (the launch syntax g++ cannot parse; one float->int conversion).
+# Two flavours: -ffp-contract=off (every product rounded) and -ffp-contract=fast (g++ fuses multiply-adds the way a
+# -fmad=true compiler may) — nvcc's actual choice is not observable here, the pair brackets it.
+REWRITE="$HERE/launch_rewrite.sed"     # the two rewrites (launch syntax; the GPU's NaN -> 0 float-to-int conversion)
+# emit one reference .cu with the rewrites applied; cudaSiftH.cu #includes cudaSiftD.cu textually: inline it in the pipe
+ref_tu() {
+  sed -f "$REWRITE" "$REF/$1.cu" | while IFS= read -r LINE; do
+    if [ "$LINE" = '#include "cudaSiftD.cu"' ]; then sed -f "$REWRITE" "$REF/cudaSiftD.cu"; else printf '%s\n' "$LINE"; fi
+  done
+}
+# -fno-toplevel-reorder: __shared__ variables (function-local statics here) are laid out in DECLARATION order, as
+# nvcc lays out static shared memory.  It matters once: the descriptor kernel's vote with angle bin 8 in the last
+# cell writes buffer[128]; in declaration order that is sums[0], which is overwritten before
+# it is read (harmless, as on the GPU) — g++'s default reverse order would make it gauss[0] and poison every later
+# descriptor of the block.
+EMUFLAGS="-x c++ -std=c++17 -O2 -fPIC -fopenmp -mavx2 -mfma -fno-math-errno -fno-toplevel-reorder -w -include $HERE/simt_emul.h -I$REF"
+for FLAVOUR in off fast; do
+  OBJ="$OUT/refemul_$FLAVOUR"
+  mkdir -p "$OBJ"
+  PIDS=""
+  for SRC in cudaImage cudaSiftH matching; do
+    ref_tu $SRC | g++ $EMUFLAGS -ffp-contract=$FLAVOUR -c -o "$OBJ/$SRC.o" - & PIDS="$PIDS $!"
+  done
+  g++ $EMUFLAGS -ffp-contract=$FLAVOUR -c -o "$OBJ/wrap.o" "$HERE/refemul_wrap.cpp" & PIDS="$PIDS $!"
+  g++ -std=c++17 -O2 -fPIC -fopenmp -c -o "$OBJ/engine.o" "$HERE/simt_emul.cpp" & PIDS="$PIDS $!"
+  for P in $PIDS; do wait $P; done
+  g++ -shared -fopenmp -o "$OUT/libcudasift_refemul_$FLAVOUR.so" "$OBJ"/cudaImage.o "$OBJ"/cudaSiftH.o "$OBJ"/matching.o \
+      "$OBJ"/wrap.o "$OBJ"/engine.o
+  echo "build_ref: built $OUT/libcudasift_refemul_$FLAVOUR.so (reference kernels on the CPU SIMT emulator)"
+done
+# ... and the reference's unmodified demo on top of it: mainSift.cpp + geomFuncs.cpp + the emulated library = the
+# whole reference program running here without a GPU (prints the feature / match counts of mainSift.cpp:80-81).
+# (its 1000 timing repetitions of ExtractSift, mainSift.cpp:66, are cut to 1 in the pipe: seconds instead of an hour)
+sed 's/i<1000;i++/i<1;i++/' "$REF/mainSift.cpp" | g++ -x c++ -std=c++17 -O2 -w -fopenmp -I"$REF" -I"$ROOT/cudasift_amd/compat" \
+    -c -o "$OUT/refemul_fast/main.o" -
+g++ -std=c++17 -O2 -w -fopenmp -I"$REF" -I"$ROOT/cudasift_amd/compat" -o "$OUT/cudasift_refemul_main" \
+    "$OUT/refemul_fast/main.o" "$REF/geomFuncs.cpp" -L"$OUT" -lcudasift_refemul_fast -Wl,-rpath,'$ORIGIN'
+echo "build_ref: built $OUT/cudasift_refemul_main"

@@ -172,6 +172,20 @@ static inline float conv9(const float kc[5], float c, float p1, float p2, float 
   return s;
 }
 
+/* The same dot product where the reference writes it as ONE expression `k4*c + k3*p1 + k2*p2 + k1*p3 + k0*p4`
+ * (LowPassBlock, cudaSiftD.cu:2001-2005, :2022-2026) instead of a running sum: a contracting compiler (LLVM's DAG
+ * combiner, which NVPTX uses under -fmad=true, and g++ -ffp-contract=fast alike) fuses the LEFT product of
+ * `a*b + c*d` and rounds the right one, then fuses every later product into the running sum.  Pinned by the
+ * reference's own source compiled that way (oracle/_ref/libcudasift_refemul_fast.so, tests/test_refemul_cpu.py). */
+static inline float conv9_expr(const float kc[5], float c, float p1, float p2, float p3, float p4)
+{
+  float s = fmaf(kc[0], c, kc[1] * p1);
+  s = fmaf(kc[2], p2, s);
+  s = fmaf(kc[3], p3, s);
+  s = fmaf(kc[4], p4, s);
+  return s;
+}
+
 /* LowPass: horizontal pass first, then vertical; clamp-to-edge.
  * cudaSiftD.cu:1999-2005 (horizontal), :2022-2026 (vertical). */
 void orc_lowpass(const float *src, int w, int h, int spitch, float *dst, int dpitch, float sigma)
@@ -185,7 +199,7 @@ void orc_lowpass(const float *src, int w, int h, int spitch, float *dst, int dpi
     const float *r = src + (size_t)y * spitch;
     for (int x = 0; x < w; x++) {
 #define R(d) r[clampi(x + (d), 0, w - 1)]
-      tmp[(size_t)y * w + x] = conv9(kc, R(0), R(1) + R(-1), R(2) + R(-2), R(3) + R(-3), R(4) + R(-4));
+      tmp[(size_t)y * w + x] = conv9_expr(kc, R(0), R(1) + R(-1), R(2) + R(-2), R(3) + R(-3), R(4) + R(-4));
 #undef R
     }
   }
@@ -193,7 +207,7 @@ void orc_lowpass(const float *src, int w, int h, int spitch, float *dst, int dpi
   for (int y = 0; y < h; y++) {
     for (int x = 0; x < w; x++) {
 #define T(d) tmp[(size_t)clampi(y + (d), 0, h - 1) * w + x]
-      dst[(size_t)y * dpitch + x] = conv9(kc, T(0), T(-1) + T(1), T(-2) + T(2), T(-3) + T(3), T(-4) + T(4));
+      dst[(size_t)y * dpitch + x] = conv9_expr(kc, T(0), T(-1) + T(1), T(-2) + T(2), T(-3) + T(3), T(-4) + T(4));
 #undef T
     }
   }
@@ -214,8 +228,7 @@ void orc_scaledown(const float *src, int w, int h, int spitch, float *dst, int d
     const float *r = src + (size_t)y * spitch;
     for (int x = 0; x < w2; x++) {
 #define R(m) r[clampi(2 * x + (m) - 2, 0, w - 1)]
-      float s = k0 * (R(0) + R(4));
-      s = fmaf(k1, R(1) + R(3), s);
+      float s = fmaf(k0, R(0) + R(4), k1 * (R(1) + R(3)));   /* one expression: left product fused, see conv9_expr */
       s = fmaf(k2, R(2), s);
       tmp[(size_t)y * w2 + x] = s;
 #undef R
@@ -225,8 +238,7 @@ void orc_scaledown(const float *src, int w, int h, int spitch, float *dst, int d
   for (int y = 0; y < h2; y++) {
     for (int x = 0; x < w2; x++) {
 #define T(m) tmp[(size_t)clampi(2 * y + (m) - 2, 0, h - 1) * w2 + x]
-      float s = k2 * T(2);
-      s = fmaf(k0, T(0) + T(4), s);
+      float s = fmaf(k2, T(2), k0 * (T(0) + T(4)));
       s = fmaf(k1, T(1) + T(3), s);
       dst[(size_t)y * dpitch + x] = s;
 #undef T

@@ -1,0 +1,333 @@
+"""The oracle pinned to the reference's OWN code.
+
+oracle/build_ref.sh compiles the reference's cudaImage.cu + cudaSiftH.cu (+ cudaSiftD.cu: all 25 kernels) +
+matching.cu where they lie against a CPU SIMT emulation (oracle/simt_emul.h: fibers for threads, barriers, 32-lane
+warp shuffles/votes, atomics, __shared__, textures with 1.8 fixed-point weights), twice: `-ffp-contract=fast` (g++
+fuses multiply-adds, like a -fmad=true CUDA compile may) and `-ffp-contract=off`.  What runs is the reference's own
+control flow, tilings, constants, shared-memory protocols and counter protocol; what stays hardware-defined (the
+fast-math intrinsics, which FMAs nvcc forms) is mapped to libm / bracketed by the two flavours.
+
+Three layers:
+  1. the emulator itself against closed forms (kernels of our own, oracle/simt_selftest.cu);
+  2. oracle/sift_oracle.c against the emulated reference, live (needs oracle/_ref: built where /root/reference exists);
+  3. oracle/sift_oracle.c against tests/golden/refemul_golden.npz, vectors the emulated reference produced
+     (tests/golden/make_fixtures.py) — runs anywhere, the GPU suite checks the HIP path against the same file.
+"""
+import ctypes as C
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from oracle import pyrefemul as ref
+from synth import descriptors_to_points, synth_descriptors, synth_frame, synth_matches
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+needs_ref = pytest.mark.skipif(not ref.available("fast"), reason="oracle/_ref not built (needs /root/reference at build time)")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------------------------------ 1. the emulator itself
+@pytest.fixture(scope="module")
+def st():
+    path = os.path.join(ROOT, "oracle", "libsimt_selftest.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libsimt_selftest.so"])
+    L = C.CDLL(path)
+    L.st_fmul_rz.restype = C.c_float
+    L.st_fmul_rz.argtypes = [C.c_float, C.c_float]
+    L.st_f2i.argtypes = [C.c_float]
+    return L
+
+
+def test_emulator_warp_collectives(st):
+    nb, nt = 3, 96                                  # 3 warps per block; tid 77 sits in block 0, warp 2
+    n = nb * nt
+    out = np.zeros((6, n), np.int32)
+    st.st_warp(out.ctypes.data_as(C.c_void_p), nb, nt)
+    tid = np.arange(n)
+    lane = (tid % nt) % 32
+    v = 1000 + tid
+    assert np.array_equal(out[0], np.where(lane + 3 < 32, v + 3, v))            # shfl_down: out of range -> own value
+    assert np.array_equal(out[1], np.where(lane - 2 >= 0, v - 2, v))            # shfl_up
+    assert np.array_equal(out[2], v - lane + 5)                                 # shfl idx 5
+    assert np.array_equal(out[3], np.where(lane % 8 + 1 < 8, v + 1, v))         # width-8 segments
+    warp_of_77 = (tid // 32) == (77 // 32)
+    assert np.array_equal(out[4], warp_of_77.astype(np.int32))                  # any: per warp
+    assert (out[5].view(np.uint32) == 0xAAAAAAAA).all()                         # ballot of odd lanes
+
+
+def test_emulator_barriers_shared_memory_and_thread_indices(st):
+    nb, bx, by = 5, 16, 8
+    n = bx * by
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 100, nb * n).astype(np.int32)
+    out = np.zeros_like(a)
+    tids = np.zeros_like(a)
+    st.st_scan(a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), tids.ctypes.data_as(C.c_void_p), nb, bx, by)
+    assert np.array_equal(out.reshape(nb, n), np.cumsum(a.reshape(nb, n), axis=1))
+    t = np.arange(n)
+    want = (t % bx + 100 * (t // bx))[None, :] + 10000 * np.arange(nb)[:, None]
+    assert np.array_equal(tids.reshape(nb, n), want)
+
+
+def test_emulator_atomics_across_blocks(st):
+    cnt = np.zeros(4, np.uint32)
+    fsum = C.c_float(0)
+    nb, nt = 37, 100
+    st.st_atomics(nb, nt, cnt.ctypes.data_as(C.c_void_p), C.byref(fsum))
+    assert cnt[0] == nb * nt and cnt[1] == nb * nt - 1 and cnt[2] == (nb * nt) % 10
+    assert fsum.value == 0.5 * nb * nt
+
+
+def test_emulator_exited_threads_do_not_block(st):
+    out = np.full(64, -1, np.int32)
+    st.st_exit(out.ctypes.data_as(C.c_void_p))
+    t = np.arange(64)
+    v = t ^ 1
+    want = np.where(t >= 48, v + np.where(t + 4 < 64, v + 4, v), v)
+    want[32:48] = -1
+    assert np.array_equal(out, want)
+
+
+def test_emulator_texture_unit_and_conversions(st):
+    rng = np.random.default_rng(1)
+    h, w, pitch = 9, 13, 16
+    img = np.zeros((h, pitch), np.float32)
+    img[:, :w] = rng.uniform(0, 255, (h, w)).astype(np.float32)
+    xy = np.concatenate([rng.uniform(-3, w + 3, (200, 1)), rng.uniform(-3, h + 3, (200, 1))], axis=1).astype(np.float32)
+    xy[:4] = [[0.5, 0.5], [1.0, 0.5], [w - 0.5, h - 0.5], [3.25, 4.75]]
+    out = np.zeros(200, np.float32)
+    st.st_tex(img.ctypes.data_as(C.c_void_p), w, h, pitch, xy.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 200)
+    # CUDA programming guide, linear filtering: xB = x - 0.5, weights in 1.8 fixed point, clamp addressing
+    xb, yb = xy[:, 0] - np.float32(0.5), xy[:, 1] - np.float32(0.5)
+    i, j = np.floor(xb), np.floor(yb)
+    a = np.rint((xb - i).astype(np.float32) * 256) / 256
+    b = np.rint((yb - j).astype(np.float32) * 256) / 256
+    i0, i1 = np.clip(i, 0, w - 1).astype(int), np.clip(i + 1, 0, w - 1).astype(int)
+    j0, j1 = np.clip(j, 0, h - 1).astype(int), np.clip(j + 1, 0, h - 1).astype(int)
+    I = img.astype(np.float64)
+    want = (1 - a) * (1 - b) * I[j0, i0] + a * (1 - b) * I[j0, i1] + (1 - a) * b * I[j1, i0] + a * b * I[j1, i1]
+    assert np.array_equal(out, want.astype(np.float32))
+    assert out[0] == img[0, 0] and out[2] == img[h - 1, w - 1]                     # texel centres
+    assert out[1] == np.float32(0.5 * (float(img[0, 0]) + float(img[0, 1])))
+    # the oracle's texture fetch is the same function up to the rounding of the blend (fp32 fmaf chain vs exact)
+    got = np.array([orc.tex2d(img[:, :w], float(x), float(y)) for x, y in xy], np.float32)
+    assert np.abs(got - out).max() <= 4e-5
+    # __fmul_rz and the GPU's float -> int conversion
+    for x, y in ((1.1, 3.3), (-1.1, 3.3), (1e-3, 7.7), (123456.7, 0.3333)):
+        p = float(np.float32(x)) * float(np.float32(y))
+        r = st.st_fmul_rz(x, y)
+        away = np.nextafter(np.float32(r), np.float32(np.copysign(np.inf, r)), dtype=np.float32)
+        assert abs(r) <= abs(p) < abs(float(away))
+    assert st.st_f2i(float("nan")) == 0 and st.st_f2i(3e9) == 2**31 - 1 and st.st_f2i(-3e9) == -2**31 and st.st_f2i(-7.9) == -7
+
+
+# ------------------------------------------------------------------ 2. oracle vs the emulated reference, live
+@needs_ref
+@pytest.mark.parametrize("shape", [(240, 320), (37, 131), (64, 256), (33, 17)])
+def test_dense_stages_bit_identical_to_reference_kernels(stereo, shape):
+    """LowPassBlock, ScaleDown, LaplaceMultiMem (cudaSiftD.cu:1986-2037, 84-168, 1753-1793) compiled with
+    contraction: the oracle's explicit fmaf chains are the SAME bits.  Without contraction: within 1e-4."""
+    h, w = shape
+    img = stereo[0][300:300 + h, 400:400 + w].copy()
+    for sigma in (1.0, 1.3):
+        assert np.array_equal(ref.lowpass(img, sigma, "fast"), orc.lowpass(img, sigma))
+    low = orc.lowpass(img, 1.0)
+    assert np.array_equal(ref.scaledown(low, "fast"), orc.scaledown(low))
+    for octave in (5, 3, 1):
+        assert np.array_equal(ref.laplace(low, 5, octave, "fast"), orc.laplace(low, 5, octave))
+    assert np.array_equal(ref.laplace_taps(5, "fast"), orc.laplace_taps(5))
+    assert np.abs(ref.lowpass(img, 1.0, "off") - orc.lowpass(img, 1.0)).max() <= 1e-4
+    assert np.abs(ref.scaledown(low, "off") - orc.scaledown(low)).max() <= 1e-4
+    assert np.abs(ref.laplace(low, 5, 5, "off") - orc.laplace(low, 5, 5)).max() <= 1e-4
+
+
+def compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, name, strict, record=None):
+    """o_* = oracle, r_* = emulated reference.  Asserts the pin; returns the statistics.
+    strict: "bits" (same contraction on both sides), "ulp" (oracle without contraction), "" (reference without)."""
+    assert np.array_equal(o_cnt, r_cnt), (name, o_cnt, r_cnt)                       # all 17 counters of d_PointCounter
+    total = int(o_cnt[2 * noct + 1])
+    O, R = o_pts[:total], r_pts[:total]
+    ia, ib, only_o, only_r = util.associate(O, R)
+    # identical keypoint SET (same counters already); without contraction in the reference build the DoG planes differ
+    # in the last bits, which moves a refined position across the 0.5-pixel fallback rule once in a thousand points
+    budget = 0 if strict else max(2, int(0.002 * total))
+    assert len(only_o) <= budget and len(only_r) <= budget, (name, len(only_o), len(only_r))
+    A, B = O[ia], R[ib]
+    st = {"n": total, "exact_keys": int(util.associate.last_exact)}
+    for f in ("xpos", "ypos", "scale", "sharpness", "edgeness"):
+        st[f] = float(util.rel_err(A[f], B[f]).max())
+    od = util.circ_diff_deg(A["orientation"], B["orientation"])
+    st["orientation_deg"] = float(od.max())
+    st["orientation_flips"] = int((od > 0.036).sum())
+    nan_ref = np.isnan(B["data"]).any(axis=1)          # FastAtan2(0,0) = NaN poisons the reference's descriptor (B#7)
+    st["nan_descriptors_reference"] = int(nan_ref.sum())
+    ok = ~nan_ref & (od <= 0.036)
+    dd = np.abs(A["data"][ok].astype(np.float64) - B["data"][ok]).max(axis=1)
+    cos = (A["data"][ok].astype(np.float64) * B["data"][ok]).sum(axis=1)
+    st["desc_over_1e-5"] = int((dd > 1e-5).sum())
+    st["desc_over_1e-4"] = int((dd > 1e-4).sum())
+    st["desc_over_1e-3"] = int((dd > 1e-3).sum())
+    st["desc_max"] = float(dd.max())
+    st["desc_min_cos"] = float(cos.min())
+    if record:
+        record(name, **st)
+    tol = 5e-7 if strict else 3e-4
+    assert max(st["xpos"], st["ypos"], st["scale"], st["sharpness"], st["edgeness"]) <= tol, (name, st)
+    if strict == "bits":
+        # contraction flavour vs the oracle's nvcc-contraction mode: positions and the edge measure are the same BITS
+        assert st["xpos"] <= 1.5e-7 and st["ypos"] <= 1.5e-7 and st["edgeness"] == 0.0, (name, st)
+    if strict:
+        assert st["orientation_deg"] <= 0.036 and st["orientation_flips"] == 0, (name, st)
+        # descriptors: libm sincos/exp vs the written-out ones move a sample coordinate in its last bit; through the
+        # 8-bit texture weights that is <= 1/256 of a local pixel difference in a few elements, and
+        # the reference's own angle-bin wrap (angi = 8 <-> 0 at dy = +-0, B#6) can move one vote between cells
+        assert st["desc_over_1e-4"] <= 0.012 * total and st["desc_over_1e-3"] <= max(2, 0.002 * total), (name, st)
+        assert st["desc_min_cos"] >= 0.995, (name, st)
+    else:
+        assert st["orientation_flips"] <= max(2, 0.002 * total), (name, st)
+    assert st["nan_descriptors_reference"] <= orc.stats()["nan_guards"], (name, st)
+    return st
+
+
+@needs_ref
+@pytest.mark.parametrize("case", ["left", "right_crop", "synth1080", "synth_odd"])
+def test_extract_pinned_to_reference_kernels(stereo, case):
+    """ExtractSift end to end: the reference's host code + six live kernels on the emulator vs the oracle.
+    Counters, keypoint set: identical.  Fields: same bits (positions, edgeness) or 1-2 ulp (libm vs det_*)."""
+    from conftest import record
+    if case == "left":
+        img, noct, th = stereo[0], 5, 4.5
+    elif case == "right_crop":
+        img, noct, th = stereo[1][100:580, 200:840].copy(), 4, 2.0
+    elif case == "synth1080":
+        img, noct, th = synth_frame(0), 5, 3.0
+    else:
+        img, noct, th = synth_frame(5, 333, 251), 3, 2.5
+    r_pts, r_n, r_cnt = ref.extract(img, noct, 1.0, th, flavour="fast")
+    orc.stats_reset()
+    with orc.contract(1):
+        o_pts, o_n, o_cnt = orc.extract(img, noct, 1.0, th)
+    assert o_n == r_n
+    compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, "refemul_fast_vs_oracle_nvcc/" + case, "bits", record)
+    # the mode every HIP parity test uses (no contraction outside the filters): same set, values within 3e-7
+    orc.stats_reset()
+    o_pts, o_n, o_cnt = orc.extract(img, noct, 1.0, th)
+    compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, "refemul_fast_vs_oracle_plain/" + case, "ulp", record)
+    # the reference built with every product rounded: same counters and set, values within the rounding of the filters
+    r_pts, r_n, r_cnt = ref.extract(img, noct, 1.0, th, flavour="off")
+    compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, "refemul_off_vs_oracle_plain/" + case, "", record)
+
+
+@needs_ref
+def test_extract_scaleup_and_lowest_scale_pinned(stereo):
+    img = stereo[0][200:440, 300:620].copy()
+    r_pts, r_n, r_cnt = ref.extract(img, 4, 1.0, 3.0, lowest_scale=1.5, scale_up=True, flavour="fast")
+    orc.stats_reset()
+    with orc.contract(1):
+        o_pts, o_n, o_cnt = orc.extract(img, 4, 1.0, 3.0, lowest_scale=1.5, scale_up=True)
+    assert o_n == r_n and o_n > 50
+    compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, 4, "refemul_scaleup", "bits")
+
+
+@needs_ref
+def test_matcher_pinned_to_reference_kernel(stereo):
+    """MatchSiftData = CleanMatches + FindMaxCorr10 (matching.cu:289-397) on the emulator: score, ambiguity (the lossy
+    8-class runner-up merge), match, match_xpos/ypos are the oracle's bits, incl. the n2 % 32 truncation."""
+    p1, n1, _ = orc.extract(stereo[0][:480, :640], 5, 1.0, 3.0)
+    p2, n2, _ = orc.extract(stereo[1][:480, :640], 5, 1.0, 3.0)
+    for m1, m2 in ((n1, n2), (100, 63), (33, 64), (1, 32), (77, 1000)):
+        a, b = p1.copy(), p1.copy()
+        ref.match(a, m1, p2, m2, "fast")
+        orc.match(b, m1, p2, m2)
+        for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+            assert np.array_equal(a[f][:m1], b[f][:m1]), (m1, m2, f)
+        a = p1.copy()
+        ref.match(a, m1, p2, m2, "off")                      # products rounded separately: same winners, scores to 1e-6
+        assert np.array_equal(a["match"][:m1], b["match"][:m1])
+        assert np.allclose(a["score"][:m1], b["score"][:m1], rtol=2e-6, atol=0)
+
+
+@needs_ref
+def test_find_homography_pinned_to_reference_kernels():
+    """FindHomography (matching.cu:1000-1087: host rand() sampling, ComputeHomographies, TestHomographies with
+    __fmul_rz) on the emulator vs the oracle: same 8 coefficients, same inlier count."""
+    m, _, _ = synth_matches(3000, seed=5, dtype=orc.POINT_DTYPE)
+    for loops, seed in ((2000, 1), (500, 7)):
+        H, nm = ref.find_homography(m, 3000, loops, 0.85, 0.95, 5.0, seed=seed, flavour="fast")
+        orc.srand(seed)
+        Ho, no, _ = orc.find_homography(m, 3000, loops, 0.85, 0.95, 5.0)
+        assert nm == no and np.array_equal(H, Ho)
+
+
+@needs_ref
+def test_reference_demo_program_runs_on_the_emulator(tmp_path, stereo):
+    """mainSift.cpp + geomFuncs.cpp + the emulated library: the reference's whole program without a GPU.  Its feature
+    counts are the oracle's; its match counts are what the golden file recorded."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cudasift_refemul_main")
+    z = np.load(os.path.join(GOLDEN, "stereo_pair_u8.npz"))
+    os.makedirs(tmp_path / "data")
+    for nm, k in (("left", "left"), ("righ", "right")):
+        with open(tmp_path / "data" / (nm + ".pgm"), "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (z[k].shape[1], z[k].shape[0]))
+            f.write(z[k].tobytes())
+    r = subprocess.run([exe, "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SIMT_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    m1 = re.search(r"Number of original features: (\d+) (\d+)", r.stdout)
+    m2 = re.search(r"Number of matching features: (\d+) (\d+)", r.stdout)
+    _, n1, _ = orc.extract(stereo[0], 5, 1.0, 4.5)
+    _, n2, _ = orc.extract(stereo[1], 5, 1.0, 4.5)
+    assert (int(m1.group(1)), int(m1.group(2))) == (n1, n2)
+    g = np.load(os.path.join(GOLDEN, "refemul_golden.npz"))
+    assert [int(m2.group(1)), int(m2.group(2))] == g["main_matching"].tolist()
+
+
+# ------------------------------------------------- 3. oracle vs the committed vectors of the emulated reference
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "refemul_golden.npz"))
+
+
+def test_golden_dense_stages(stereo, golden):
+    crop = stereo[0][300:540, 400:720].copy()
+    low = orc.lowpass(crop, 1.0)
+    assert sha(low) == str(golden["sha_lowpass"])
+    assert sha(orc.scaledown(low)) == str(golden["sha_scaledown"])
+    assert sha(orc.laplace(low, 5, 5)) == str(golden["sha_laplace"])
+    odd = crop[:37, :131].copy()
+    assert sha(orc.lowpass(odd, 1.3)) == str(golden["sha_lowpass_odd"])
+    assert sha(orc.scaledown(odd)) == str(golden["sha_scaledown_odd"])
+    assert sha(orc.laplace(odd, 5, 3)) == str(golden["sha_laplace_odd"])
+
+
+@pytest.mark.parametrize("name,noct,th", [("crop", 4, 3.5), ("left", 5, 4.5)])
+def test_golden_extract(stereo, golden, name, noct, th):
+    img = stereo[0][300:540, 400:720].copy() if name == "crop" else stereo[0]
+    orc.stats_reset()
+    with orc.contract(1):
+        pts, n, cnt = orc.extract(img, noct, 1.0, th)
+    assert n == int(golden[name + "_n"])
+    compare_with_reference(pts, cnt, golden[name + "_records"], golden[name + "_counters"], noct, "golden/" + name, "bits")
+
+
+def test_golden_match_and_homography(golden):
+    a = descriptors_to_points(synth_descriptors(1000, 7), orc.POINT_DTYPE)
+    b = descriptors_to_points(synth_descriptors(1500, 8), orc.POINT_DTYPE)
+    orc.match(a, 1000, b, 1500)
+    for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+        assert np.array_equal(a[f], golden["match_" + f]), f
+    m, _, _ = synth_matches(3000, seed=5, dtype=orc.POINT_DTYPE)
+    orc.srand(1)
+    H, nm, _ = orc.find_homography(m, 3000, 2000, 0.85, 0.95, 5.0)
+    assert nm == int(golden["homography_inliers"]) and np.array_equal(H, golden["homography_H"])
