@@ -342,6 +342,216 @@ def matcher_leg(ops, rank, world, nm, msteps=3, validate_rows=100, l2=False, poi
     return out
 
 
+class StepPipeline:
+    """The software-pipelined step loop of ONE rank, the same for every N: batch k is extracted AND packed on the device
+    (misift_extract_batch_packed_async, nothing synchronises), then the host completes batch k-LAG: reads its per-frame
+    counts back and — with a communicator — gathers the packed SiftPoint records of all ranks on rank 0
+    (misift_gather_post / misift_gather_complete on the communicator's own stream), overlapping the extraction of the
+    batches queued behind it.  Every batch's read-back/gather completes before run() returns: nothing is skipped, only
+    overlapped."""
+
+    def __init__(self, torch, capi, ctxs, ctx_streams, comm, rank, world, device, frames, B, NB, scratches, pts, unfused):
+        self.torch, self.capi, self.ctxs, self.ctx_streams, self.comm = torch, capi, ctxs, ctx_streams, comm
+        self.rank, self.world, self.frames, self.B, self.NB, self.scratches = rank, world, frames, B, NB, scratches
+        self.pts, self.unfused = pts, unfused
+        NCTX = self.NCTX = len(ctxs)
+        self.LAG = NCTX + 1                 # the host completes batch k-LAG: NCTX batches stay queued on the GPU
+        NSLOT = self.NSLOT = self.LAG + 1
+        REC_CAP = self.REC_CAP = MAX_PTS    # mainSift.cpp:58-67 capacity (32768 records per frame)
+        self.packed = [torch.empty((B * REC_CAP * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
+        self.cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(NSLOT)]
+        self.done_ev = [None] * NSLOT
+        self.recv = (torch.empty((world * B * REC_CAP * 576,), dtype=torch.uint8, device=device)
+                     if (comm and rank == 0) else None)
+        # normal priority: high-priority streams share ONE hardware queue with the contexts' coarse-level streams
+        # (2 contexts: 49 k -> 54 k frames/s)
+        self.rb_stream = torch.cuda.Stream(device=device)
+        self.step_ev = []
+        self.host_t = {"enqueue": 0.0, "complete": 0.0}
+        self.trace_host = os.environ.get("BENCH_TRACE") == "1"     # developer aid: where the host spends the pipelined loop
+
+    def enqueue(self, k):
+        torch, capi, B = self.torch, self.capi, self.B
+        slot = k % self.NSLOT
+        b0 = (k % self.NB) * B
+        ci = k % self.NCTX
+        capi.check(capi.lib().misift_extract_batch_packed_async(
+            self.ctxs[ci].h, self.frames[b0].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0,
+            self.scratches[ci].data_ptr(),
+            self.pts.data_ptr() if self.unfused else None,      # merged-octave path writes the packed array directly
+            self.REC_CAP, self.cnts[slot].data_ptr(), self.cnts[slot][B:].data_ptr(), self.packed[slot].data_ptr()),
+            "misift_extract_batch_packed_async")
+        if self.comm is not None:
+            self.comm.gather_post(slot, self.cnts[slot].data_ptr(), B, self.packed[slot].data_ptr(), ctx=self.ctxs[ci])
+        else:
+            ev = torch.cuda.Event()
+            ev.record(self.ctx_streams[ci])
+            self.done_ev[slot] = ev
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(self.ctx_streams[ci])
+        self.step_ev.append(e)
+
+    def complete(self, k):
+        torch, B = self.torch, self.B
+        slot = k % self.NSLOT
+        if self.comm is not None:
+            c, _ = self.comm.gather_complete(slot, B, 0, self.recv.data_ptr() if self.recv is not None else None,
+                                             self.world * B * self.REC_CAP)
+            return c
+        with torch.cuda.stream(self.rb_stream):             # count read-back beside the running extraction
+            self.rb_stream.wait_event(self.done_ev[slot])
+            c = self.cnts[slot][:B].cpu().numpy()
+        return c[None, :]
+
+    def run(self, k0, nsteps):
+        last, LAG = None, self.LAG
+        for k in range(k0, k0 + nsteps):
+            ta = time.perf_counter()
+            self.enqueue(k)
+            tb = time.perf_counter()
+            if k - k0 >= LAG:
+                last = self.complete(k - LAG)
+            if self.trace_host:
+                self.host_t["enqueue"] += tb - ta
+                self.host_t["complete"] += time.perf_counter() - tb
+            if k - k0 >= LAG:
+                if (last < 0).any():
+                    raise RuntimeError("candidate list overflow in the bench workload")
+        for k in range(max(k0, k0 + nsteps - LAG), k0 + nsteps):
+            last = self.complete(k)
+        if (last < 0).any():
+            raise RuntimeError("candidate list overflow in the bench workload")
+        return last
+
+
+# ------------------------------------------------------------------------------------------------ emulated ranks
+class LoopbackMatchOps(CabiMatchOps):
+    """CabiMatchOps for ranks that are host THREADS of this process (loopback world): the two reductions that main()
+    does through torch.distributed go through a threading.Barrier."""
+
+    def __init__(self, torch, capi, ctx, comm, device, rank, world, shared):
+        super().__init__(torch, capi, ctx, comm, device, rank, world)
+        self.shared = shared
+
+    def barrier(self):
+        self.comm.barrier()
+        self.torch.cuda.current_stream().synchronize()
+        self.shared["bar"].wait()
+
+    def max_over_ranks(self, x):
+        self.shared["vals"][self.rank] = x
+        self.shared["bar"].wait()
+        m = max(self.shared["vals"])
+        self.shared["bar"].wait()
+        return m
+
+
+def emulate_ranks(args):
+    """`--emulate-ranks N`: the N-rank driver loops of BASELINE configs 4 and 5 executed END TO END on ONE GPU — N host
+    threads, N contexts of device 0, N communicators of a misift_loopback_world (include/misift.h): the same
+    StepPipeline (extract + pack, gather_post / gather_complete to rank 0) and the same matcher_leg (misift_match_sharded:
+    set-2 all-gather, MFMA sweep, result all-gather) as a real N-GPU run, device-to-device copies instead of RCCL.
+    FUNCTIONAL ONLY: the ranks share one GPU, the line it prints carries no rate and must never be read as scaling."""
+    import threading
+    import numpy as np
+    import torch
+    from cudasift_amd import capi
+    N = args.emulate_ranks
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    B, NB = max(1, min(args.frames_per_gpu, 4)), 2
+    steps, warm = max(3, min(args.steps, 6)), min(args.warmup, 2)
+    nm = min(args.match_n, 16384)
+    frames_of = []
+    for r in range(N):                       # every rank's own frames, generated as main() generates them
+        f = torch.empty((NB * B, H, W), dtype=torch.float32, device=device)
+        gen_frames_torch(torch, NB * B, r * NB * B, device, out=f)
+        frames_of.append(f)
+    torch.cuda.synchronize()
+    lw = capi.LoopbackWorld(N)
+    shared = {"bar": threading.Barrier(N), "vals": [0.0] * N}
+    res, errs = [None] * N, []
+    orc = None
+    if not args.no_cpu:
+        from oracle import pyoracle as orc
+
+    def body(rank):
+        try:
+            stream = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(stream):
+                ctx = capi.Context(0, stream.cuda_stream)
+                ctx.set_options(quiet=1)
+                comm = capi.Comm(ctx, N, rank, lw)
+                S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
+                scratch = torch.empty((B * S,), dtype=torch.float32, device=device)
+                stream.synchronize()
+                pl = StepPipeline(torch, capi, [ctx], [stream], comm, rank, N, device, frames_of[rank], B, NB, [scratch], None, False)
+                pl.run(0, warm)
+                comm.barrier()
+                counts = pl.run(warm, steps)
+                comm.barrier()
+                stream.synchronize()
+                out = {"counts": counts}
+                if rank == 0:                # the root holds every rank's records of the LAST batch, rank after rank
+                    total = int(np.maximum(counts, 0).sum())
+                    out["records"] = pl.recv[: total * 576].cpu().numpy().view(capi.POINT_DTYPE).copy()
+                    out["last_batch"] = (warm + steps - 1) % NB
+                if not args.no_match:
+                    ops = LoopbackMatchOps(torch, capi, ctx, comm, device, rank, N, shared)
+                    out["match"] = matcher_leg(ops, rank, N, nm, msteps=1, validate_rows=50, l2=False,
+                                               point_dtype=capi.POINT_DTYPE, result_dtype=capi.RESULT_DTYPE, oracle=orc)
+                res[rank] = out
+                comm.close()
+                ctx.close()
+        except Exception as e:               # noqa: BLE001 — reported by the main thread
+            import traceback
+            errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+            try:
+                shared["bar"].abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(N)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise RuntimeError("emulated ranks failed:\n" + "\n".join(errs))
+    lw.close()
+    counts = res[0]["counts"]
+    for r in range(1, N):
+        assert np.array_equal(res[r]["counts"], counts), "ranks disagree on the gathered counts"
+    validated = None
+    if orc is not None:                      # every rank's frames of the last batch, as gathered on rank 0, vs the oracle
+        from util import compare_points
+        recs, off, validated = res[0]["records"], 0, 0
+        b0 = res[0]["last_batch"] * B
+        for r in range(N):
+            host = frames_of[r][b0:b0 + B].cpu().numpy()
+            ref, nref, _ = orc.extract_batch(host, NUM_OCTAVES, INIT_BLUR, THRESH, max_pts=8192)
+            for f in range(B):
+                if int(nref[f]) != int(counts[r, f]):
+                    raise RuntimeError("emulated rank %d frame %d: %d records, oracle %d" % (r, f, counts[r, f], nref[f]))
+                compare_points(ref[f, :nref[f]], recs[off:off + nref[f]], "emulate_r%d_f%d" % (r, f))
+                off += int(nref[f])
+                validated += 1
+        assert off == len(recs)
+    m = res[0].get("match")
+    out = {"mode": "emulate-ranks", "functional_only": True, "emulated_ranks": N, "n_gpus": 1, "frames_per_rank": B,
+           "steps": steps, "warmup": warm,
+           "transport": "misift_loopback_world: N communicators / contexts / host threads on ONE device, device-to-device "
+                        "copies through a shared rendezvous (no RCCL); same StepPipeline and matcher_leg as --gpus N",
+           "gathered_frames_last_step": int(N * B), "validated_frames": validated,
+           "keypoints_per_frame": round(float(np.mean(counts)), 1),
+           "match": None if m is None else {"n1": m["n1"], "n2": m["n2"], "split": m["split"],
+                                            "validated_rows_per_rank": m.get("validated_rows")},
+           "note": "functional run of the N-rank code path on one GPU; carries no rate on purpose — it is not a scaling number"}
+    C.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -364,6 +574,9 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (H2D + extract + D2H) side measurement")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC traffic passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="run the N-rank driver loops (gather of SiftData, sharded matcher) end to end on ONE GPU through the "
+                         "loopback transport; functional only, prints no rate")
     args = ap.parse_args()
     # HIP multiplexes a process's streams onto 4 hardware queues unless told otherwise, and a stream that shares a
     # queue with the extraction stream runs BEHIND the batches queued there: the gather's communication stream then
@@ -373,6 +586,8 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.pmc_child:
         return pmc_child()
+    if args.emulate_ranks > 0:
+        return emulate_ranks(args)
 
     import numpy as np
     import torch                     # first: libmisift.so then binds to torch's HIP runtime
@@ -422,75 +637,12 @@ def main():
     counts = (C.c_int * B)()
     torch.cuda.synchronize()
 
-    # Software-pipelined step loop, the same for every N: batch k is extracted AND packed on the device
-    # (misift_extract_batch_packed_async, nothing synchronises), then the host completes batch k-LAG: reads its
-    # per-frame counts back and — with more than one GPU — gathers the packed SiftPoint records of all ranks on
-    # rank 0 (misift_gather_post / misift_gather_complete on the communicator's own stream), overlapping the
-    # extraction of the batches queued behind it.  Every batch's read-back/gather completes before the closing
-    # barrier: nothing is skipped, only overlapped.
-    LAG = NCTX + 1                      # the host completes batch k-LAG: NCTX batches stay queued on the GPU
-    NSLOT = LAG + 1
-    REC_CAP = MAX_PTS                   # mainSift.cpp:58-67 capacity (32768 records per frame)
-    packed = [torch.empty((B * REC_CAP * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
-    cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(NSLOT)]
-    done_ev = [None] * NSLOT
-    recv = torch.empty((world * B * REC_CAP * 576,), dtype=torch.uint8, device=device) if (comm and rank == 0) else None
-    rb_stream = torch.cuda.Stream(device=device)     # normal priority: high-priority streams share ONE hardware queue with the
-                                                     # contexts' coarse-level streams (2 contexts: 49 k -> 54 k frames/s)
-    step_ev = []
-
-    def enqueue(k):
-        slot = k % NSLOT
-        b0 = (k % NB) * B
-        ci = k % NCTX
-        capi.check(capi.lib().misift_extract_batch_packed_async(
-            ctxs[ci].h, frames[b0].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0,
-            scratches[ci].data_ptr(),
-            pts.data_ptr() if args.unfused else None,      # merged-octave path writes the packed array directly
-            REC_CAP, cnts[slot].data_ptr(), cnts[slot][B:].data_ptr(), packed[slot].data_ptr()),
-            "misift_extract_batch_packed_async")
-        if comm is not None:
-            comm.gather_post(slot, cnts[slot].data_ptr(), B, packed[slot].data_ptr(), ctx=ctxs[ci])
-        else:
-            ev = torch.cuda.Event()
-            ev.record(ctx_streams[ci])
-            done_ev[slot] = ev
-        e = torch.cuda.Event(enable_timing=True)
-        e.record(ctx_streams[ci])
-        step_ev.append(e)
-
-    def complete(k):
-        slot = k % NSLOT
-        if comm is not None:
-            c, _ = comm.gather_complete(slot, B, 0, recv.data_ptr() if recv is not None else None, world * B * REC_CAP)
-            return c
-        with torch.cuda.stream(rb_stream):                  # count read-back beside the running extraction
-            rb_stream.wait_event(done_ev[slot])
-            c = cnts[slot][:B].cpu().numpy()
-        return c[None, :]
-
-    host_t = {"enqueue": 0.0, "complete": 0.0}
-    trace_host = os.environ.get("BENCH_TRACE") == "1"     # developer aid: where the host spends the pipelined loop
-
-    def run(k0, nsteps):
-        last = None
-        for k in range(k0, k0 + nsteps):
-            ta = time.perf_counter()
-            enqueue(k)
-            tb = time.perf_counter()
-            if k - k0 >= LAG:
-                last = complete(k - LAG)
-            if trace_host:
-                host_t["enqueue"] += tb - ta
-                host_t["complete"] += time.perf_counter() - tb
-            if k - k0 >= LAG:
-                if (last < 0).any():
-                    raise RuntimeError("candidate list overflow in the bench workload")
-        for k in range(max(k0, k0 + nsteps - LAG), k0 + nsteps):
-            last = complete(k)
-        if (last < 0).any():
-            raise RuntimeError("candidate list overflow in the bench workload")
-        return last
+    # Software-pipelined step loop, the same for every N (class StepPipeline above; `--emulate-ranks` drives N of them
+    # from N host threads of this process over the loopback transport)
+    pl = StepPipeline(torch, capi, ctxs, ctx_streams, comm, rank, world, device, frames, B, NB, scratches, pts, args.unfused)
+    LAG, NSLOT, REC_CAP = pl.LAG, pl.NSLOT, pl.REC_CAP
+    packed, cnts, step_ev = pl.packed, pl.cnts, pl.step_ev
+    enqueue, run, host_t, trace_host = pl.enqueue, pl.run, pl.host_t, pl.trace_host
 
     def barrier():
         if comm is not None:

@@ -80,6 +80,10 @@ SIGNATURES = {
     "misift_comm_unique_id": (_i, [_vp]),
     "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "misift_comm_adopt": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "misift_loopback_world_create": (_i, [_i, C.POINTER(_vp)]),
+    "misift_loopback_world_destroy": (None, [_vp]),
+    "misift_comm_create_loopback": (_i, [_vp, _vp, _i, C.POINTER(_vp)]),
+    "misift_gather_test": (_i, [_vp, _i, _ip]),
     "misift_comm_destroy": (None, [_vp]),
     "misift_comm_rank": (_i, [_vp]),
     "misift_comm_size": (_i, [_vp]),
@@ -456,14 +460,33 @@ def comm_unique_id():
     return buf.raw
 
 
+class LoopbackWorld:
+    """misift_loopback_world: the rendezvous object of N in-process communicators (fake N ranks on one GPU)."""
+
+    def __init__(self, nranks):
+        h = C.c_void_p()
+        check(lib().misift_loopback_world_create(nranks, C.byref(h)), "misift_loopback_world_create")
+        self.h, self.size = h, nranks
+
+    def close(self):
+        if self.h:
+            lib().misift_loopback_world_destroy(self.h)
+            self.h = None
+
+
 class Comm:
-    """One RCCL communicator per context (misift_comm_*): the multi-GPU entry points of the C-ABI."""
+    """One communicator per context (misift_comm_*): the multi-GPU entry points of the C-ABI.
+    id_bytes: the 128-byte RCCL id — or a LoopbackWorld for the in-process transport."""
 
     def __init__(self, ctx, nranks, rank, id_bytes):
-        assert len(id_bytes) == COMM_ID_BYTES
         h = C.c_void_p()
-        buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
-        check(lib().misift_comm_create(ctx.h, nranks, rank, C.cast(buf, C.c_void_p), C.byref(h)), "misift_comm_create")
+        if isinstance(id_bytes, LoopbackWorld):
+            assert nranks == id_bytes.size
+            check(lib().misift_comm_create_loopback(ctx.h, id_bytes.h, rank, C.byref(h)), "misift_comm_create_loopback")
+        else:
+            assert len(id_bytes) == COMM_ID_BYTES
+            buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
+            check(lib().misift_comm_create(ctx.h, nranks, rank, C.cast(buf, C.c_void_p), C.byref(h)), "misift_comm_create")
         self.h = h
         self.ctx = ctx
         self.rank, self.size = lib().misift_comm_rank(h), lib().misift_comm_size(h)
@@ -474,6 +497,12 @@ class Comm:
     def gather_post(self, slot, d_counts, nframes, d_packed, ctx=None):
         """ctx: the context (of the communicator's device) whose stream produced the buffers; default = the communicator's own."""
         check(lib().misift_gather_post((ctx or self.ctx).h, self.h, slot, d_counts, nframes, d_packed), "misift_gather_post")
+
+    def gather_test(self, slot):
+        """True once the batch posted in `slot` has finished on the GPU (non-blocking)."""
+        r = C.c_int(0)
+        check(lib().misift_gather_test(self.h, slot, C.byref(r)), "misift_gather_test")
+        return bool(r.value)
 
     def gather_complete(self, slot, nframes, root=0, d_recv=None, capacity_records=0):
         """Returns (all_counts [size, nframes] int32, rank offsets [size+1] in records)."""

@@ -108,8 +108,8 @@ inline Mat operator*(const Mat &a, double s)
 }
 inline Mat operator*(double s, const Mat &a) { return a * s; }
 
-// Solve src1 * dst = src2.  DECOMP_CHOLESKY: symmetric positive definite src1; returns false
-// (dst untouched) when the matrix is not positive definite, like OpenCV.
+// Solve src1 * dst = src2.  DECOMP_CHOLESKY: symmetric positive definite src1; when the matrix is not positive
+// definite it returns false and ZEROES dst, like OpenCV (cv::solve: `if (!result) dst = Scalar(0);`).
 inline bool solve(const Mat &src1, const Mat &src2, Mat &dst, int flags = DECOMP_LU)
 {
   const int n = src1.rows, m = src2.cols;
@@ -122,7 +122,11 @@ inline bool solve(const Mat &src1, const Mat &src2, Mat &dst, int flags = DECOMP
         double s = A[(size_t)i * n + j];
         for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
         if (i == j) {
-          if (!(s > 0)) return false;
+          if (!(s > 0)) {
+            Mat zero(n, m, src2.type() == CV_32F ? CV_32F : CV_64F);     // create() zero-fills
+            dst = zero;
+            return false;
+          }
           A[(size_t)i * n + i] = std::sqrt(s);
         } else {
           A[(size_t)i * n + j] = s / A[(size_t)j * n + j];

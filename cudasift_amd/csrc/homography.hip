@@ -413,6 +413,8 @@ __global__ __launch_bounds__(64) void improve_homography_kernel(ImproveArgs P, S
           B[i] = s / L[i * 8 + i];
         }
         for (int k = 0; k < 8; k++) s_A[k] = B[k];
+      } else {
+        for (int k = 0; k < 8; k++) s_A[k] = 0.0;       // cv::solve zeroes the solution when the factorisation fails
       }
     }
     __syncthreads();

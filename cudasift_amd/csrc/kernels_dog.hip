@@ -797,7 +797,7 @@ __device__ __forceinline__ void dog_patch(const float *img, int w, int h, int pi
 __device__ __forceinline__ float det_exp2(float x)
 {
   const bool tiny = x < -125.0f;
-  x = fminf(x, 126.0f);
+  x = x > 126.0f ? 126.0f : x;         // not fminf: a NaN exponent (singular Hessian) must stay NaN and be rejected, like exp2f
   x = tiny ? 0.0f : x;
   const float n = rintf(x);
   const float r = x - n;

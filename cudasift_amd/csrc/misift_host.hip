@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <mutex>
 #include <vector>
 #include "common.hpp"
 
@@ -44,9 +45,8 @@ extern "C" const char *misift_last_error(void) { return g_err; }
 static int (*g_roctx_push)(const char *) = nullptr;
 static int (*g_roctx_pop)(void) = nullptr;
 static int g_roctx_state = 0;          // 0 = untried, 1 = bound, -1 = off
-static void roctx_bind(void)
+static void roctx_bind_once(void)
 {
-  if (g_roctx_state) return;
   g_roctx_state = -1;
   const char *names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
   const char *env = getenv("MISIFT_ROCTX");
@@ -62,6 +62,11 @@ static void roctx_bind(void)
   *(void **)(&g_roctx_pop) = dlsym(h, "roctxRangePop");
   if (g_roctx_push && g_roctx_pop) g_roctx_state = 1;
 }
+static void roctx_bind(void)
+{
+  static std::once_flag once;          // contexts are created from several host threads (one per device)
+  std::call_once(once, roctx_bind_once);
+}
 struct RoctxRange {
   bool on;
   explicit RoctxRange(const char *name) : on(g_roctx_state > 0) { if (on) g_roctx_push(name); }
@@ -74,7 +79,7 @@ struct PendingProf { int slot; hipEvent_t a, b; };
 // 1000 times, mainSift.cpp:64-69; a tracker calls with the same buffers every frame) replays a captured hipGraph.
 struct CallKey {
   const void *imgs; float *scratch; void *pts;
-  int src_u8, nframes, width, height, pitch, num_octaves, scale_up, max_pts, fused, texfrac, fixnum, alloc_gen;
+  int src_u8, nframes, width, height, pitch, num_octaves, scale_up, max_pts, fused, texfrac, fixnum, determ, alloc_gen;
   long long frame_stride;
   float init_blur, thresh, lowest_scale;
   // field by field: the struct has padding, and plain assignment need not preserve padding bytes
@@ -83,7 +88,7 @@ struct CallKey {
     return imgs == o.imgs && scratch == o.scratch && pts == o.pts && src_u8 == o.src_u8 && nframes == o.nframes &&
            width == o.width && height == o.height && pitch == o.pitch && num_octaves == o.num_octaves &&
            scale_up == o.scale_up && max_pts == o.max_pts && fused == o.fused && texfrac == o.texfrac &&
-           fixnum == o.fixnum && alloc_gen == o.alloc_gen && frame_stride == o.frame_stride &&
+           fixnum == o.fixnum && determ == o.determ && alloc_gen == o.alloc_gen && frame_stride == o.frame_stride &&
            init_blur == o.init_blur && thresh == o.thresh && lowest_scale == o.lowest_scale;
   }
 };
@@ -171,28 +176,31 @@ static CtxExtra *extra(misift_ctx *ctx) { return &reinterpret_cast<CtxFull *>(ct
 // MISIFT_DEVICES="2,3" (SURVEY section 5): device i of this library = HIP device list[i], the others do not exist for
 // it — like HIP_VISIBLE_DEVICES but for libmisift.so only (a process that shares the GPUs with another runtime keeps
 // its own numbering).  Unset or empty: every HIP device, identity.  Read once.
+static std::vector<int> build_device_map(void)
+{
+  std::vector<int> m;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  const char *e = getenv("MISIFT_DEVICES");
+  if (e && *e) {
+    for (const char *p = e; *p;) {
+      char *end = nullptr;
+      const long d = strtol(p, &end, 10);
+      if (end == p) break;
+      if (d >= 0 && d < n) m.push_back((int)d);
+      p = (*end == ',') ? end + 1 : end;
+      if (*end && *end != ',') break;
+    }
+  } else {
+    for (int i = 0; i < n; i++) m.push_back(i);
+  }
+  return m;
+}
 static const std::vector<int> &device_map(void)
 {
-  static std::vector<int> m;
-  static bool init = false;
-  if (!init) {
-    init = true;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
-    const char *e = getenv("MISIFT_DEVICES");
-    if (e && *e) {
-      for (const char *p = e; *p;) {
-        char *end = nullptr;
-        const long d = strtol(p, &end, 10);
-        if (end == p) break;
-        if (d >= 0 && d < n) m.push_back((int)d);
-        p = (*end == ',') ? end + 1 : end;
-        if (*end && *end != ',') break;
-      }
-    } else {
-      for (int i = 0; i < n; i++) m.push_back(i);
-    }
-  }
+  // C++11 magic static: built exactly once even when several host threads create their contexts at the same time
+  // (one thread per device is how the multi-GPU entry points are meant to be driven)
+  static const std::vector<int> m = build_device_map();
   return m;
 }
 static int physical_device(int logical)
@@ -985,7 +993,7 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
       key.imgs = d_imgs; key.scratch = d_scratch; key.pts = pts;
       key.src_u8 = src_u8; key.nframes = nframes; key.width = width; key.height = height; key.pitch = pitch;
       key.num_octaves = num_octaves; key.scale_up = scale_up; key.max_pts = max_pts; key.fused = ctx->opt.fused;
-      key.texfrac = ctx->opt.texfrac_bits; key.fixnum = ctx->opt.fix_numpts; key.alloc_gen = ctx->alloc_gen;
+      key.texfrac = ctx->opt.texfrac_bits; key.fixnum = ctx->opt.fix_numpts; key.determ = ctx->opt.deterministic; key.alloc_gen = ctx->alloc_gen;
       key.frame_stride = frame_stride; key.init_blur = init_blur; key.thresh = thresh; key.lowest_scale = lowest_scale;
       queued = enqueue_via_graph(ctx, key, d_imgs, frame_stride, d_scratch, pts);
     }

@@ -12,10 +12,21 @@
 // loads it, and inside a process that already holds an RCCL (PyTorch ships its own librccl.so) that copy is
 // reused instead of loading a second one.  xGMI is point to point (7 links per GPU): the variable-length
 // gather is ONE message per sender (7 senders -> 7 distinct links into the root), never a ring of padded blocks.
+//
+// Transports.  Everything above the five primitives {all-gather, group start / send / recv / group end} — count
+// staging, per-rank record counts and offsets, root placement, the -1 frames, the collective ENOMEM decision, the
+// set-2 placement and the result all-gather of the sharded matcher — is ONE code path over a transport table with two
+// implementations: RCCL (production) and an in-process LOOPBACK WORLD (misift_comm_create_loopback): N communicators
+// owned by N host threads, normally on ONE device, exchanging through a shared rendezvous object with device-to-device
+// copies.  The loopback world exists so that the N > 1 branches run on the hardware a developer has (SURVEY section 4:
+// "fake N ranks on one GPU"); it is functional, never a scaling measurement.
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 #include <rccl/rccl.h>      // types and prototypes only; every call goes through the table below
 #include "common.hpp"
@@ -38,8 +49,10 @@ struct RcclApi {
 static RcclApi g_rccl;
 static int g_rccl_state = 0;      // 0 = untried, 1 = bound, -1 = unavailable
 
+static std::mutex g_rccl_mutex;      // communicators are created from several host threads (one per device)
 static int rccl_bind(void)
 {
+  std::lock_guard<std::mutex> lk(g_rccl_mutex);
   if (g_rccl_state) return g_rccl_state > 0 ? MISIFT_OK : MISIFT_ENODEV;
   void *h = nullptr;
   // an RCCL already mapped into the process wins (PyTorch's own copy has the soname librccl.so)
@@ -105,10 +118,25 @@ struct GatherSlot {
   bool posted;
 };
 
+struct misift_comm;
+// stream-ordered like NCCL: an operation is complete for the caller once `stream` has drained
+struct Transport {
+  int (*allgather)(misift_comm *, const void *send, void *recv, size_t bytes_per_rank, hipStream_t stream);
+  int (*group_start)(misift_comm *);
+  int (*send)(misift_comm *, const void *buf, size_t bytes, int peer, hipStream_t stream);
+  int (*recv)(misift_comm *, void *buf, size_t bytes, int peer, hipStream_t stream);
+  int (*group_end)(misift_comm *, hipStream_t stream);
+};
+
+struct PendingP2P { bool is_send; void *buf; size_t bytes; int peer; };
+
 struct misift_comm {
   misift_ctx *ctx;
-  ncclComm_t nccl;
+  const Transport *tp;
+  ncclComm_t nccl;              // RCCL transport
   bool owns_nccl;
+  misift_loopback_world *world; // loopback transport
+  std::vector<PendingP2P> pending;
   int rank, nranks;
   hipStream_t stream;           // communication stream: high priority, beside the extraction on the context stream
   int *d_all_counts;            // [nranks][cap_frames] staging of the count all-gather
@@ -117,7 +145,185 @@ struct misift_comm {
   std::vector<GatherSlot> slots;
 };
 
+// ---- RCCL transport
+static int rccl_allgather(misift_comm *c, const void *send, void *recv, size_t bytes, hipStream_t st)
+{
+  NCCL_TRY(g_rccl.AllGather(send, recv, bytes, ncclUint8, c->nccl, st));
+  return MISIFT_OK;
+}
+static int rccl_group_start(misift_comm *) { NCCL_TRY(g_rccl.GroupStart()); return MISIFT_OK; }
+static int rccl_send(misift_comm *c, const void *buf, size_t bytes, int peer, hipStream_t st)
+{
+  NCCL_TRY(g_rccl.Send(buf, bytes, ncclUint8, peer, c->nccl, st));
+  return MISIFT_OK;
+}
+static int rccl_recv(misift_comm *c, void *buf, size_t bytes, int peer, hipStream_t st)
+{
+  NCCL_TRY(g_rccl.Recv(buf, bytes, ncclUint8, peer, c->nccl, st));
+  return MISIFT_OK;
+}
+static int rccl_group_end(misift_comm *, hipStream_t) { NCCL_TRY(g_rccl.GroupEnd()); return MISIFT_OK; }
+static const Transport kRcclTransport = {rccl_allgather, rccl_group_start, rccl_send, rccl_recv, rccl_group_end};
 
+// ---- loopback transport: a rendezvous object shared by the N communicators of one process
+struct misift_loopback_world {
+  int nranks;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;                       // reusable barrier
+  unsigned long long generation = 0;
+  bool failed = false;                   // a rank gave up (timeout / size mismatch): everybody fails fast
+  std::vector<const void *> ag_send;     // all-gather deposits, valid between the two barriers of one operation
+  std::vector<size_t> ag_bytes;
+  struct Msg { const void *buf; size_t bytes; bool posted; };
+  std::vector<Msg> box;                  // point-to-point mailboxes [src * nranks + dst]
+  std::vector<char> attached;
+  double timeout_s = 60.0;
+};
+
+static bool lw_wait(misift_loopback_world *w, std::unique_lock<std::mutex> &lk, const char *what, bool (*pred)(void *), void *arg)
+{
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(w->timeout_s);
+  while (!pred(arg) && !w->failed) {
+    if (w->cv.wait_until(lk, deadline) == std::cv_status::timeout && !pred(arg)) {
+      w->failed = true;
+      w->cv.notify_all();
+      misift_set_error("loopback world: rank timed out in %s (a rank never made the matching call)", what);
+      return false;
+    }
+  }
+  if (w->failed) { misift_set_error("loopback world: a peer failed during %s", what); return false; }
+  return true;
+}
+
+static int lw_barrier(misift_loopback_world *w, const char *what)
+{
+  std::unique_lock<std::mutex> lk(w->m);
+  if (w->failed) { misift_set_error("loopback world: a peer failed before %s", what); return MISIFT_EHIP; }
+  struct A { misift_loopback_world *w; unsigned long long g; } a = {w, w->generation};
+  if (++w->arrived == w->nranks) {
+    w->arrived = 0;
+    w->generation++;
+    w->cv.notify_all();
+    return MISIFT_OK;
+  }
+  return lw_wait(w, lk, what, [](void *p) { A *x = (A *)p; return x->w->generation != x->g; }, &a) ? MISIFT_OK : MISIFT_EHIP;
+}
+
+static int loop_allgather(misift_comm *c, const void *send, void *recv, size_t bytes, hipStream_t st)
+{
+  misift_loopback_world *w = c->world;
+  HIP_TRY(hipStreamSynchronize(st));                 // my contribution is complete, my receive buffer is free
+  {
+    std::lock_guard<std::mutex> lk(w->m);
+    w->ag_send[c->rank] = send;
+    w->ag_bytes[c->rank] = bytes;
+  }
+  int rc = lw_barrier(w, "all-gather (deposit)");
+  if (rc) return rc;
+  for (int r = 0; r < c->nranks; r++) {
+    if (w->ag_bytes[r] != bytes) {
+      misift_set_error("loopback all-gather: rank %d contributes %zu bytes, rank %d %zu", r, w->ag_bytes[r], c->rank, bytes);
+      std::lock_guard<std::mutex> lk(w->m);
+      w->failed = true;
+      w->cv.notify_all();
+      return MISIFT_EINVAL;
+    }
+    char *dst = (char *)recv + (size_t)r * bytes;
+    if (bytes && dst != (const char *)w->ag_send[r])       // in-place contribution of this rank: nothing to move
+      HIP_TRY(hipMemcpyAsync(dst, w->ag_send[r], bytes, hipMemcpyDefault, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return lw_barrier(w, "all-gather (release)");      // nobody's send buffer is reused before everybody has read it
+}
+
+static int loop_group_start(misift_comm *c) { c->pending.clear(); return MISIFT_OK; }
+static int loop_send(misift_comm *c, const void *buf, size_t bytes, int peer, hipStream_t)
+{
+  c->pending.push_back({true, (void *)buf, bytes, peer});
+  return MISIFT_OK;
+}
+static int loop_recv(misift_comm *c, void *buf, size_t bytes, int peer, hipStream_t)
+{
+  c->pending.push_back({false, buf, bytes, peer});
+  return MISIFT_OK;
+}
+static int loop_group_end(misift_comm *c, hipStream_t st)
+{
+  misift_loopback_world *w = c->world;
+  const int n = c->nranks;
+  HIP_TRY(hipStreamSynchronize(st));                 // what I send is complete
+  {
+    std::lock_guard<std::mutex> lk(w->m);
+    for (const PendingP2P &p : c->pending)
+      if (p.is_send) w->box[(size_t)c->rank * n + p.peer] = {p.buf, p.bytes, true};
+    w->cv.notify_all();
+  }
+  for (const PendingP2P &p : c->pending) {
+    if (p.is_send) continue;
+    misift_loopback_world::Msg msg;
+    {
+      std::unique_lock<std::mutex> lk(w->m);
+      struct A { misift_loopback_world *w; size_t i; } a = {w, (size_t)p.peer * n + c->rank};
+      if (!lw_wait(w, lk, "recv", [](void *q) { A *x = (A *)q; return x->w->box[x->i].posted; }, &a)) return MISIFT_EHIP;
+      msg = w->box[a.i];
+    }
+    if (msg.bytes != p.bytes) {                      // the offset arithmetic of the two sides disagrees
+      misift_set_error("loopback recv: rank %d expects %zu bytes from rank %d, which sends %zu", c->rank, p.bytes, p.peer, msg.bytes);
+      std::lock_guard<std::mutex> lk(w->m);
+      w->failed = true;
+      w->cv.notify_all();
+      return MISIFT_EINVAL;
+    }
+    if (p.bytes) HIP_TRY(hipMemcpyAsync(p.buf, msg.buf, p.bytes, hipMemcpyDefault, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  {
+    std::unique_lock<std::mutex> lk(w->m);
+    for (const PendingP2P &p : c->pending)           // consumed: the sender may reuse its buffer
+      if (!p.is_send) w->box[(size_t)p.peer * n + c->rank].posted = false;
+    w->cv.notify_all();
+    for (const PendingP2P &p : c->pending) {
+      if (!p.is_send) continue;
+      struct A { misift_loopback_world *w; size_t i; } a = {w, (size_t)c->rank * n + p.peer};
+      if (!lw_wait(w, lk, "send", [](void *q) { A *x = (A *)q; return !x->w->box[x->i].posted; }, &a)) return MISIFT_EHIP;
+    }
+  }
+  c->pending.clear();
+  return MISIFT_OK;
+}
+static const Transport kLoopbackTransport = {loop_allgather, loop_group_start, loop_send, loop_recv, loop_group_end};
+
+extern "C" int misift_loopback_world_create(int nranks, misift_loopback_world **out)
+{
+  MG_CHECK(out && nranks >= 1 && nranks <= 64);
+  misift_loopback_world *w = new misift_loopback_world();
+  w->nranks = nranks;
+  w->ag_send.assign((size_t)nranks, nullptr);
+  w->ag_bytes.assign((size_t)nranks, 0);
+  w->box.assign((size_t)nranks * nranks, {nullptr, 0, false});
+  w->attached.assign((size_t)nranks, 0);
+  if (const char *e = getenv("MISIFT_LOOPBACK_TIMEOUT_S")) w->timeout_s = atof(e) > 0 ? atof(e) : w->timeout_s;
+  *out = w;
+  return MISIFT_OK;
+}
+
+extern "C" void misift_loopback_world_destroy(misift_loopback_world *w) { delete w; }
+
+// Streams of one process share HIP's hardware queues (4 by default): the communication stream then queues behind
+// the extraction stream's kernels and a pipelined gather loses ~20 %.  Say so once.
+static void warn_hw_queues(const char *who)
+{
+  static bool said = false;
+  if (said) return;
+  const char *e = getenv("GPU_MAX_HW_QUEUES");
+  if (e && atoi(e) >= 8) return;
+  said = true;
+  misift_set_error("%s: GPU_MAX_HW_QUEUES is %s; with fewer than 8 hardware queues the communication / copy streams share "
+                   "a queue with the extraction stream (set GPU_MAX_HW_QUEUES=8 before the first HIP call)", who,
+                   e ? e : "unset (HIP default: 4)");
+  if (!getenv("MISIFT_QUIET")) fprintf(stderr, "misift: warning: %s\n", misift_last_error());
+}
 
 extern "C" int misift_comm_unique_id(void *id128)
 {
@@ -131,17 +337,25 @@ extern "C" int misift_comm_unique_id(void *id128)
   return MISIFT_OK;
 }
 
-static int comm_finish_create(misift_ctx *ctx, ncclComm_t nc, bool owns, misift_comm **out)
+static int comm_finish_create(misift_ctx *ctx, ncclComm_t nc, bool owns, misift_loopback_world *world, int world_rank,
+                              misift_comm **out)
 {
   misift_comm *c = new misift_comm();
-  c->ctx = ctx; c->nccl = nc; c->owns_nccl = owns;
+  c->ctx = ctx; c->nccl = nc; c->owns_nccl = owns; c->world = world;
+  c->tp = world ? &kLoopbackTransport : &kRcclTransport;
   c->rank = 0; c->nranks = 1; c->stream = nullptr;
   c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0;
   c->slots.resize(MISIFT_GATHER_SLOTS);
   for (GatherSlot &s : c->slots) { memset(&s, 0, sizeof(s)); }
   *out = c;                                           // from here on misift_comm_destroy cleans up after a failure
-  NCCL_TRY(g_rccl.CommCount(nc, &c->nranks));
-  NCCL_TRY(g_rccl.CommUserRank(nc, &c->rank));
+  if (world) {
+    c->nranks = world->nranks;
+    c->rank = world_rank;
+  } else {
+    NCCL_TRY(g_rccl.CommCount(nc, &c->nranks));
+    NCCL_TRY(g_rccl.CommUserRank(nc, &c->rank));
+  }
+  warn_hw_queues("misift_comm_create");
   int lo = 0, hi = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
@@ -155,6 +369,10 @@ extern "C" void misift_comm_destroy(misift_comm *c)
   if (c->ctx) hipSetDevice(c->ctx->device);
   if (c->stream) { hipStreamSynchronize(c->stream); }
   if (c->nccl && c->owns_nccl && g_rccl_state > 0) g_rccl.CommDestroy(c->nccl);
+  if (c->world) {
+    std::lock_guard<std::mutex> lk(c->world->m);
+    c->world->attached[c->rank] = 0;
+  }
   if (c->stream) hipStreamDestroy(c->stream);
   for (GatherSlot &s : c->slots)
     if (s.ready) hipEventDestroy(s.ready);
@@ -174,7 +392,7 @@ extern "C" int misift_comm_create(misift_ctx *ctx, int nranks, int rank, const v
   memcpy(&id, id128, sizeof(id));
   ncclComm_t nc = nullptr;
   NCCL_TRY(g_rccl.CommInitRank(&nc, nranks, id, rank));
-  rc = comm_finish_create(ctx, nc, true, out);
+  rc = comm_finish_create(ctx, nc, true, nullptr, 0, out);
   if (rc) { misift_comm_destroy(*out); *out = nullptr; }
   return rc;
 }
@@ -186,7 +404,22 @@ extern "C" int misift_comm_adopt(misift_ctx *ctx, void *nccl_comm, misift_comm *
   int rc = rccl_bind();
   if (rc) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
-  rc = comm_finish_create(ctx, (ncclComm_t)nccl_comm, false, out);
+  rc = comm_finish_create(ctx, (ncclComm_t)nccl_comm, false, nullptr, 0, out);
+  if (rc) { misift_comm_destroy(*out); *out = nullptr; }
+  return rc;
+}
+
+extern "C" int misift_comm_create_loopback(misift_ctx *ctx, misift_loopback_world *world, int rank, misift_comm **out)
+{
+  MG_CHECK(ctx && world && out && rank >= 0 && rank < world->nranks);
+  *out = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(world->m);
+    MG_CHECK(!world->attached[rank]);
+    world->attached[rank] = 1;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = comm_finish_create(ctx, nullptr, false, world, rank, out);
   if (rc) { misift_comm_destroy(*out); *out = nullptr; }
   return rc;
 }
@@ -206,7 +439,8 @@ extern "C" int misift_comm_barrier(misift_comm *c)
     HIP_TRY(hipMemsetAsync(c->d_all_counts, 0, sizeof(int) * (size_t)c->nranks * 64, c->stream));
     c->cap_frames = 64;
   }
-  NCCL_TRY(g_rccl.AllGather(c->d_all_counts + c->rank, c->d_all_counts, 1, ncclInt32, c->nccl, c->stream));
+  int rc = c->tp->allgather(c, c->d_all_counts + c->rank, c->d_all_counts, sizeof(int), c->stream);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return MISIFT_OK;
 }
@@ -223,6 +457,22 @@ extern "C" int misift_gather_post(misift_ctx *ctx, misift_comm *c, int slot, con
   HIP_TRY(hipEventRecord(s.ready, ctx->stream));      // the batch queued so far on the context stream produces these buffers
   s.posted = true;
   return MISIFT_OK;
+}
+
+// Non-blocking companion of misift_gather_complete: *ready = 1 once the posted batch has finished on the GPU, i.e.
+// once misift_gather_complete would only wait for the exchange itself (microseconds of counts + one message), not
+// for the extraction kernels queued before the post.  A C++ caller polls this instead of parking a thread.
+extern "C" int misift_gather_test(misift_comm *c, int slot, int *ready)
+{
+  MG_CHECK(c && ready && slot >= 0 && slot < (int)c->slots.size());
+  GatherSlot &s = c->slots[slot];
+  MG_CHECK(s.posted);
+  HIP_TRY(hipSetDevice(c->ctx->device));
+  const hipError_t e = hipEventQuery(s.ready);
+  if (e == hipSuccess) { *ready = 1; return MISIFT_OK; }
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); *ready = 0; return MISIFT_OK; }
+  misift_set_error("misift_gather_test: hipEventQuery failed: %s", hipGetErrorString(e));
+  return MISIFT_EHIP;
 }
 
 extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h_all_counts, void *d_recv,
@@ -247,8 +497,10 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
   // 1. per-frame counts of every rank (nframes ints per rank; every rank must post the same nframes)
   if (nr == 1)           // nothing to gather: a plain copy
     HIP_TRY(hipMemcpyAsync(c->d_all_counts, s.d_counts, sizeof(int) * (size_t)nf, hipMemcpyDeviceToDevice, c->stream));
-  else
-    NCCL_TRY(g_rccl.AllGather(s.d_counts, c->d_all_counts, (size_t)nf, ncclInt32, c->nccl, c->stream));
+  else {
+    int rc = c->tp->allgather(c, s.d_counts, c->d_all_counts, sizeof(int) * (size_t)nf, c->stream);
+    if (rc) { s.posted = false; return rc; }
+  }
   HIP_TRY(hipMemcpyAsync(c->h_all_counts, c->d_all_counts, sizeof(int) * (size_t)nr * nf, hipMemcpyDeviceToHost,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));          // the message sizes must be known on the host (NCCL API)
@@ -270,17 +522,18 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
     return MISIFT_ENOMEM;
   }
   // 2. ONE point-to-point message per sender with exactly its valid bytes (xGMI: distinct links into the root)
-  NCCL_TRY(g_rccl.GroupStart());
+  int rc = c->tp->group_start(c);
   if (c->rank == root) {
-    for (int r = 0; r < nr; r++) {
+    for (int r = 0; r < nr && !rc; r++) {
       if (r == root || nrec[r] == 0) continue;
-      NCCL_TRY(g_rccl.Recv((char *)d_recv + off[r] * sizeof(SiftPointD), nrec[r] * sizeof(SiftPointD), ncclUint8, r,
-                           c->nccl, c->stream));
+      rc = c->tp->recv(c, (char *)d_recv + off[r] * sizeof(SiftPointD), nrec[r] * sizeof(SiftPointD), r, c->stream);
     }
-  } else if (nrec[c->rank]) {
-    NCCL_TRY(g_rccl.Send(s.d_packed, nrec[c->rank] * sizeof(SiftPointD), ncclUint8, root, c->nccl, c->stream));
+  } else if (nrec[c->rank] && !rc) {
+    rc = c->tp->send(c, s.d_packed, nrec[c->rank] * sizeof(SiftPointD), root, c->stream);
   }
-  NCCL_TRY(g_rccl.GroupEnd());
+  // a failure inside the group must still close it: an open NCCL group swallows every later collective of this thread
+  const int rc_end = c->tp->group_end(c, c->stream);
+  if (rc || rc_end) { s.posted = false; return rc ? rc : rc_end; }
   if (c->rank == root && d_recv && nrec[root])
     HIP_TRY(hipMemcpyAsync((char *)d_recv + off[root] * sizeof(SiftPointD), s.d_packed, nrec[root] * sizeof(SiftPointD),
                            hipMemcpyDeviceToDevice, c->stream));
@@ -315,9 +568,10 @@ extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_row
   MG_CHECK(n2 < (1ll << 31));
   // 1. replicate set 2: all-gather of the record shards (576 B x shard_count per rank; 57.6 MB at 100k) on the context
   //    stream — it must precede the sweep, there is nothing to overlap it with
-  if (shard_count)
-    NCCL_TRY(g_rccl.AllGather(d_shard2, d_set2_all, (size_t)shard_count * sizeof(SiftPointD), ncclUint8, c->nccl,
-                              ctx->stream));
+  if (shard_count) {
+    int rc = c->tp->allgather(c, d_shard2, d_set2_all, (size_t)shard_count * sizeof(SiftPointD), ctx->stream);
+    if (rc) return rc;
+  }
   // 2. this rank's rows against all of set 2 (fp32 MFMA sweep, same kernel as misift_match)
   if (row_count && n2) {
     int rc = launch_match(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2);
@@ -330,7 +584,8 @@ extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_row
     hipLaunchKernelGGL(pack_match_results_kernel, dim3((row_count + 255) / 256), dim3(256), 0, ctx->stream,
                        (const SiftPointD *)d_rows1, row_count, mine);
     HIP_TRY(hipGetLastError());
-    NCCL_TRY(g_rccl.AllGather(mine, all, (size_t)row_count * sizeof(MatchResult), ncclUint8, c->nccl, ctx->stream));
+    int rc = c->tp->allgather(c, mine, all, (size_t)row_count * sizeof(MatchResult), ctx->stream);
+    if (rc) return rc;
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));         // matching.cu:1191: MatchSiftData returns with the results in place
   return MISIFT_OK;

@@ -295,6 +295,17 @@ typedef struct misift_comm misift_comm;
 int misift_comm_unique_id(void *id128);
 int misift_comm_create(misift_ctx *ctx, int nranks, int rank, const void *id128, misift_comm **out);
 int misift_comm_adopt(misift_ctx *ctx, void *nccl_comm, misift_comm **out);
+/* In-process LOOPBACK WORLD ("fake N ranks on one GPU").  The reference has no multi-device code at
+ * all (cudaSiftH.cu:19-37 picks one device), so nothing in it corresponds to this; it exists so that every N > 1
+ * branch behind misift_gather_* / misift_match_sharded runs on the hardware a developer has: N communicators, one host
+ * thread each, normally N contexts of ONE device, exchanging through a shared rendezvous object with device-to-device
+ * copies instead of RCCL.  Same entry points, same code above the transport; functional only, never a scaling number.
+ * A rank that never makes the matching call makes its peers fail with an error after MISIFT_LOOPBACK_TIMEOUT_S (60)
+ * seconds instead of hanging; mismatching message sizes between the two sides of a send/recv are an error. */
+typedef struct misift_loopback_world misift_loopback_world;
+int misift_loopback_world_create(int nranks, misift_loopback_world **out);
+void misift_loopback_world_destroy(misift_loopback_world *world);    /* after all its communicators */
+int misift_comm_create_loopback(misift_ctx *ctx, misift_loopback_world *world, int rank, misift_comm **out);
 void misift_comm_destroy(misift_comm *comm);
 int misift_comm_rank(const misift_comm *comm);
 int misift_comm_size(const misift_comm *comm);
@@ -321,6 +332,10 @@ int misift_gather_post(misift_ctx *ctx, misift_comm *comm, int slot, const int *
                        const void *d_packed);
 int misift_gather_complete(misift_comm *comm, int slot, int root, int *h_all_counts, void *d_recv,
                            size_t capacity_records, size_t *h_rank_offsets);
+/* Non-blocking: *ready = 1 once the batch posted in `slot` has finished on the GPU (misift_gather_complete then only
+ * waits for the exchange itself), 0 while its kernels are still running.  Lets a caller poll instead of parking a
+ * thread in misift_gather_complete. */
+int misift_gather_test(misift_comm *comm, int slot, int *ready);
 
 /* BASELINE config 5 — MatchSiftData (matching.cu:1090-1206) with set 1 split into row blocks, one per rank.
  * d_rows1: this rank's row block (row_count records, updated in place like misift_match); d_shard2: this rank's

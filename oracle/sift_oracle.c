@@ -1209,7 +1209,7 @@ int orc_find_homography(const SiftPoint *pts, int numPts, float *homography, int
  * Iterative least-squares refinement of a homography over the stored matches, geomFuncs.cpp:6-72: numLoops times,
  * accumulate the 8x8 normal equations over the points that pass the score / ambiguity gates AND currently reproject
  * within `thresh` (weight 1, else 0), solve by Cholesky (cv::solve DECOMP_CHOLESKY; a matrix that is not positive
- * definite leaves the estimate unchanged); finally write match_error = sqrt(err) for every point and return the
+ * definite ZEROES the estimate, as OpenCV's solve does); finally write match_error = sqrt(err) for every point and return the
  * number with err < thresh^2.  Types as in the reference: the estimate A and the sums are double, the point fields
  * float; `den`, `dx`, `dy`, `err` are float variables assigned from double expressions; the products
  * -xpos*match_xpos etc. are float products stored in double (geomFuncs.cpp:38-39, :49-50). */
@@ -1223,7 +1223,10 @@ static int cholesky_solve8(const double *Min, const double *Xin, double *out)
       double s = A[i * 8 + j];
       for (int k = 0; k < j; k++) s -= A[i * 8 + k] * A[j * 8 + k];
       if (i == j) {
-        if (!(s > 0)) return 0;
+        if (!(s > 0)) {                     /* cv::solve zeroes the solution when the factorisation fails */
+          memset(out, 0, sizeof(B));
+          return 0;
+        }
         A[i * 8 + i] = sqrt(s);
       } else {
         A[i * 8 + j] = s / A[j * 8 + j];
@@ -1275,7 +1278,7 @@ int orc_improve_homography(SiftPoint *pts, int numPts, float *homography, int nu
         for (int r = 0; r < 8; r++) M[r * 8 + c] += (Y[c] * Y[r] * wei);
       for (int r = 0; r < 8; r++) X[r] += Y[r] * pt->match_ypos * wei;
     }
-    cholesky_solve8(M, X, A);                        /* not positive definite: A stays (cv::solve returns false) */
+    cholesky_solve8(M, X, A);                        /* not positive definite: A = 0 (cv::solve returns false, dst zeroed) */
   }
   int numfit = 0;
   for (int i = 0; i < numPts; i++) {

@@ -148,3 +148,173 @@ def test_comm_two_devices_threads(ctx):
     assert len(out) == world
     _check(capi, ctx, world, out, _frames_of, 4096)
     record("comm_two_devices", ok=True)
+
+
+# ------------------------------------------------------------------------------------------- loopback world
+# the N > 1 branches of multigpu.hip (count all-gather, per-rank record counts and offsets, root
+# placement, grouped send/recv, -1 frames, the collective ENOMEM decision, set-2 placement, result all-gather) executed on
+# ONE GPU: N host threads, N contexts of device 0, N communicators of a misift_loopback_world.  Same entry points and
+# the same code above the transport table as with RCCL.
+def _loop_rank(capi, rank, world, lw, plan, out, errs):
+    """plan: dict(root, mp, frames(rank, k) -> [B,h,w], thresh(rank, k), nbatches, capacity)"""
+    try:
+        c = capi.Context(0)
+        comm = capi.Comm(c, world, rank, lw)
+        assert comm.rank == rank and comm.size == world
+        root, mp, nb = plan["root"], plan["mp"], plan["nbatches"]
+        keep, results, nslot = [], [], 2
+        B = plan["frames"](0, 0).shape[0]
+        cap = plan["capacity"]
+
+        def extract(k):
+            fr = plan["frames"](rank, k)
+            h, w = fr.shape[1:]
+            d = c.upload(fr)
+            sc = capi.DevBuf(4 * capi.scratch_floats(w, h, 5, False) * B)
+            cnt = c.zeros(4 * (2 * B + 1))
+            packed = c.zeros(576 * mp * B)
+            capi.check(capi.lib().misift_extract_batch_packed_async(c.h, d.ptr, B, h * w, w, h, w, 5, 1.0, plan["thresh"](rank, k),
+                                                                    0.0, sc.ptr, None, mp, cnt.ptr, cnt.ptr + 4 * B, packed.ptr),
+                       "misift_extract_batch_packed_async")
+            keep.extend([d, sc, cnt, packed])
+            return cnt, packed
+
+        def complete(k):
+            recv = c.zeros(576 * cap) if rank == root else None
+            polls = 0
+            while not comm.gather_test(k % nslot):          # the non-blocking companion: poll instead of parking
+                polls += 1
+            counts, offs = comm.gather_complete(k % nslot, B, root, recv.ptr if recv else None, cap)
+            recs = c.download(recv, (int(offs[-1]),), capi.POINT_DTYPE) if rank == root else None
+            results.append((k, counts, offs, recs))
+
+        for k in range(nb):                                  # post(k) ... complete(k-1): two batches in flight
+            cnt, packed = extract(k)
+            comm.gather_post(k % nslot, cnt.ptr, B, packed.ptr)
+            if k >= 1:
+                complete(k - 1)
+        complete(nb - 1)
+        comm.barrier()
+        # too little room on the root: every rank takes the same decision, nothing is exchanged, nobody hangs
+        cnt, packed = extract(0)
+        comm.gather_post(0, cnt.ptr, B, packed.ptr)
+        try:
+            comm.gather_complete(0, B, root, c.zeros(576 * 8).ptr if rank == root else None, 7)
+            raise AssertionError("capacity overflow not reported")
+        except RuntimeError as e:
+            assert "room for 7" in str(e), e
+        comm.barrier()
+        # matcher: row blocks of set 1, shards of set 2 (shard size deliberately not a multiple of 32)
+        rows, shard = plan["rows"], plan["shard"]
+        n1, n2 = rows * world, shard * world
+        p1 = descriptors_to_points(synth_descriptors(n1, 31), capi.POINT_DTYPE)
+        p2 = descriptors_to_points(synth_descriptors(n2, 32), capi.POINT_DTYPE)
+        d1 = c.upload(p1[rank * rows:(rank + 1) * rows])
+        d2 = c.upload(p2[rank * shard:(rank + 1) * shard])
+        all2 = c.zeros(576 * n2)
+        res = c.zeros(12 * n1)
+        comm.match_sharded(d1.ptr, rows, d2.ptr, shard, all2.ptr, res.ptr)
+        out[rank] = dict(results=results, rows=c.download(d1, (rows,), capi.POINT_DTYPE),
+                         res=c.download(res, (n1,), capi.RESULT_DTYPE), set2=c.download(all2, (n2,), capi.POINT_DTYPE),
+                         p1=p1, p2=p2)
+        comm.close()
+        c.close()
+    except Exception as e:                         # noqa: BLE001 — reported by the main thread
+        import traceback
+        errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+
+
+def _run_loopback(capi, world, plan):
+    lw = capi.LoopbackWorld(world)
+    out, errs = {}, []
+    ts = [threading.Thread(target=_loop_rank, args=(capi, r, world, lw, plan, out, errs)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=900)
+    assert not any(t.is_alive() for t in ts), "a loopback rank is stuck"
+    assert not errs, "\n".join(errs)
+    assert len(out) == world
+    lw.close()
+    return out
+
+
+def _check_loopback(capi, ctx, world, plan, out):
+    root, mp = plan["root"], plan["mp"]
+    n_overflowed = 0
+    for k, counts, offs, recs in out[root]["results"]:
+        assert counts.shape[0] == world and offs[0] == 0
+        for r in range(world):
+            th = plan["thresh"](r, k)
+            fr = plan["frames"](r, k)
+            assert np.array_equal(out[r]["results"][k][1], counts)          # every rank holds every count
+            assert np.array_equal(out[r]["results"][k][2], offs)
+            off = int(offs[r])
+            if th < 0.01:                                                   # candidate lists overflow: -1, no records
+                assert (counts[r] == -1).all(), counts[r]
+                n_overflowed += len(counts[r])
+            else:
+                rp, rn = ctx.extract_batch(fr, thresh=th, max_pts=mp)
+                assert np.array_equal(counts[r], rn), (k, r, counts[r], rn)
+                for f in range(len(rn)):
+                    assert _canon(recs[off:off + rn[f]]) == _canon(rp[f, :rn[f]]), (k, r, f)
+                    off += rn[f]
+            assert off == offs[r + 1], (k, r)
+        assert len(recs) == offs[world]
+    p1, p2 = out[0]["p1"], out[0]["p2"]
+    ref = ctx.match(p1, len(p1), p2, len(p2))
+    rows = plan["rows"]
+    for r in range(world):
+        assert np.array_equal(out[r]["set2"].tobytes(), p2.tobytes())        # set 2 replicated in rank order
+        blk = out[r]["rows"]
+        for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+            assert np.array_equal(blk[f], ref[f][r * rows:(r + 1) * rows]), (r, f)
+        for f in ("score", "ambiguity", "match"):
+            assert np.array_equal(out[r]["res"][f], ref[f]), (r, f)
+    return n_overflowed
+
+
+def _plan(world, root, empty_rank=None, overflow_rank=None, B=2, w=320, h=208, mp=2048):
+    flat = np.full((B, h, w), 77.0, np.float32)                              # no keypoints at all: an empty rank
+
+    def frames(rank, k):
+        if rank == empty_rank:
+            return flat
+        # ragged: different frames (and counts) on every rank and batch
+        return np.stack([synth_frame(7000 + 31 * rank + 5 * k + i, width=w, height=h) for i in range(B)]).astype(np.float32)
+
+    def thresh(rank, k):
+        return 0.0005 if (rank == overflow_rank and k == 1) else 2.0 + 0.25 * (rank % 3)
+
+    return dict(root=root, mp=mp, frames=frames, thresh=thresh, nbatches=3, capacity=mp * B * world, rows=96, shard=100)
+
+
+@pytest.mark.parametrize("world,root,empty,overflow", [(2, 0, None, None), (2, 1, 0, None), (4, 2, 1, 3), (8, 5, 6, 0)])
+def test_loopback_world_gather_and_match_sharded(ctx, world, root, empty, overflow):
+    """world ranks on ONE GPU through the loopback transport: ragged counts, an empty rank, a rank whose frames
+    overflow their candidate lists (-1 counts), root != 0, capacity too small, shard size % 32 != 0."""
+    from cudasift_amd import capi
+    plan = _plan(world, root, empty, overflow)
+    out = _run_loopback(capi, world, plan)
+    nov = _check_loopback(capi, ctx, world, plan, out)
+    if overflow is not None:
+        assert nov > 0
+    record("loopback_world_%d" % world, root=root, empty_rank=empty, overflow_rank=overflow, overflowed_frames=nov, ok=True)
+
+
+def test_loopback_world_reports_a_missing_rank(ctx):
+    """A rank that never makes the matching call: its peer gets an error after the timeout instead of hanging."""
+    import os
+    from cudasift_amd import capi
+    os.environ["MISIFT_LOOPBACK_TIMEOUT_S"] = "2"
+    try:
+        lw = capi.LoopbackWorld(2)
+    finally:
+        del os.environ["MISIFT_LOOPBACK_TIMEOUT_S"]
+    c = capi.Context(0)
+    comm = capi.Comm(c, 2, 0, lw)
+    with pytest.raises(RuntimeError, match="timed out"):
+        comm.barrier()
+    comm.close()
+    c.close()
+    lw.close()
