@@ -280,6 +280,9 @@ def _plan(world, root, empty_rank=None, overflow_rank=None, B=2, w=320, h=208, m
     def frames(rank, k):
         if rank == empty_rank:
             return flat
+        if rank == overflow_rank and k == 1:         # white noise at a near-zero threshold: more in-row extrema than the
+            rng = np.random.default_rng(123 + rank)  # per-octave candidate list max(16384, w*h/4) holds
+            return rng.uniform(0.0, 255.0, (B, h, w)).astype(np.float32)
         # ragged: different frames (and counts) on every rank and batch
         return np.stack([synth_frame(7000 + 31 * rank + 5 * k + i, width=w, height=h) for i in range(B)]).astype(np.float32)
 
