@@ -77,6 +77,7 @@ SIGNATURES = {
     "misift_match_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
     "misift_improve_homography": (_i, [_vp, _vp, _i, _fp, _i, _f, _f, _f, _ip]),
     "misift_malloc_managed": (_i, [_sz, C.POINTER(_vp)]),
+    "misift_test_elementary": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i]),
     "misift_comm_unique_id": (_i, [_vp]),
     "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "misift_comm_adopt": (_i, [_vp, _vp, C.POINTER(_vp)]),
@@ -426,6 +427,17 @@ class Context:
         check(lib().misift_improve_homography(self.h, dpts_ptr, npts, h, num_loops, min_score, max_ambiguity, thresh,
                                               C.byref(nf)), "misift_improve_homography")
         return np.array(list(h), np.float32).reshape(3, 3), nf.value
+
+    def test_elementary(self, fn, x, y=None):
+        """Device copies of det_exp2 (0) / det_atan2(y, x) (1) / det_exp (2) / det_sincos (3) on float32 arrays."""
+        x = np.ascontiguousarray(x, np.float32)
+        dx = self.upload(x)
+        dy = self.upload(np.ascontiguousarray(y, np.float32)) if y is not None else None
+        o1, o2 = self.zeros(4 * len(x)), self.zeros(4 * len(x))
+        check(lib().misift_test_elementary(self.h, fn, dx.ptr, dy.ptr if dy else None, o1.ptr, o2.ptr, len(x)),
+              "misift_test_elementary")
+        a = self.download(o1, (len(x),), np.float32)
+        return (a, self.download(o2, (len(x),), np.float32)) if fn == 3 else a
 
     # ---- profiling
     def profile_enable(self, on=True):

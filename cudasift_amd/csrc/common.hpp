@@ -383,4 +383,6 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
 int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
                       float thresh, float edge_limit, float factor, int max_pts);
 int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2);
+int launch_test_exp2(misift_ctx *ctx, const float *x, float *out, int n);
+int launch_test_points_fn(misift_ctx *ctx, int fn, const float *x, const float *y, float *out, float *out2, int n);
 int launch_selftest(misift_ctx *ctx);

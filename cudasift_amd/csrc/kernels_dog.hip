@@ -1207,3 +1207,17 @@ int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
                      ctx->d_counters, ctx->d_cand, ctx->d_det);
   return ls.finish();
 }
+
+// ---- test-only: the device det_exp2 on caller-supplied inputs (misift_test_elementary; tests compare the bits with the
+// oracle's and the values with float64 libm)
+__global__ void test_exp2_kernel(const float *__restrict__ x, float *__restrict__ out, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = det_exp2(x[i]);
+}
+int launch_test_exp2(misift_ctx *ctx, const float *x, float *out, int n)
+{
+  hipLaunchKernelGGL(test_exp2_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, x, out, n);
+  HIP_TRY(hipGetLastError());
+  return MISIFT_OK;
+}

@@ -1650,3 +1650,25 @@ int launch_rescale(misift_ctx *ctx, SiftPointD *pts, int npts, float scale)
   hipLaunchKernelGGL(rescale_kernel, dim3((npts + 255) / 256), dim3(256), 0, ctx->stream, pts, npts, scale);
   return ls.finish();
 }
+
+// ---- test-only: the device det_atan2 / det_exp / det_sincos on caller-supplied inputs (misift_test_elementary)
+__global__ void test_points_fn_kernel(int fn, const float *__restrict__ x, const float *__restrict__ y,
+                                      float *__restrict__ out, float *__restrict__ out2, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (fn == 1) out[i] = det_atan2(y[i], x[i]);
+  else if (fn == 2) out[i] = det_exp(x[i]);
+  else {
+    float sn, cs;
+    det_sincos(x[i], sn, cs);
+    out[i] = sn;
+    out2[i] = cs;
+  }
+}
+int launch_test_points_fn(misift_ctx *ctx, int fn, const float *x, const float *y, float *out, float *out2, int n)
+{
+  hipLaunchKernelGGL(test_points_fn_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fn, x, y, out, out2, n);
+  HIP_TRY(hipGetLastError());
+  return MISIFT_OK;
+}

@@ -1273,6 +1273,22 @@ extern "C" int misift_descriptors(misift_ctx *ctx, const float *d_base, int widt
   return resolve_profile(ctx);
 }
 
+// Test-only: evaluate the DEVICE copy of one written-out elementary function on n inputs (0 = det_exp2(x),
+// 1 = det_atan2(y, x), 2 = det_exp(x), 3 = det_sincos(x) -> out = sin, out2 = cos).  The kernels and the oracle share
+// these expressions, so parity tests cannot see an error in them; tests/test_gpu_parity.py checks the bits against the
+// oracle's copy and tests/test_oracle_cpu.py the values against float64 libm.
+extern "C" int misift_test_elementary(misift_ctx *ctx, int fn, const float *d_x, const float *d_y, float *d_out,
+                                      float *d_out2, int n)
+{
+  ARG_CHECK(ctx && fn >= 0 && fn <= 3 && d_x && d_out && n >= 0 && (fn != 1 || d_y) && (fn != 3 || d_out2));
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return MISIFT_OK;
+  int rc = fn == 0 ? launch_test_exp2(ctx, d_x, d_out, n) : launch_test_points_fn(ctx, fn, d_x, d_y, d_out, d_out2, n);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
 extern "C" int misift_rescale_positions(misift_ctx *ctx, void *d_pts, int npts, float scale)
 {
   ARG_CHECK(ctx && d_pts && npts >= 0);

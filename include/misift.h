@@ -364,6 +364,12 @@ int misift_improve_homography(misift_ctx *ctx, void *d_pts, int npts, float *hom
  * host and device (SiftData.m_data). */
 int misift_malloc_managed(size_t bytes, void **out);
 
+/* Test-only entry point (no reference counterpart): the device copies of the written-out elementary functions that
+ * replace CUDA's exp2f / atan2f / expf / __sinf,__cosf (cudaSiftD.cu:1417, 1008, 987, 331-332), evaluated on n inputs.
+ * fn: 0 = exp2(x), 1 = atan2(y, x), 2 = exp(x), 3 = sin/cos(x) -> d_out, d_out2.  Device pointers; synchronous. */
+int misift_test_elementary(misift_ctx *ctx, int fn, const float *d_x, const float *d_y, float *d_out, float *d_out2,
+                           int n);
+
 /* ------------------------------------------------------------------- timing */
 
 /* TimerGPU (cudautils.h:61-81): event pair on the context stream. */

@@ -79,6 +79,7 @@ def lib():
         L.orc_find_homography.restype = C.c_int
         L.orc_improve_homography.argtypes = [vp, C.c_int, fp, C.c_int, C.c_float, C.c_float, C.c_float]
         L.orc_improve_homography.restype = C.c_int
+        L.orc_det_eval.argtypes = [C.c_int, vp, vp, vp, vp, C.c_long]
         L.orc_stats_get.argtypes = [C.POINTER(OrcStats)]
         L.orc_sizeof_point.restype = C.c_int
         assert L.orc_sizeof_point() == 576
@@ -170,6 +171,16 @@ def descriptors(base, pts, first, last, subsampling=1.0, fracbits=8):
     base = _f32(base)
     h, w = base.shape
     lib().orc_descriptors(_p(base), w, h, w, _p(pts), first, last, subsampling, fracbits)
+
+
+def det_eval(fn, x, y=None):
+    """The oracle's written-out elementary functions on arrays: fn 0 = exp2(x), 1 = atan2(y, x), 2 = exp(x),
+    3 = sincos(x) -> (sin, cos)."""
+    x = _f32(x)
+    y = _f32(y) if y is not None else x
+    out, out2 = np.empty_like(x), np.empty_like(x)
+    lib().orc_det_eval(fn, _p(x), _p(y), _p(out), _p(out2), x.size)
+    return (out, out2) if fn == 3 else out
 
 
 def tex2d(img, x, y, fracbits=8):

@@ -676,6 +676,16 @@ static inline void det_sincos(float x, float *sn, float *cs)
   *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 void orc_det_sincos(float x, float *sn, float *cs) { det_sincos(x, sn, cs); }
+/* array form for the accuracy tests: fn 0 = exp2(x), 1 = atan2(y, x), 2 = exp(x), 3 = sincos(x) -> out, out2 */
+void orc_det_eval(int fn, const float *x, const float *y, float *out, float *out2, long n)
+{
+  for (long i = 0; i < n; i++) {
+    if (fn == 0) out[i] = det_exp2(x[i]);
+    else if (fn == 1) out[i] = det_atan2(y[i], x[i]);
+    else if (fn == 2) out[i] = det_exp(x[i]);
+    else det_sincos(x[i], &out[i], &out2[i]);
+  }
+}
 
 /* ExtractSiftDescriptorsCONSTNew, cudaSiftD.cu:308-417, for points [first,last). */
 void orc_descriptors(const float *img, int w, int h, int pitch, SiftPoint *pts, int first, int last,

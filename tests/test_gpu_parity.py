@@ -892,3 +892,24 @@ def test_misift_devices_env():
     assert "count 1" in outs["0"] and "ctx ok True" in outs["0"], outs
     assert "count 0" in outs["63"] and "ctx failed" in outs["63"] and "no HIP device visible" in outs["63"], outs
     assert "ctx ok True" in outs[""], outs
+
+
+def test_device_elementary_functions_have_the_oracles_bits(ctx):
+    """The device copies of det_exp2 / det_atan2 / det_exp / det_sincos (test-only entry misift_test_elementary) return
+    the oracle's bits on 10^6 inputs each — the premise of the bit-identical scale / orientation assertions above; the
+    oracle's copies are checked against float64 libm in tests/test_oracle_cpu.py::test_det_functions_accuracy."""
+    rng = np.random.default_rng(7)
+    n = 1 << 20
+    x = np.concatenate([rng.uniform(-0.12, 0.12, n // 2), rng.uniform(-150, 150, n // 2 - 3),
+                        [np.nan, -200.0, 200.0]]).astype(np.float32)
+    a, b = ctx.test_elementary(0, x), orc().det_eval(0, x)
+    assert np.array_equal(a.view(np.uint32)[:-3], b.view(np.uint32)[:-3]) and np.isnan(a[-3]) and a[-2] == 0.0 and a[-1] == b[-1]
+    gx = np.concatenate([rng.uniform(-255, 255, n // 2), rng.normal(0, 1e-3, n // 2 - 4), [0.0, -0.0, 1.0, -1.0]]).astype(np.float32)
+    gy = np.concatenate([rng.uniform(-255, 255, n // 2), rng.normal(0, 1e-3, n // 2 - 4), [0.0, 0.0, 0.0, -0.0]]).astype(np.float32)
+    assert np.array_equal(ctx.test_elementary(1, gx, gy).view(np.uint32), orc().det_eval(1, gx, gy).view(np.uint32))
+    x = np.concatenate([-rng.uniform(0, 1, n // 2), -rng.uniform(0, 100, n // 2)]).astype(np.float32)
+    assert np.array_equal(ctx.test_elementary(2, x).view(np.uint32), orc().det_eval(2, x).view(np.uint32))
+    x = rng.uniform(0.0, 2.0 * 3.1415, n).astype(np.float32)
+    s, c = ctx.test_elementary(3, x)
+    so, co = orc().det_eval(3, x)
+    assert np.array_equal(s.view(np.uint32), so.view(np.uint32)) and np.array_equal(c.view(np.uint32), co.view(np.uint32))
