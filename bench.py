@@ -350,13 +350,20 @@ class StepPipeline:
     batches queued behind it.  Every batch's read-back/gather completes before run() returns: nothing is skipped, only
     overlapped."""
 
-    def __init__(self, torch, capi, ctxs, ctx_streams, comm, rank, world, device, frames, B, NB, scratches, pts, unfused):
+    def __init__(self, torch, capi, ctxs, ctx_streams, comm, rank, world, device, frames, B, NB, scratches, pts, unfused,
+                 ring=1):
         self.torch, self.capi, self.ctxs, self.ctx_streams, self.comm = torch, capi, ctxs, ctx_streams, comm
         self.rank, self.world, self.frames, self.B, self.NB, self.scratches = rank, world, frames, B, NB, scratches
         self.pts, self.unfused = pts, unfused
         NCTX = self.NCTX = len(ctxs)
-        self.LAG = NCTX + 1                 # the host completes batch k-LAG: NCTX batches stay queued on the GPU
+        self.RING = ring                    # batches in flight INSIDE every context (misift_ctx_set_batches_in_flight)
+        self.INFLIGHT = NCTX * ring
+        assert len(scratches) >= self.INFLIGHT, "one scratch arena per batch in flight"
+        self.LAG = self.INFLIGHT + 1        # the host completes batch k-LAG: INFLIGHT batches stay queued on the GPU
         NSLOT = self.NSLOT = self.LAG + 1
+        # with a ring the results of a call are not ordered on the context stream: a side stream per slot waits for the
+        # batch (misift_ctx_wait_batch) and carries the events
+        self.slot_streams = [torch.cuda.Stream(device=device) for _ in range(NSLOT)] if ring > 1 else None
         REC_CAP = self.REC_CAP = MAX_PTS    # mainSift.cpp:58-67 capacity (32768 records per frame)
         self.packed = [torch.empty((B * REC_CAP * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
         self.cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(NSLOT)]
@@ -377,18 +384,22 @@ class StepPipeline:
         ci = k % self.NCTX
         capi.check(capi.lib().misift_extract_batch_packed_async(
             self.ctxs[ci].h, self.frames[b0].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0,
-            self.scratches[ci].data_ptr(),
+            self.scratches[k % self.INFLIGHT].data_ptr(),
             self.pts.data_ptr() if self.unfused else None,      # merged-octave path writes the packed array directly
             self.REC_CAP, self.cnts[slot].data_ptr(), self.cnts[slot][B:].data_ptr(), self.packed[slot].data_ptr()),
             "misift_extract_batch_packed_async")
+        done_stream = self.ctx_streams[ci]
+        if self.RING > 1:
+            done_stream = self.slot_streams[slot]
+            self.ctxs[ci].wait_batch(done_stream.cuda_stream)
         if self.comm is not None:
             self.comm.gather_post(slot, self.cnts[slot].data_ptr(), B, self.packed[slot].data_ptr(), ctx=self.ctxs[ci])
         else:
             ev = torch.cuda.Event()
-            ev.record(self.ctx_streams[ci])
+            ev.record(done_stream)
             self.done_ev[slot] = ev
         e = torch.cuda.Event(enable_timing=True)
-        e.record(self.ctx_streams[ci])
+        e.record(done_stream)
         self.step_ev.append(e)
 
     def complete(self, k):
@@ -564,6 +575,9 @@ def main():
                     help="contexts (own stream, staging and scratch arena each) the steps rotate over = batches in flight on the "
                          "GPU.  4 measures ~8 %% more frames/s (profiles/r02_bench_contexts4.json) but every kernel's duration is "
                          "then stretched by its neighbours, so the per-kernel roofline is quoted on the default, 1")
+    ap.add_argument("--batches-in-flight", type=int, default=1,
+                    help="pipelines INSIDE the context (misift_ctx_set_batches_in_flight): consecutive batches overlap on the GPU "
+                         "behind ONE context.  The per-kernel roofline durations always come from a K = 1 child run")
     ap.add_argument("--match-n", type=int, default=100000)
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg AND the oracle self-validation")
@@ -614,8 +628,11 @@ def main():
     ctx = capi.Context(local_rank, stream.cuda_stream)
     ctx_streams = [stream] + [torch.cuda.Stream(device=device) for _ in range(NCTX - 1)]
     ctxs = [ctx] + [capi.Context(local_rank, st.cuda_stream) for st in ctx_streams[1:]]
+    RING = 1 if args.unfused else max(1, args.batches_in_flight)
     for c in ctxs:
         c.set_options(quiet=1, fused=0 if args.unfused else 1)
+        if RING > 1:
+            c.set_batches_in_flight(RING)
 
     # the data-path communicator lives behind the C-ABI (RCCL over xGMI): rank 0 makes the id, torch ships it
     comm = None
@@ -631,7 +648,7 @@ def main():
     frames = torch.empty((NB * B, H, W), dtype=torch.float32, device=device)
     gen_frames_torch(torch, NB * B, rank * NB * B, device, out=frames)
     S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
-    scratches = [torch.empty((B * S,), dtype=torch.float32, device=device) for _ in range(NCTX)]
+    scratches = [torch.empty((B * S,), dtype=torch.float32, device=device) for _ in range(NCTX * RING)]
     scratch = scratches[0]
     pts = torch.zeros((B * MAX_PTS * 576,), dtype=torch.uint8, device=device) if args.unfused else None
     counts = (C.c_int * B)()
@@ -639,7 +656,8 @@ def main():
 
     # Software-pipelined step loop, the same for every N (class StepPipeline above; `--emulate-ranks` drives N of them
     # from N host threads of this process over the loopback transport)
-    pl = StepPipeline(torch, capi, ctxs, ctx_streams, comm, rank, world, device, frames, B, NB, scratches, pts, args.unfused)
+    pl = StepPipeline(torch, capi, ctxs, ctx_streams, comm, rank, world, device, frames, B, NB, scratches, pts, args.unfused,
+                      ring=RING)
     LAG, NSLOT, REC_CAP = pl.LAG, pl.NSLOT, pl.REC_CAP
     packed, cnts, step_ev = pl.packed, pl.cnts, pl.step_ev
     enqueue, run, host_t, trace_host = pl.enqueue, pl.run, pl.host_t, pl.trace_host
@@ -673,9 +691,11 @@ def main():
                  ms_per_step), file=sys.stderr)
     # distribution of the pipelined loop's steps on the GPU timeline (median + p10/p90)
     step_ms = None
-    if rank == 0 and len(step_ev) >= NCTX + 2:
+    if rank == 0 and len(step_ev) >= NCTX * RING + 2:
         # step k and step k+NCTX end on the same stream: that interval / NCTX is the loop's period seen from one context
-        d = np.array([step_ev[i].elapsed_time(step_ev[i + NCTX]) / NCTX for i in range(len(step_ev) - NCTX)])
+        # (with a ring: the completion markers of batches k and k + batches-in-flight)
+        NI = NCTX * RING
+        d = np.array([step_ev[i].elapsed_time(step_ev[i + NI]) / NI for i in range(len(step_ev) - NI)])
         step_ms = {"p10": round(float(np.percentile(d, 10)), 4), "p50": round(float(np.percentile(d, 50)), 4),
                    "p90": round(float(np.percentile(d, 90)), 4), "samples": int(len(d)),
                    "note": "HIP-event interval between the ends of steps k and k+contexts (same stream) / contexts, "
@@ -1051,6 +1071,9 @@ def main():
                                       "5 octaves initBlur 1.0 thresh 3.0 maxPts 32768, frames resident in HBM, count read-back%s"
                                       % (B, NB, NB * B, " + RCCL gather of SiftData to rank 0 (misift_gather_*)" if comm else ""),
                           "frames_per_gpu": B, "distinct_frames_per_gpu": NB * B, "contexts": NCTX,
+                          "batches_in_flight": NCTX * RING,
+                          "batches_in_flight_note": "misift_ctx_set_batches_in_flight(%d): pipelines behind ONE context; kernel "
+                                                    "durations of the roofline come from a one-batch-at-a-time child run" % RING,
                           "contexts_note": "the steps rotate over this many misift contexts per GPU (own stream, staging and "
                                            "scratch arena each): that many batches are in flight on the GPU",
                           "path": "unfused" if args.unfused else "fused dog+detect",

@@ -77,6 +77,9 @@ SIGNATURES = {
     "misift_match_rows": (_i, [_vp, _vp, _i, _i, _vp, _i]),
     "misift_improve_homography": (_i, [_vp, _vp, _i, _fp, _i, _f, _f, _f, _ip]),
     "misift_malloc_managed": (_i, [_sz, C.POINTER(_vp)]),
+    "misift_ctx_set_batches_in_flight": (_i, [_vp, _i]),
+    "misift_ctx_get_batches_in_flight": (_i, [_vp]),
+    "misift_ctx_wait_batch": (_i, [_vp, _vp]),
     "misift_test_elementary": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i]),
     "misift_comm_unique_id": (_i, [_vp]),
     "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
@@ -203,6 +206,14 @@ class Context:
                 raise KeyError(k)
             setattr(o, k, int(v))
         check(lib().misift_set_options(self.h, C.byref(o)), "misift_set_options")
+
+    def set_batches_in_flight(self, k):
+        """K pipelines behind this context (misift_ctx_set_batches_in_flight): consecutive packed-async calls overlap."""
+        check(lib().misift_ctx_set_batches_in_flight(self.h, k), "misift_ctx_set_batches_in_flight")
+
+    def wait_batch(self, stream):
+        """Make `stream` (a raw hipStream_t value) wait for the most recently enqueued batch of this context."""
+        check(lib().misift_ctx_wait_batch(self.h, stream), "misift_ctx_wait_batch")
 
     def sync(self):
         check(lib().misift_ctx_sync(self.h), "misift_ctx_sync")

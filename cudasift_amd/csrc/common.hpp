@@ -310,6 +310,8 @@ struct misift_ctx {
 
 void misift_set_error(const char *fmt, ...);
 int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap);
+// the stream the most recent batch of `ctx` ran on (its own, or a pipeline's with batches in flight)
+hipStream_t misift_ctx_result_stream(misift_ctx *ctx);
 int misift_ensure_tmp(misift_ctx *ctx, size_t bytes);
 int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride,
                            int width, int height, int pitch, int num_octaves, float init_blur, float thresh,

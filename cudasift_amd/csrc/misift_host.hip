@@ -102,6 +102,16 @@ struct CtxExtra {
   hipGraphExec_t gexec = nullptr;
   hipStream_t gstream = nullptr;      // capture / replay stream (capture is not allowed on the null stream)
   hipEvent_t gev_in = nullptr, gev_out = nullptr;
+  // batches in flight (misift_ctx_set_batches_in_flight): K child contexts = K in-order pipelines (stream, counters,
+  // candidate lists, detection staging each) that misift_extract_batch_packed_async rotates over
+  std::vector<misift_ctx *> lanes;
+  std::vector<hipEvent_t> lane_done;   // 2K events: done[ticket % 2K] is recorded behind batch `ticket` on its lane's stream
+  hipEvent_t ev_in = nullptr;          // recorded on the caller's stream at every call: the lane starts behind it
+  hipEvent_t ev_single = nullptr;      // K = 1: misift_ctx_wait_batch records this one on the context stream
+  unsigned long long ticket = 0;
+  misift_ctx *last_lane = nullptr;     // the pipeline that took the most recent batch (nullptr: the context itself)
+  hipEvent_t last_done = nullptr;
+  hipStream_t own_stream = nullptr;    // a child context owns its stream
 };
 static CtxExtra *extra(misift_ctx *ctx);
 
@@ -305,6 +315,34 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   return launch_selftest(ctx);
 }
 
+static int ctx_create_physical(int device, void *stream, bool own_stream, misift_ctx **out)
+{
+  HIP_TRY(hipSetDevice(device));
+  CtxFull *f = new CtxFull();
+  misift_ctx *ctx = &f->c;
+  memset(ctx, 0, sizeof(*ctx));
+  if (own_stream) {
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      misift_set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+      delete f;
+      return MISIFT_EHIP;
+    }
+    f->x.own_stream = s;
+    stream = s;
+  }
+  const int rc = ctx_init(ctx, f, device, stream);
+  if (rc) {
+    misift_ctx_destroy(ctx);                            // keeps the error message of the failing step
+    return rc;
+  }
+  *out = ctx;
+  return MISIFT_OK;
+}
+
+extern "C" int misift_ctx_set_batches_in_flight(misift_ctx *ctx, int k);
+
 extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
 {
   ARG_CHECK(out != nullptr);
@@ -317,16 +355,80 @@ extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
   }
   if (device < 0 || device >= n) device = n - 1;      // like InitCuda: clamp (cudaSiftH.cu:27)
   device = physical_device(device);                   // MISIFT_DEVICES: from here on the HIP device number
-  HIP_TRY(hipSetDevice(device));
-  CtxFull *f = new CtxFull();
-  misift_ctx *ctx = &f->c;
-  memset(ctx, 0, sizeof(*ctx));
-  const int rc = ctx_init(ctx, f, device, stream);
-  if (rc) {
-    misift_ctx_destroy(ctx);                            // keeps the error message of the failing step
-    return rc;
+  int rc = ctx_create_physical(device, stream, false, out);
+  if (rc) return rc;
+  if (const char *e = getenv("MISIFT_BATCHES_IN_FLIGHT")) {
+    rc = misift_ctx_set_batches_in_flight(*out, atoi(e));
+    if (rc) { misift_ctx_destroy(*out); *out = nullptr; }
   }
-  *out = ctx;
+  return rc;
+}
+
+// ---- batches in flight: an in-context ring of pipelines
+// One misift_ctx is ONE in-order pipeline: batch k+1 starts when batch k is done, so the HBM-bound front end of a batch
+// (lowpass_down, 0.24 ms at 0.7 of the HBM peak) never runs beside the VALU-bound kernels of another and every launch
+// tail leaves CUs idle.  With K > 1 the context owns K child pipelines (own stream, counters, candidate lists, detection
+// staging each — the caller rotates >= K scratch arenas and output buffers) and misift_extract_batch_packed_async hands
+// consecutive calls to consecutive pipelines: r02 measured +8-9 % frames/s for K = 3-4 with separate contexts
+// (bench.py --contexts); this is the same thing behind ONE context.  The caller's stream only carries a marker per
+// call (the batch starts behind everything enqueued on it before the call); completion is observed through
+// misift_ctx_wait_batch / misift_gather_post / misift_ctx_sync — NOT through the caller's stream.
+extern "C" int misift_ctx_set_batches_in_flight(misift_ctx *ctx, int k)
+{
+  ARG_CHECK(ctx != nullptr && k >= 1 && k <= 8);
+  CtxExtra *x = extra(ctx);
+  HIP_TRY(hipSetDevice(ctx->device));
+  // drain and drop the current ring first
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (misift_ctx *l : x->lanes) { hipStreamSynchronize(l->stream); misift_ctx_destroy(l); }
+  x->lanes.clear();
+  for (hipEvent_t e : x->lane_done) hipEventDestroy(e);
+  x->lane_done.clear();
+  x->last_lane = nullptr; x->last_done = nullptr; x->ticket = 0;
+  if (k == 1) return MISIFT_OK;
+  if (!x->ev_in) HIP_TRY(hipEventCreateWithFlags(&x->ev_in, hipEventDisableTiming));
+  for (int i = 0; i < k; i++) {
+    misift_ctx *l = nullptr;
+    const int rc = ctx_create_physical(ctx->device, nullptr, true, &l);
+    if (rc) return rc;
+    x->lanes.push_back(l);
+  }
+  for (int i = 0; i < 2 * k; i++) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    x->lane_done.push_back(e);
+  }
+  return MISIFT_OK;
+}
+
+extern "C" int misift_ctx_get_batches_in_flight(misift_ctx *ctx)
+{
+  return ctx ? (extra(ctx)->lanes.empty() ? 1 : (int)extra(ctx)->lanes.size()) : 0;
+}
+
+// The pipeline that holds the results (counters, profile) of the most recent batch, and the stream it ran on.
+static misift_ctx *result_ctx(misift_ctx *ctx)
+{
+  CtxExtra *x = extra(ctx);
+  return x->last_lane ? x->last_lane : ctx;
+}
+hipStream_t misift_ctx_result_stream(misift_ctx *ctx) { return result_ctx(ctx)->stream; }
+
+// `stream` waits for the most recently enqueued batch of `ctx` (any K; with K = 1 the same as an event recorded on the
+// context stream now).
+extern "C" int misift_ctx_wait_batch(misift_ctx *ctx, void *stream)
+{
+  ARG_CHECK(ctx != nullptr);
+  CtxExtra *x = extra(ctx);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (x->last_done) {
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, x->last_done, 0));
+    return MISIFT_OK;
+  }
+  if ((hipStream_t)stream == ctx->stream) return MISIFT_OK;
+  if (!x->ev_single) HIP_TRY(hipEventCreateWithFlags(&x->ev_single, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(x->ev_single, ctx->stream));
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, x->ev_single, 0));
   return MISIFT_OK;
 }
 
@@ -336,6 +438,11 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   CtxExtra *x = extra(ctx);
+  for (misift_ctx *l : x->lanes) misift_ctx_destroy(l);
+  x->lanes.clear();
+  for (hipEvent_t e : x->lane_done) hipEventDestroy(e);
+  if (x->ev_in) hipEventDestroy(x->ev_in);
+  if (x->ev_single) hipEventDestroy(x->ev_single);
   if (x->gexec) hipGraphExecDestroy(x->gexec);
   if (x->gstream) { hipStreamSynchronize(x->gstream); hipStreamDestroy(x->gstream); }
   if (x->gev_in) hipEventDestroy(x->gev_in);
@@ -354,6 +461,7 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (x->own_stream) hipStreamDestroy(x->own_stream);
   delete reinterpret_cast<CtxFull *>(ctx);
 }
 
@@ -375,6 +483,7 @@ extern "C" int misift_ctx_sync(misift_ctx *ctx)
 {
   ARG_CHECK(ctx != nullptr);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (misift_ctx *l : extra(ctx)->lanes) HIP_TRY(hipStreamSynchronize(l->stream));
   return MISIFT_OK;
 }
 
@@ -1085,6 +1194,27 @@ extern "C" int misift_extract_batch_packed_async(misift_ctx *ctx, const float *d
                                                  int *d_offsets_out, void *d_packed_out)
 {
   ARG_CHECK(ctx && d_counts_out && d_offsets_out && d_packed_out);
+  CtxExtra *px = extra(ctx);
+  if (!px->lanes.empty()) {
+    // batches in flight: this call goes to the next pipeline of the ring, behind a marker on the caller's stream
+    const size_t k = px->lanes.size();
+    misift_ctx *lane = px->lanes[px->ticket % k];
+    hipEvent_t done = px->lane_done[px->ticket % (2 * k)];
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(px->ev_in, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(lane->stream, px->ev_in, 0));
+    lane->opt = ctx->opt;
+    lane->profile = ctx->profile;
+    const int rc = misift_extract_batch_packed_async(lane, d_imgs, nframes, frame_stride, width, height, pitch, num_octaves,
+                                                     init_blur, thresh, lowest_scale, d_scratch, d_pts, max_pts, d_counts_out,
+                                                     d_offsets_out, d_packed_out);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(done, lane->stream));
+    px->last_lane = lane;
+    px->last_done = done;
+    px->ticket++;
+    return MISIFT_OK;
+  }
   if (ctx->opt.fused) {
     // merged-octave path: descr_all writes the packed array itself (no separate packing pass); d_pts may be NULL
     ctx->pack_counts = d_counts_out; ctx->pack_offsets = d_offsets_out; ctx->pack_dst = (SiftPointD *)d_packed_out;
@@ -1107,7 +1237,9 @@ extern "C" int misift_extract_batch_packed_async(misift_ctx *ctx, const float *d
 
 extern "C" int misift_get_counters(misift_ctx *ctx, int frame, unsigned int *counters17)
 {
-  ARG_CHECK(ctx && counters17 && frame >= 0 && frame < ctx->cap_frames);
+  ARG_CHECK(ctx != nullptr);
+  ctx = result_ctx(ctx);               // batches in flight: the pipeline that took the most recent batch
+  ARG_CHECK(counters17 && frame >= 0 && frame < ctx->cap_frames);
   unsigned tmp[CNT_STRIDE];
   HIP_TRY(hipMemcpyAsync(tmp, ctx->d_counters + (size_t)frame * CNT_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost,
                          ctx->stream));
@@ -1339,6 +1471,11 @@ extern "C" int misift_profile_enable(misift_ctx *ctx, int on)
   ARG_CHECK(ctx != nullptr);
   int rc = resolve_profile(ctx);
   ctx->profile = on != 0;
+  for (misift_ctx *l : extra(ctx)->lanes) {
+    const int r2 = resolve_profile(l);
+    l->profile = on != 0;
+    if (!rc) rc = r2;
+  }
   return rc;
 }
 
@@ -1347,6 +1484,11 @@ extern "C" int misift_profile_reset(misift_ctx *ctx)
   ARG_CHECK(ctx != nullptr);
   int rc = resolve_profile(ctx);
   ctx->nprof = 0;
+  for (misift_ctx *l : extra(ctx)->lanes) {
+    const int r2 = resolve_profile(l);
+    l->nprof = 0;
+    if (!rc) rc = r2;
+  }
   return rc;
 }
 
@@ -1355,12 +1497,28 @@ extern "C" int misift_profile_read(misift_ctx *ctx, int cap, char (*names)[32], 
   ARG_CHECK(ctx && names && total_ms && calls && n_out);
   int rc = resolve_profile(ctx);
   if (rc) return rc;
-  int n = ctx->nprof < cap ? ctx->nprof : cap;
-  for (int i = 0; i < n; i++) {
-    memcpy(names[i], ctx->prof[i].name, 32);
-    total_ms[i] = ctx->prof[i].total_ms;
-    calls[i] = ctx->prof[i].calls;
+  int n = 0;
+  // the context's own launches, then those of its pipelines (batches in flight), merged by kernel name
+  std::vector<misift_ctx *> all(1, ctx);
+  for (misift_ctx *l : extra(ctx)->lanes) {
+    rc = resolve_profile(l);
+    if (rc) return rc;
+    all.push_back(l);
   }
+  for (misift_ctx *c : all)
+    for (int i = 0; i < c->nprof; i++) {
+      int j = 0;
+      while (j < n && strncmp(names[j], c->prof[i].name, 32) != 0) j++;
+      if (j == n) {
+        if (n == cap) continue;
+        memcpy(names[n], c->prof[i].name, 32);
+        total_ms[n] = 0.0f;
+        calls[n] = 0;
+        n++;
+      }
+      total_ms[j] += c->prof[i].total_ms;
+      calls[j] += c->prof[i].calls;
+    }
   *n_out = n;
   return MISIFT_OK;
 }

@@ -454,7 +454,9 @@ extern "C" int misift_gather_post(misift_ctx *ctx, misift_comm *c, int slot, con
   GatherSlot &s = c->slots[slot];
   s.d_counts = d_counts; s.d_packed = d_packed; s.nframes = nframes;
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipEventRecord(s.ready, ctx->stream));      // the batch queued so far on the context stream produces these buffers
+  // the batch queued last on the context (on its own stream, or on one of its pipelines with batches in flight)
+  // produces these buffers
+  HIP_TRY(hipEventRecord(s.ready, misift_ctx_result_stream(ctx)));
   s.posted = true;
   return MISIFT_OK;
 }

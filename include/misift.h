@@ -280,6 +280,21 @@ int misift_match(misift_ctx *ctx, void *d_pts1, int n1, const void *d_pts2, int 
 int misift_match_rows(misift_ctx *ctx, void *d_pts1, int row_begin, int row_count,
                       const void *d_pts2, int n2);
 
+/* Batches in flight (no reference counterpart: ExtractSift is synchronous, cudaSiftH.cu:72-144).  A context is one
+ * in-order pipeline; with K > 1 it owns K child pipelines (own stream, counters, candidate lists, detection staging) and
+ * misift_extract_batch_packed_async hands consecutive calls to consecutive pipelines, so the HBM-bound prefilter of one
+ * batch runs beside the VALU-bound kernels of another and launch tails are filled (+8-9 % frames/s at K = 3-4 on 64 x
+ * 1080p).  Contract with K > 1:
+ *   - every call still starts behind whatever was enqueued on the context stream before it (a marker is recorded there);
+ *   - its results are NOT ordered on the context stream: observe them with misift_ctx_wait_batch (makes a stream of the
+ *     caller's wait for the most recent batch), misift_gather_post (marks the most recent batch) or misift_ctx_sync;
+ *   - the scratch arena and the output buffers of a call must stay untouched until that batch is done: rotate >= K sets.
+ * K = 1 (default) is the plain in-order context.  Also MISIFT_BATCHES_IN_FLIGHT at context creation.  Changing K drains
+ * the context. */
+int misift_ctx_set_batches_in_flight(misift_ctx *ctx, int k);
+int misift_ctx_get_batches_in_flight(misift_ctx *ctx);
+int misift_ctx_wait_batch(misift_ctx *ctx, void *stream);
+
 /* ------------------------------------------------------------ multi-GPU
  * The reference is single-GPU (InitCuda picks ONE device, cudaSiftH.cu:19-37); BASELINE configs 4 and 5 shard
  * frames / matcher rows over the GPUs of a node.  One misift_ctx per device (one host thread or process each) and

@@ -775,6 +775,76 @@ def test_three_contexts_in_flight_equal_one_context(ctx):
             c.close()
 
 
+def test_batches_in_flight_inside_one_context(ctx):
+    """misift_ctx_set_batches_in_flight(K): ONE context, K pipelines behind it.  Seven batches queued back to back with
+    nothing synchronising in between (their kernels share the GPU) come out exactly as from the plain in-order context;
+    misift_ctx_wait_batch orders a side stream behind the most recent batch; counters and the per-kernel profile follow the
+    pipeline that took the batch; K back to 1 restores the in-order context."""
+    from cudasift_amd import capi
+    B, mp, K, NBATCH = 4, 8192, 3, 7
+    frames = np.stack([synth_frame(7100 + f) for f in range(2 * B)])
+    d = [ctx.upload(frames[:B]), ctx.upload(frames[B:])]
+    S = 4 * capi.scratch_floats(1920, 1080, 5, False) * B
+    ref = []
+    scratch0 = capi.DevBuf(S)
+    was_fused = ctx.get_options().fused
+    ctx.set_options(fused=1)
+    try:
+        for k in range(2):
+            ref.append(_packed_async_1080p(ctx, d[k], B, scratch0, ctx.zeros(4 * (2 * B + 1)), ctx.zeros(576 * mp * B), mp))
+    finally:
+        ctx.set_options(fused=was_fused)
+    c = capi.Context(0)
+    try:
+        c.set_options(fused=1)
+        c.set_batches_in_flight(K)
+        assert capi.lib().misift_ctx_get_batches_in_flight(c.h) == K
+        scr = [capi.DevBuf(S) for _ in range(K)]
+        cnts = [ctx.zeros(4 * (2 * B + 1)) for _ in range(NBATCH)]
+        packs = [ctx.upload(np.full(576 * mp * B, 0xA5, np.uint8)) for _ in range(NBATCH)]
+        ctx.sync()
+        c.profile_enable(True)
+        for k in range(NBATCH):                       # queue everything, then wait once
+            capi.check(capi.lib().misift_extract_batch_packed_async(
+                c.h, d[k % 2].ptr, B, 1080 * 1920, 1920, 1080, 1920, 5, 1.0, 3.0, 0.0, scr[k % K].ptr, None, mp,
+                cnts[k].ptr, cnts[k].ptr + 4 * B, packs[k].ptr), "misift_extract_batch_packed_async")
+        c.sync()
+        prof = c.profile_read()
+        assert prof["descr_all"]["calls"] == NBATCH and prof["lowpass_down"]["calls"] == NBATCH     # merged over the pipelines
+        c.profile_enable(False)
+        last = (NBATCH - 1) % 2
+        assert np.array_equal(np.stack([c.get_counters(f) for f in range(B)]), ref[last][3])        # the last batch's pipeline
+        for k in range(NBATCH):
+            ci = ctx.download(cnts[k], (2 * B + 1,), np.int32)
+            counts, offs = ci[:B], ci[B:]
+            rcounts, roffs, rrecs, _ = ref[k % 2]
+            assert np.array_equal(counts, rcounts) and np.array_equal(offs, roffs), (k, counts, rcounts)
+            recs = ctx.download(packs[k], (int(offs[B]),), capi.POINT_DTYPE)
+            for f in range(B):
+                assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(rrecs[roffs[f]:roffs[f + 1]]), (k, f)
+        # misift_ctx_wait_batch: a copy on the caller's own stream ordered behind the most recent batch
+        import ctypes as C
+        side = C.c_void_p()
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipStreamCreateWithFlags(C.byref(side), 1) == 0
+        probe = ctx.zeros(4 * (2 * B + 1))
+        capi.check(capi.lib().misift_extract_batch_packed_async(
+            c.h, d[0].ptr, B, 1080 * 1920, 1920, 1080, 1920, 5, 1.0, 3.0, 0.0, scr[0].ptr, None, mp,
+            cnts[0].ptr, cnts[0].ptr + 4 * B, packs[0].ptr), "misift_extract_batch_packed_async")
+        c.wait_batch(side)
+        assert hip.hipMemcpyAsync(C.c_void_p(probe.ptr), C.c_void_p(cnts[0].ptr), 4 * (2 * B + 1), 3, side) == 0     # device to device
+        assert hip.hipStreamSynchronize(side) == 0
+        assert np.array_equal(ctx.download(probe, (2 * B + 1,), np.int32)[:B], ref[0][0])
+        hip.hipStreamDestroy(side)
+        # back to the plain in-order context
+        c.set_batches_in_flight(1)
+        got = _packed_async_1080p(c, d[1], B, scratch0, ctx.zeros(4 * (2 * B + 1)), ctx.zeros(576 * mp * B), mp)
+        assert np.array_equal(got[0], ref[1][0]) and np.array_equal(got[3], ref[1][3])
+        record("batches_in_flight", pipelines=K, batches=NBATCH)
+    finally:
+        c.close()
+
+
 def test_extract_batch_scaleup_and_u8(ctx, stereo):
     """misift_extract_batch_ex: the scaleUp path over a BATCH (the reference applies it per call, cudaSiftH.cu:118-132),
     fp32 and 8-bit frames — every frame against the oracle's scaleUp extraction."""
