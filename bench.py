@@ -361,9 +361,9 @@ class StepPipeline:
         assert len(scratches) >= self.INFLIGHT, "one scratch arena per batch in flight"
         self.LAG = self.INFLIGHT + 1        # the host completes batch k-LAG: INFLIGHT batches stay queued on the GPU
         NSLOT = self.NSLOT = self.LAG + 1
-        # with a ring the results of a call are not ordered on the context stream: a side stream per slot waits for the
-        # batch (misift_ctx_wait_batch) and carries the events
-        self.slot_streams = [torch.cuda.Stream(device=device) for _ in range(NSLOT)] if ring > 1 else None
+        # with a ring the results of a call are not ordered on the context stream: raw HIP events recorded behind each
+        # batch (misift_ctx_record_batch) mark completion.  (No waiting side streams: a stream that waits and shares a
+        # hardware queue with a pipeline holds that pipeline up.)
         REC_CAP = self.REC_CAP = MAX_PTS    # mainSift.cpp:58-67 capacity (32768 records per frame)
         self.packed = [torch.empty((B * REC_CAP * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
         self.cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(NSLOT)]
@@ -388,18 +388,19 @@ class StepPipeline:
             self.pts.data_ptr() if self.unfused else None,      # merged-octave path writes the packed array directly
             self.REC_CAP, self.cnts[slot].data_ptr(), self.cnts[slot][B:].data_ptr(), self.packed[slot].data_ptr()),
             "misift_extract_batch_packed_async")
-        done_stream = self.ctx_streams[ci]
-        if self.RING > 1:
-            done_stream = self.slot_streams[slot]
-            self.ctxs[ci].wait_batch(done_stream.cuda_stream)
         if self.comm is not None:
             self.comm.gather_post(slot, self.cnts[slot].data_ptr(), B, self.packed[slot].data_ptr(), ctx=self.ctxs[ci])
+        if self.RING > 1:
+            e = capi.HipEvent()
+            self.ctxs[ci].record_batch(e)
+            self.done_ev[slot] = e
         else:
-            ev = torch.cuda.Event()
-            ev.record(done_stream)
-            self.done_ev[slot] = ev
-        e = torch.cuda.Event(enable_timing=True)
-        e.record(done_stream)
+            if self.comm is None:
+                ev = torch.cuda.Event()
+                ev.record(self.ctx_streams[ci])
+                self.done_ev[slot] = ev
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(self.ctx_streams[ci])
         self.step_ev.append(e)
 
     def complete(self, k):
@@ -410,7 +411,10 @@ class StepPipeline:
                                              self.world * B * self.REC_CAP)
             return c
         with torch.cuda.stream(self.rb_stream):             # count read-back beside the running extraction
-            self.rb_stream.wait_event(self.done_ev[slot])
+            if self.RING > 1:
+                self.done_ev[slot].stream_wait(self.rb_stream.cuda_stream)
+            else:
+                self.rb_stream.wait_event(self.done_ev[slot])
             c = self.cnts[slot][:B].cpu().numpy()
         return c[None, :]
 
@@ -575,7 +579,7 @@ def main():
                     help="contexts (own stream, staging and scratch arena each) the steps rotate over = batches in flight on the "
                          "GPU.  4 measures ~8 %% more frames/s (profiles/r02_bench_contexts4.json) but every kernel's duration is "
                          "then stretched by its neighbours, so the per-kernel roofline is quoted on the default, 1")
-    ap.add_argument("--batches-in-flight", type=int, default=1,
+    ap.add_argument("--batches-in-flight", type=int, default=4,
                     help="pipelines INSIDE the context (misift_ctx_set_batches_in_flight): consecutive batches overlap on the GPU "
                          "behind ONE context.  The per-kernel roofline durations always come from a K = 1 child run")
     ap.add_argument("--match-n", type=int, default=100000)
@@ -597,7 +601,8 @@ def main():
     # completes batch k-2 only after batch k, the host cannot run ahead and the pipeline loses its depth (1 rank through
     # the communicator: 41 k instead of 51 k frames/s; the host-fed pipe wanders between 16 k and 24 k).  Must be set
     # before the HIP runtime initialises, i.e. before torch is imported; a caller's own setting wins.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    if not os.environ.get("BENCH_NO_QUEUE_DEFAULT"):     # developer switch: leave HIP's default of 4 hardware queues
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.pmc_child:
         return pmc_child()
     if args.emulate_ranks > 0:

@@ -80,6 +80,7 @@ SIGNATURES = {
     "misift_ctx_set_batches_in_flight": (_i, [_vp, _i]),
     "misift_ctx_get_batches_in_flight": (_i, [_vp]),
     "misift_ctx_wait_batch": (_i, [_vp, _vp]),
+    "misift_ctx_record_batch": (_i, [_vp, _vp]),
     "misift_test_elementary": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i]),
     "misift_comm_unique_id": (_i, [_vp]),
     "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
@@ -210,6 +211,10 @@ class Context:
     def set_batches_in_flight(self, k):
         """K pipelines behind this context (misift_ctx_set_batches_in_flight): consecutive packed-async calls overlap."""
         check(lib().misift_ctx_set_batches_in_flight(self.h, k), "misift_ctx_set_batches_in_flight")
+
+    def record_batch(self, event):
+        """Record a HipEvent behind the most recently enqueued batch of this context."""
+        check(lib().misift_ctx_record_batch(self.h, event.h), "misift_ctx_record_batch")
 
     def wait_batch(self, stream):
         """Make `stream` (a raw hipStream_t value) wait for the most recently enqueued batch of this context."""
@@ -470,6 +475,45 @@ class Context:
             nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
             out[nm] = {"total_ms": float(ms[i]), "calls": int(calls[i])}
         return out
+
+
+class HipEvent:
+    """A raw hipEvent_t (timing enabled) for the entry points that take one as void*: misift_ctx_record_batch."""
+    _hip = None
+
+    def __init__(self):
+        if HipEvent._hip is None:
+            HipEvent._hip = C.CDLL("libamdhip64.so")
+            HipEvent._hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+            HipEvent._hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+            HipEvent._hip.hipEventSynchronize.argtypes = [C.c_void_p]
+            HipEvent._hip.hipEventDestroy.argtypes = [C.c_void_p]
+        self.h = C.c_void_p()
+        if HipEvent._hip.hipEventCreate(C.byref(self.h)) != 0:
+            raise MisiftError("hipEventCreate failed")
+
+    def synchronize(self):
+        if HipEvent._hip.hipEventSynchronize(self.h) != 0:
+            raise MisiftError("hipEventSynchronize failed")
+
+    def stream_wait(self, stream):
+        """`stream` (raw hipStream_t value) waits for this event."""
+        if HipEvent._hip.hipStreamWaitEvent(C.c_void_p(stream), self.h, 0) != 0:
+            raise MisiftError("hipStreamWaitEvent failed")
+
+    def elapsed_time(self, later):
+        ms = C.c_float(0)
+        if HipEvent._hip.hipEventElapsedTime(C.byref(ms), self.h, later.h) != 0:
+            raise MisiftError("hipEventElapsedTime failed")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                HipEvent._hip.hipEventDestroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 COMM_ID_BYTES = 128

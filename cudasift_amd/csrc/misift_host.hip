@@ -414,6 +414,17 @@ static misift_ctx *result_ctx(misift_ctx *ctx)
 }
 hipStream_t misift_ctx_result_stream(misift_ctx *ctx) { return result_ctx(ctx)->stream; }
 
+// Record a caller-owned hipEvent_t behind the most recently enqueued batch of `ctx` (on the stream that batch runs on).
+// Unlike misift_ctx_wait_batch this adds no waiting stream: on a GPU whose hardware queues are oversubscribed a waiting
+// side stream can share a queue with a pipeline and hold it up.
+extern "C" int misift_ctx_record_batch(misift_ctx *ctx, void *hip_event)
+{
+  ARG_CHECK(ctx != nullptr && hip_event != nullptr);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipEventRecord((hipEvent_t)hip_event, result_ctx(ctx)->stream));
+  return MISIFT_OK;
+}
+
 // `stream` waits for the most recently enqueued batch of `ctx` (any K; with K = 1 the same as an event recorded on the
 // context stream now).
 extern "C" int misift_ctx_wait_batch(misift_ctx *ctx, void *stream)

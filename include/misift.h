@@ -286,14 +286,19 @@ int misift_match_rows(misift_ctx *ctx, void *d_pts1, int row_begin, int row_coun
  * batch runs beside the VALU-bound kernels of another and launch tails are filled (+8-9 % frames/s at K = 3-4 on 64 x
  * 1080p).  Contract with K > 1:
  *   - every call still starts behind whatever was enqueued on the context stream before it (a marker is recorded there);
- *   - its results are NOT ordered on the context stream: observe them with misift_ctx_wait_batch (makes a stream of the
- *     caller's wait for the most recent batch), misift_gather_post (marks the most recent batch) or misift_ctx_sync;
+ *   - its results are NOT ordered on the context stream: observe them with misift_ctx_record_batch (an event of the
+ *     caller's behind the most recent batch), misift_ctx_wait_batch (a stream of the caller's waits for it),
+ *     misift_gather_post (marks the most recent batch) or misift_ctx_sync;
  *   - the scratch arena and the output buffers of a call must stay untouched until that batch is done: rotate >= K sets.
  * K = 1 (default) is the plain in-order context.  Also MISIFT_BATCHES_IN_FLIGHT at context creation.  Changing K drains
  * the context. */
 int misift_ctx_set_batches_in_flight(misift_ctx *ctx, int k);
 int misift_ctx_get_batches_in_flight(misift_ctx *ctx);
 int misift_ctx_wait_batch(misift_ctx *ctx, void *stream);
+/* Record the caller's hipEvent_t (passed as void*) behind the most recent batch, on the stream that batch runs on; the
+ * caller then queries / waits on the event as it likes.  Preferable to misift_ctx_wait_batch when many side streams would
+ * oversubscribe the hardware queues (a waiting stream that shares a queue with a pipeline holds that pipeline up). */
+int misift_ctx_record_batch(misift_ctx *ctx, void *hip_event);
 
 /* ------------------------------------------------------------ multi-GPU
  * The reference is single-GPU (InitCuda picks ONE device, cudaSiftH.cu:19-37); BASELINE configs 4 and 5 shard
