@@ -158,6 +158,30 @@ void orc_laplace_taps(int numOctaves, float *kernel)
   orc_laplace_taps_rec(numOctaves, 0.0f, kernel);   /* cudaSiftH.cu:110 */
 }
 
+/* ---------------------------------------------------- per-thread work buffers
+ * The big work buffers of an extraction (scratch arena 101 MB, Laplace intermediate 66 MB, filter rows 8 MB at 1080p)
+ * are kept per thread and re-used from frame to frame.  malloc/free would serve them with mmap/munmap (they exceed the
+ * 64 MB heaps of glibc's per-thread arenas whatever M_MMAP_THRESHOLD says), and with one frame per core every munmap
+ * is a TLB shoot-down interrupt on all the cores the process runs on: that, not memory bandwidth, is what held the
+ * frame-parallel CPU baseline to 0.2 frames/s per core on a 256-core host. */
+#define ORC_TLS_SLOTS 4
+static __thread void *tls_ptr[ORC_TLS_SLOTS];
+static __thread size_t tls_cap[ORC_TLS_SLOTS];
+static void *tls_buf(int slot, size_t bytes)
+{
+  if (tls_cap[slot] < bytes) {
+    free(tls_ptr[slot]);
+    tls_ptr[slot] = malloc(bytes);
+    tls_cap[slot] = tls_ptr[slot] ? bytes : 0;
+  }
+  return tls_ptr[slot];
+}
+/* release the calling thread's buffers (the test-suite's sanitizer flavour calls it; worker threads keep theirs) */
+void orc_release_thread_buffers(void)
+{
+  for (int i = 0; i < ORC_TLS_SLOTS; i++) { free(tls_ptr[i]); tls_ptr[i] = NULL; tls_cap[i] = 0; }
+}
+
 /* ---------------------------------------------------- separable filtering */
 
 /* Symmetric 9-tap dot product, kc[0] = centre tap, p_j = (value at -j) + (value at +j).
@@ -193,7 +217,7 @@ void orc_lowpass(const float *src, int w, int h, int spitch, float *dst, int dpi
   float k9[9], kc[5];
   orc_lowpass_taps(sigma, k9);
   for (int j = 0; j <= 4; j++) kc[j] = k9[4 - j];   /* kc[0]=k[4] centre … kc[4]=k[0] */
-  float *tmp = (float *)malloc(sizeof(float) * (size_t)w * h);
+  float *tmp = (float *)tls_buf(0, sizeof(float) * (size_t)w * h);
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; y++) {
     const float *r = src + (size_t)y * spitch;
@@ -211,7 +235,6 @@ void orc_lowpass(const float *src, int w, int h, int spitch, float *dst, int dpi
 #undef T
     }
   }
-  free(tmp);
 }
 
 /* ScaleDown: 5-tap Gaussian (variance 0.5) + 2x decimation, horizontal then vertical.
@@ -222,7 +245,7 @@ void orc_scaledown(const float *src, int w, int h, int spitch, float *dst, int d
   orc_scaledown_taps(0.5f, k);
   const float k0 = k[0], k1 = k[1], k2 = k[2];
   int w2 = w / 2, h2 = h / 2;
-  float *tmp = (float *)malloc(sizeof(float) * (size_t)(w2 > 0 ? w2 : 1) * h);
+  float *tmp = (float *)tls_buf(1, sizeof(float) * (size_t)(w2 > 0 ? w2 : 1) * h);
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; y++) {
     const float *r = src + (size_t)y * spitch;
@@ -244,7 +267,6 @@ void orc_scaledown(const float *src, int w, int h, int spitch, float *dst, int d
 #undef T
     }
   }
-  free(tmp);
 }
 
 /* ScaleUp: cudaSiftD.cu:170-190.  dst is (2w, 2h). */
@@ -269,7 +291,7 @@ void orc_scaleup(const float *src, int w, int h, int spitch, float *dst, int dpi
 void orc_laplace(const float *base, int w, int h, int pitch, const float *taps, int octave, float *dog)
 {
   const float *kt = taps + octave * 12 * 16;
-  float *vbuf = (float *)malloc(sizeof(float) * (size_t)LAPLACE_S * w * h);
+  float *vbuf = (float *)tls_buf(2, sizeof(float) * (size_t)LAPLACE_S * w * h);
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; y++) {
     for (int x = 0; x < w; x++) {
@@ -294,7 +316,6 @@ void orc_laplace(const float *base, int w, int h, int pitch, const float *taps, 
       }
     }
   }
-  free(vbuf);
 }
 
 /* 2^x as a written-out fmaf chain (cephes exp2f: split off the nearest integer, degree-6 kernel on [-0.5, 0.5], scale
@@ -875,7 +896,7 @@ int orc_extract(const float *img, int width, int height, int pitch, int numOctav
       sizeTmp += (size_t)nd * hh * ialign_up(ww, 128);
     }
   }
-  float *memoryTmp = (float *)malloc(sizeof(float) * total);
+  float *memoryTmp = (float *)tls_buf(3, sizeof(float) * total);
   float *memorySub = memoryTmp + sizeTmp;
   float *lowImg = memorySub;
   orc_job_t job;
@@ -900,7 +921,6 @@ int orc_extract(const float *img, int width, int height, int pitch, int numOctav
     }
   }
   if (counters17) memcpy(counters17, job.cnt, sizeof(job.cnt));
-  free(memoryTmp);
   return numPts;
 }
 
@@ -935,7 +955,9 @@ void orc_extract_batch(const float *imgs, int nframes, int width, int height, in
   omp_set_max_active_levels(2);
   if (outer_threads < 1) outer_threads = 1;
   if (inner_threads < 1) inner_threads = 1;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(outer_threads)
+  /* static: frame f runs on thread f % outer_threads, so a warm-up batch of outer_threads frames touches every thread's
+   * work buffers once */
+#pragma omp parallel for schedule(static, 1) num_threads(outer_threads)
 #endif
   for (int f = 0; f < nframes; f++) {
 #ifdef _OPENMP
