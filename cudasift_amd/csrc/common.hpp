@@ -144,25 +144,51 @@ __device__ __forceinline__ float4 load_quad(const float *row, int q, int width, 
 // branches in the streaming loops.
 struct QuadCol {
   int off;      // float offset of the clamped quad within a row
-  int edge;     // -1: quad lies left of the image, +1: right of it, 0: inside
+  int edge;     // -1: quad lies left of the image, +1: right of it, 0: inside;
+                // ragged widths (width % 4 != 0, MODE 2): 2 = the quad that holds the last column, 3 = right of it
+  int rem;      // width % 4 (MODE 2)
 };
 __device__ __forceinline__ QuadCol make_quadcol(int q, int width)
 {
-  const int nq = width >> 2;
+  const int nq = width >> 2;                  // full quads
+  const int rem = width & 3;
   QuadCol c;
-  c.edge = q < 0 ? -1 : (q > nq - 1 ? 1 : 0);
-  c.off = 4 * clampi(q, 0, nq - 1);
+  c.rem = rem;
+  if (rem == 0) {
+    c.edge = q < 0 ? -1 : (q > nq - 1 ? 1 : 0);
+    c.off = 4 * clampi(q, 0, nq - 1);
+  } else {                                    // the partial quad nq exists; quads right of it re-load it
+    c.edge = q < 0 ? -1 : (q == nq ? 2 : (q > nq ? 3 : 0));
+    c.off = 4 * clampi(q, 0, nq);
+  }
   return c;
 }
-template <bool FAST>
+// clamp-to-edge of a quad loaded at a clamped position.  MODE 1: width % 4 == 0.  MODE 2: any width — the partial quad
+// is read as a whole dwordx4 (the up-to-3 floats past the last column lie inside the row pitch: the launchers check
+// pitch >= roundup4(width)) and its invalid elements, like every quad right of it, take the value of column width-1.
+template <int MODE>
+__device__ __forceinline__ float4 clamp_quad(float4 v, const QuadCol &c)
+{
+  if (c.edge < 0) v = make_float4(v.x, v.x, v.x, v.x);
+  if (MODE == 2) {
+    if (c.edge == 1) v = make_float4(v.w, v.w, v.w, v.w);
+    if (c.edge >= 2) {
+      const float e = c.rem == 1 ? v.x : (c.rem == 2 ? v.y : v.z);
+      if (c.edge == 3 || c.rem < 2) v.y = e;
+      if (c.edge == 3 || c.rem < 3) v.z = e;
+      v.w = e;
+      if (c.edge == 3) v.x = e;
+    }
+  } else {
+    if (c.edge > 0) v = make_float4(v.w, v.w, v.w, v.w);
+  }
+  return v;
+}
+// MODE: 0 = generic (scalar edge loads, any alignment), 1 = fast (bool true), 2 = fast with ragged widths
+template <int MODE>
 __device__ __forceinline__ float4 load_quad_t(const float *row, int q, int width, bool aligned, const QuadCol &c)
 {
-  if (FAST) {
-    float4 v = *reinterpret_cast<const float4 *>(row + c.off);
-    if (c.edge < 0) v = make_float4(v.x, v.x, v.x, v.x);
-    if (c.edge > 0) v = make_float4(v.w, v.w, v.w, v.w);
-    return v;
-  }
+  if (MODE) return clamp_quad<MODE>(*reinterpret_cast<const float4 *>(row + c.off), c);
   return load_quad(row, q, width, aligned);
 }
 
@@ -179,15 +205,12 @@ __device__ __forceinline__ float4 load_quad(const unsigned char *row, int q, int
   return make_float4((float)row[clampi(x, 0, w1)], (float)row[clampi(x + 1, 0, w1)], (float)row[clampi(x + 2, 0, w1)],
                      (float)row[clampi(x + 3, 0, w1)]);
 }
-template <bool FAST>
+template <int MODE>
 __device__ __forceinline__ float4 load_quad_t(const unsigned char *row, int q, int width, bool aligned, const QuadCol &c)
 {
-  if (FAST) {
+  if (MODE) {
     const uchar4 u = *reinterpret_cast<const uchar4 *>(row + c.off);
-    float4 v = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
-    if (c.edge < 0) v = make_float4(v.x, v.x, v.x, v.x);
-    if (c.edge > 0) v = make_float4(v.w, v.w, v.w, v.w);
-    return v;
+    return clamp_quad<MODE>(make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w), c);
   }
   return load_quad(row, q, width, aligned);
 }

@@ -549,7 +549,7 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
   }
 }
 
-template <bool FAST, typename TAPS>
+template <int FAST, typename TAPS>
 __device__ __forceinline__ void scan_strip(const float *img, int width, int height, int pitch, int q, int lane,
                                            int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
                                            unsigned *list, unsigned cand_cap, int octave, bool al)
@@ -602,7 +602,7 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
 // nothing by itself: the kernel is bound by VALU instruction issue and a SIMD is saturated from 2-3 wavefronts on
 // (DESIGN.md section 4).  What it does save is the register rotation of the window (-3.4 % instructions).  The row
 // loop is unrolled nine times so that every slot is an immediate offset of the ds_read_b128 / ds_write_b128.
-template <bool FAST, typename TAPS>
+template <int FAST, typename TAPS>      // 0 = generic loads, 1 = fast (width % 4 == 0), 2 = fast with ragged widths
 __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int height, int pitch, int q, int lane,
                                                 int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
                                                 unsigned *list, unsigned cand_cap, int octave, bool al, float4 *mine)
@@ -699,7 +699,7 @@ struct ScanAllGeom {
 #ifndef SCAN_OCC
 #define SCAN_OCC (SCAN_RING ? 4 : 3)
 #endif
-template <bool FAST>
+template <int FAST>
 __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
                                                               AllTaps taps, float thresh,
                                                               unsigned *__restrict__ counters,
@@ -1145,7 +1145,7 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
   ScanAllGeom G;
   memset(&G, 0, sizeof(G));
   G.nlev = lev_end - lev_begin; G.nframes = P.nframes; G.frame_stride = P.frame_stride;
-  bool fast = (is_aligned16(scratch, 4) && (P.frame_stride & 3) == 0);
+  bool fast = (is_aligned16(scratch, 4) && (P.frame_stride & 3) == 0), ragged = false;
   long long items = 0;
   unsigned cand_stride = 0;
   for (int o = 1; o <= P.noct; o++) cand_stride += P.o[o].cand_cap;
@@ -1177,17 +1177,21 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
     S.nsegs = (L.h + seg - 1) / seg;
     S.item_begin = items;
     items += (long long)P.nframes * S.nstrips * S.nsegs;
-    if ((L.w & 3) != 0 || (L.p & 3) != 0 || (L.img_off & 3) != 0) fast = false;
+    if ((L.p & 3) != 0 || (L.img_off & 3) != 0) fast = false;
+    if ((L.w & 3) != 0) ragged = true;          // some level's width is not a multiple of 4 (e.g. 1000 -> 250 -> 125)
   }
   G.total_items = items;
   const AllTaps at = pack_taps(taps, P.noct);
   const dim3 grid((unsigned)((items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
   LaunchScope ls(ctx, "dog_scan");
-  if (fast)
-    hipLaunchKernelGGL(dog_scan_all_kernel<true>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
+  if (fast && !ragged)
+    hipLaunchKernelGGL(dog_scan_all_kernel<1>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
+                       ctx->d_counters, ctx->d_cand);
+  else if (fast)          // pyramid levels are ours (pitch % 128 == 0): ragged widths keep the dwordx4 row loads (r03)
+    hipLaunchKernelGGL(dog_scan_all_kernel<2>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
                        ctx->d_counters, ctx->d_cand);
   else
-    hipLaunchKernelGGL(dog_scan_all_kernel<false>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
+    hipLaunchKernelGGL(dog_scan_all_kernel<0>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
                        ctx->d_counters, ctx->d_cand);
   return ls.finish();
 }

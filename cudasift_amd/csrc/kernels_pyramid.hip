@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256, 4) void lowpass_kernel(const SRC *__restrict__
 // Lanes 1..62 hold valid prefiltered quads, lanes 2..61 store (the decimation needs both neighbours),
 // so a strip advances by 60 quads.
 #define FUSED_OUT_LANES 60
-template <typename SRC>
+// MODE 1: width % 4 == 0; MODE 2: any width (ragged last quad, see clamp_quad in common.hpp).
+template <typename SRC, int MODE>
 __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restrict__ src, StripGeom g,
                                                               float *__restrict__ dst, int dpitch,
                                                               long long dst_frame_stride, Taps5 t,
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
   const float d0 = t5.k[0], d1 = t5.k[1], d2 = t5.k[2];   // t5.k[2] = centre tap (reference order)
   const QuadCol qc = make_quadcol(q, g.width);
   auto ldraw = [&](int y) -> float4 {
-    return load_quad_t<true>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, true, qc);
+    return load_quad_t<MODE>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, true, qc);
   };
   auto hfilt = [&](const float4 c) -> float4 {
     const float4 l = quad_from_left(c);
@@ -211,7 +212,14 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
     o.z = conv9_expr(k0, k1, k2, k3, k4, w4.z, w3.z + w5.z, w2.z + w6.z, w1.z + w7.z, w0.z + w8.z);
     o.w = conv9_expr(k0, k1, k2, k3, k4, w4.w, w3.w + w5.w, w2.w + w6.w, w1.w + w7.w, w0.w + w8.w);
     if (writer && y >= y0 && y < y1) *reinterpret_cast<float4 *>(out + (size_t)y * dpitch + 4 * q) = o;
-    const float2 hd = hdec(o);
+    float4 oc = o;                                         // the prefiltered row as ScaleDown's clamped reads see it:
+    if (MODE == 2 && qc.edge == 2) {                       // columns past width-1 take the value of column width-1
+      const float e = qc.rem == 1 ? o.x : (qc.rem == 2 ? o.y : o.z);
+      if (qc.rem < 2) oc.y = e;
+      if (qc.rem < 3) oc.z = e;
+      oc.w = e;
+    }
+    const float2 hd = hdec(oc);
     a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = hd;
     if (y == 0) { a2 = hd; a3 = hd; }                     // rows -2, -1 clamp to row 0
     if ((y & 1) == 0 && y >= y0 + 2) emit((y - 2) >> 1, a0, a1, a2, a3, a4);
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
 // ---------------------------------------------------------------- ScaleDown
 // 5-tap Gaussian (variance 0.5) + 2x decimation: horizontal then vertical.
 // Geometry `g` describes the SOURCE image; strips/segments tile the OUTPUT (w/2, h/2).
-template <bool FAST>
+template <int FAST>      // 0 = generic, 1 = fast (width % 4 == 0), 2 = fast with a ragged last quad
 __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict__ src, StripGeom g,
                                                         float *__restrict__ dst, int dpitch,
                                                         long long dst_frame_stride, Taps5 t, int src_aligned,
@@ -358,7 +366,7 @@ int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const Stri
                         long long dst2_frame_stride, const float k5[5], int *done)
 {
   *done = 0;
-  if ((g.width & 3) || g.height < 8 || (g.seg_rows & 7)) return MISIFT_OK;
+  if (g.height < 8 || (g.seg_rows & 7)) return MISIFT_OK;
   const int dal = is_aligned16(dst, dpitch) && (dst_frame_stride & 3) == 0;
   const int d2al = (((uintptr_t)dst2) & 7) == 0 && (dpitch2 & 1) == 0 && (dst2_frame_stride & 1) == 0;
   int sal;
@@ -369,14 +377,22 @@ int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const Stri
   for (int j = 0; j <= 4; j++) t.k[j] = k9[4 - j];
   for (int j = 0; j < 5; j++) t5.k[j] = k5[j];
   LaunchScope ls(ctx, "lowpass_down");
-  if (src_u8)
-    hipLaunchKernelGGL(lowpass_down_kernel<unsigned char>, grid_for(g), dim3(256), 0, ctx->stream,
-                       static_cast<const unsigned char *>(src), g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2,
-                       dst2_frame_stride, t5);
-  else
-    hipLaunchKernelGGL(lowpass_down_kernel<float>, grid_for(g), dim3(256), 0, ctx->stream,
-                       static_cast<const float *>(src), g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2,
-                       dst2_frame_stride, t5);
+  // widths that are not a multiple of 4 (r03): the same kernel with the ragged-quad loads; the aligned rows checked
+  // above make the row pitch a multiple of 4, so the partial quad's dwordx4 stays inside the row
+  const bool rag = (g.width & 3) != 0;
+  if (src_u8) {
+    const unsigned char *s8 = static_cast<const unsigned char *>(src);
+    if (rag) hipLaunchKernelGGL((lowpass_down_kernel<unsigned char, 2>), grid_for(g), dim3(256), 0, ctx->stream, s8, g, dst,
+                                dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5);
+    else hipLaunchKernelGGL((lowpass_down_kernel<unsigned char, 1>), grid_for(g), dim3(256), 0, ctx->stream, s8, g, dst,
+                            dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5);
+  } else {
+    const float *sf = static_cast<const float *>(src);
+    if (rag) hipLaunchKernelGGL((lowpass_down_kernel<float, 2>), grid_for(g), dim3(256), 0, ctx->stream, sf, g, dst, dpitch,
+                                dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5);
+    else hipLaunchKernelGGL((lowpass_down_kernel<float, 1>), grid_for(g), dim3(256), 0, ctx->stream, sf, g, dst, dpitch,
+                            dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5);
+  }
   *done = 1;
   return ls.finish();
 }
@@ -390,10 +406,13 @@ int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, floa
   const int dal = is_aligned16(dst, dpitch) && (dst_frame_stride & 3) == 0;
   LaunchScope ls(ctx, "scaledown");
   if (sal && (g.width & 3) == 0)
-    hipLaunchKernelGGL(scaledown_kernel<true>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+    hipLaunchKernelGGL(scaledown_kernel<1>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+                       dst_frame_stride, t, sal, dal);
+  else if (sal)                                   // ragged width: still one dwordx4 per quad (r03)
+    hipLaunchKernelGGL(scaledown_kernel<2>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
                        dst_frame_stride, t, sal, dal);
   else
-    hipLaunchKernelGGL(scaledown_kernel<false>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
+    hipLaunchKernelGGL(scaledown_kernel<0>, grid_for(g), dim3(256), 0, ctx->stream, src, g, dst, dpitch,
                        dst_frame_stride, t, sal, dal);
   return ls.finish();
 }

@@ -500,10 +500,11 @@ def test_pipe_error_paths(ctx):
 
 
 @pytest.mark.parametrize("h,w", [(1080, 1920), (960, 1280), (135, 240), (37, 260), (8, 4), (270, 480), (539, 484),
-                                 (67, 1024)])
+                                 (67, 1024), (135, 241), (64, 1281), (270, 483), (33, 17), (100, 250), (77, 999)])
 def test_fused_lowpass_scaledown_bit_exact(ctx, h, w):
     """lowpass_down_kernel == LowPass then ScaleDown (oracle), bit for bit: strip seams (w > 240), segment
-    seams, odd and even heights (bottom clamp), tiny images."""
+    seams, odd and even heights (bottom clamp), tiny images; since r03 also widths that are not a multiple of 4 (the
+    ragged-quad instantiation: remainders 1, 2 and 3, one strip and several)."""
     rng = np.random.default_rng(h * 10007 + w)
     img = (rng.random((h, w), dtype=np.float32) * 255.0).astype(np.float32)
     lp, dn = ctx.lowpass_scaledown(img, 1.0)
@@ -983,3 +984,25 @@ def test_device_elementary_functions_have_the_oracles_bits(ctx):
     s, c = ctx.test_elementary(3, x)
     so, co = orc().det_eval(3, x)
     assert np.array_equal(s.view(np.uint32), so.view(np.uint32)) and np.array_equal(c.view(np.uint32), co.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,noct", [(1000, 750, 5), (1283, 721, 5), (642, 483, 4), (250, 187, 3)])
+def test_extract_ragged_widths_take_the_fast_kernels(ctx, w, h, noct):
+    """Widths that are not a multiple of 4 at SOME pyramid level (1000 -> 500 -> 250 -> 125 -> 62; 1283 at every level):
+    r02 sent the whole image through the generic kernels (separate LowPass + ScaleDown, scalar edge loads: 0.73x).  r03:
+    the fused prefilter, the ScaleDowns and the merged-octave scan keep their dwordx4 row loads with a ragged last quad —
+    the profile shows lowpass_down (not lowpass) — and the records equal the oracle's."""
+    from cudasift_amd import capi
+    imgs = np.stack([synth_frame(8200 + f, w, h) for f in range(2)])
+    c = capi.Context(0)
+    try:
+        c.profile_enable(True)
+        pts, n = c.extract_batch(imgs, num_octaves=noct, thresh=2.5, max_pts=16384)
+        prof = c.profile_read()
+        assert "lowpass_down" in prof and "lowpass" not in prof, prof.keys()
+    finally:
+        c.close()
+    for f in range(2):
+        ref, nref, _ = orc().extract(imgs[f], noct, 1.0, 2.5, max_pts=16384)
+        assert n[f] == nref and nref > 100
+        compare_points(ref[:nref], pts[f, :nref], "ragged_%dx%d_f%d" % (w, h, f), record)
