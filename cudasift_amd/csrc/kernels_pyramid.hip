@@ -191,7 +191,14 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
       float2 o;
       o.x = vcomb(a0.x, a1.x, a2.x, a3.x, a4.x);
       o.y = vcomb(a0.y, a1.y, a2.y, a3.y, a4.y);
-      *reinterpret_cast<float2 *>(out2 + (size_t)Y * dpitch2 + 2 * q) = o;
+      float *d2 = out2 + (size_t)Y * dpitch2 + 2 * q;
+      if (MODE == 2) {               // ragged width: the lane of the last quad may own only one (or no) decimated column,
+        const int w2o = g.width >> 1;     // and the next one may already be the neighbouring row (pitch == width/2)
+        if (2 * q + 1 < w2o) *reinterpret_cast<float2 *>(d2) = o;
+        else if (2 * q < w2o) d2[0] = o.x;
+      } else {
+        *reinterpret_cast<float2 *>(d2) = o;
+      }
     }
   };
 

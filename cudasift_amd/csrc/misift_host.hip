@@ -1125,8 +1125,39 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
     if (rc) { ctx->opt.fused = fused_saved; return rc; }
     if (!ovf) break;
     if (ctx->opt.fused && attempt == 0) {
+      // Exact re-run with the dense kernels — of the frames whose candidate list overflowed ONLY (r02 redid the whole
+      // batch at 0.3x the fused rate for one bad frame).  Every run of consecutive overflowed frames is one sub-call on
+      // its own slices of the inputs, the scratch arena and the output; its counters are merged into the batch's.
+      std::vector<unsigned> merged(ctx->h_counters, ctx->h_counters + (size_t)CNT_STRIDE * nframes);
+      const size_t S = misift_scratch_floats(width, height, num_octaves, scale_up);
+      const size_t esz = src_u8 ? 1 : sizeof(float);
       ctx->opt.fused = 0;
-      continue;
+      bool ovf2 = false;
+      for (int f0 = 0; f0 < nframes && !rc;) {
+        if (!merged[(size_t)f0 * CNT_STRIDE + CNT_CANDOVF]) { f0++; continue; }
+        int f1 = f0 + 1;
+        while (f1 < nframes && merged[(size_t)f1 * CNT_STRIDE + CNT_CANDOVF]) f1++;
+        const int nr = f1 - f0;
+        rc = misift_extract_enqueue(ctx, (const char *)d_imgs + (size_t)f0 * frame_stride * esz, src_u8, nr, frame_stride, width,
+                                    height, pitch, num_octaves, init_blur, thresh, lowest_scale, scale_up,
+                                    d_scratch ? d_scratch + (size_t)f0 * S : nullptr, pts + (size_t)f0 * max_pts, max_pts);
+        if (!rc) rc = read_counts(ctx, nr, num_octaves, max_pts, num_pts_out + f0, &ovf2);
+        if (!rc) memcpy(&merged[(size_t)f0 * CNT_STRIDE], ctx->h_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nr);
+        f0 = f1;
+      }
+      ctx->opt.fused = fused_saved;
+      if (rc) return rc;
+      if (ovf2) {
+        misift_set_error("candidate list overflow: more than %zu scale-space extrema in one octave of one frame "
+                         "(raise thresh)", ctx->cand_cap);
+        return MISIFT_ENOMEM;
+      }
+      // the batch's counters (misift_get_counters) are the merged ones
+      memcpy(ctx->h_counters, merged.data(), sizeof(unsigned) * merged.size());
+      HIP_TRY(hipMemcpyAsync(ctx->d_counters, ctx->h_counters, sizeof(unsigned) * merged.size(), hipMemcpyHostToDevice,
+                             ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      return MISIFT_OK;
     }
     ctx->opt.fused = fused_saved;
     misift_set_error("candidate list overflow: more than %zu scale-space extrema in one octave of one frame "

@@ -585,6 +585,33 @@ def test_candidate_overflow_falls_back_to_dense_kernels(ctx):
     assert ctx.download(cnt, (1,), np.int32)[0] == -1
 
 
+def test_overflow_rerun_touches_only_the_overflowed_frames(ctx):
+    """A batch in which frames 1, 2 and 5 of 6 flood their candidate lists: the exact dense re-run covers those frames
+    only (two runs of consecutive frames -> 2 detect launches per octave, not one over the whole batch), every frame
+    equals the oracle, and the 17 counters of every frame — re-run or not — are the oracle's."""
+    from cudasift_amd import capi
+    h, w, noct, th = 256, 256, 3, 0.05
+    normal = [np.clip(np.rint(synth_frame(8800 + i, w, h)), 0, 255).astype(np.float32) for i in range(3)]
+    noise = [_noise_u8(h, w, 21 + i).astype(np.float32) for i in range(3)]
+    frames = np.stack([normal[0], noise[0], noise[1], normal[1], normal[2], noise[2]])
+    c = capi.Context(0)
+    try:
+        c.set_options(fused=1)
+        c.profile_enable(True)
+        pts, n = c.extract_batch(frames, num_octaves=noct, thresh=th, max_pts=32768)
+        prof = c.profile_read()
+        counters = np.stack([c.get_counters(f) for f in range(len(frames))])
+    finally:
+        c.close()
+    assert prof["detect"]["calls"] == 2 * noct, prof["detect"]             # frames {1,2} and {5}: two sub-calls
+    assert prof["dog_scan"]["calls"] >= 1
+    for f in range(len(frames)):
+        ref, nref, cref = orc().extract(frames[f], num_octaves=noct, thresh=th, max_pts=32768)
+        assert n[f] == nref and np.array_equal(counters[f], cref), f
+        compare_points(ref[:nref], pts[f, :nref], "overflow_selective_f%d" % f, record)
+    assert n[1] > 2000 and n[0] < 2000
+
+
 def test_pipe_overflow_falls_back(ctx):
     """The same inside the pipeline: the overflowed batch is redone when it is collected; the batches around
     it are untouched."""
