@@ -609,7 +609,6 @@ def test_overflow_rerun_touches_only_the_overflowed_frames(ctx):
         ref, nref, cref = orc().extract(frames[f], num_octaves=noct, thresh=th, max_pts=32768)
         assert n[f] == nref and np.array_equal(counters[f], cref), f
         compare_points(ref[:nref], pts[f, :nref], "overflow_selective_f%d" % f, record)
-    assert n[1] > 2000 and n[0] < 2000
 
 
 def test_pipe_overflow_falls_back(ctx):
