@@ -17,23 +17,25 @@
  *   ExtractSift     cudaSiftH.cu:72-232    (octave recursion, counter protocol, numPts rule)
  *   MatchSiftData   matching.cu:289-397, :1090-1206 (CleanMatches + FindMaxCorr10)
  *
- * PARITY PINNING.  The reference ships no golden vectors, known-answer tests or
- * fixtures for extraction and cannot be built here (CUDA), so
- * the EXTRACTION part of this oracle is "parity unpinned": it is checked only
- * against closed forms, the tap table of SURVEY Appendix C and independent cross
- * implementations of every stage (tests/test_oracle_cpu.py: scipy separable filters,
- * scipy rank filters + numpy.linalg for detection/refinement, float64 numpy for
- * orientation and descriptor).  The MATCHER part is pinned against
- * the reference's own CPU routines MatchC1/MatchC3 (match.cu:57-130), compiled
- * from the reference tree into oracle/_ref/ by oracle/build_ref.sh.
+ * PARITY PINNING (round 3: pinned).  The reference ships no golden vectors, known-answer tests or fixtures for
+ * extraction and its CUDA cannot be built here — but its kernels and host code CAN be executed:
+ * oracle/build_ref.sh compiles the reference's own cudaImage.cu, cudaSiftH.cu (+ cudaSiftD.cu) and matching.cu where
+ * they lie against a CPU SIMT emulation of the CUDA subset they use (oracle/simt_emul.h) into
+ * oracle/_ref/libcudasift_refemul_{fast,off}.so.  tests/test_refemul_cpu.py holds this restatement against that library
+ * (all 17 counters and the keypoint set identical; separable filters, DoG planes, positions, match scores, homographies
+ * the same bits in the contraction flavour; 1-2 ulp / 0.01 degrees where the reference calls hardware math functions),
+ * and against tests/golden/refemul_golden.npz, vectors the emulated reference produced (they travel to the GPU box).
+ * The MATCHER is additionally pinned to the reference's CPU routines MatchC1/MatchC3 (match.cu:57-130) and
+ * ImproveHomography to the reference's own geomFuncs.cpp, both compiled by the same script.  The independent
+ * cross-implementations of tests/test_oracle_cpu.py (scipy separable filters, scipy rank filters + numpy.linalg for
+ * detection / refinement, float64 numpy for orientation and descriptor) stay as a second line.
  *
- * Arithmetic conventions (shared with the HIP kernels so the DoG pyramid and
- * every discrete decision agree bit for bit): IEEE fp32, compiled with
- * -ffp-contract=off; the separable filters use the explicit fmaf chains written
- * below (centre tap first, then outward — the order of the reference
- * expressions with nvcc's default multiply-add contraction); everything else is
- * plain, uncontracted arithmetic — contract mode ORC_CONTRACT_PLAIN, the one the
- * HIP kernels implement and all parity tests use.
+ * Arithmetic conventions (shared with the HIP kernels so the DoG pyramid and every discrete decision agree bit for
+ * bit): IEEE fp32, compiled with -ffp-contract=off; the separable filters use the explicit fmaf chains written below —
+ * conv9 where the reference accumulates a running sum (LaplaceMulti), conv9_expr where it writes one expression
+ * (LowPass, ScaleDown: the left product fused, the right one rounded, as a contracting compiler does; bit-identical to
+ * the reference source built with contraction); everything else is plain, uncontracted arithmetic — contract mode
+ * ORC_CONTRACT_PLAIN, the one the HIP kernels implement and all parity tests use.
  *
  * ERROR BAR ON THAT CHOICE.  nvcc (-fmad=true by default) would also contract the
  * multiply-adds of the refinement, orientation and descriptor code.  Which ones
