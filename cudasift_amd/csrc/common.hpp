@@ -147,6 +147,9 @@ struct QuadCol {
   int edge;     // -1: quad lies left of the image, +1: right of it, 0: inside;
                 // ragged widths (width % 4 != 0, MODE 2): 2 = the quad that holds the last column, 3 = right of it
   int rem;      // width % 4 (MODE 2)
+  int wave_has_edge;   // wave-uniform: some lane of this wavefront holds a quad outside / on the ragged edge of the image.
+                       // Only the first and the last strip of a row do; everywhere else the eight selects of the
+                       // clamp are skipped by a scalar branch (r03: they were 9 of the 130 VALU of a lowpass_down row)
 };
 __device__ __forceinline__ QuadCol make_quadcol(int q, int width)
 {
@@ -161,6 +164,7 @@ __device__ __forceinline__ QuadCol make_quadcol(int q, int width)
     c.edge = q < 0 ? -1 : (q == nq ? 2 : (q > nq ? 3 : 0));
     c.off = 4 * clampi(q, 0, nq);
   }
+  c.wave_has_edge = __builtin_amdgcn_readfirstlane(__any(c.edge != 0) ? 1 : 0);
   return c;
 }
 // clamp-to-edge of a quad loaded at a clamped position.  MODE 1: width % 4 == 0.  MODE 2: any width — the partial quad
@@ -188,7 +192,11 @@ __device__ __forceinline__ float4 clamp_quad(float4 v, const QuadCol &c)
 template <int MODE>
 __device__ __forceinline__ float4 load_quad_t(const float *row, int q, int width, bool aligned, const QuadCol &c)
 {
-  if (MODE) return clamp_quad<MODE>(*reinterpret_cast<const float4 *>(row + c.off), c);
+  if (MODE) {
+    float4 v = *reinterpret_cast<const float4 *>(row + c.off);
+    if (c.wave_has_edge) v = clamp_quad<MODE>(v, c);
+    return v;
+  }
   return load_quad(row, q, width, aligned);
 }
 
@@ -210,7 +218,9 @@ __device__ __forceinline__ float4 load_quad_t(const unsigned char *row, int q, i
 {
   if (MODE) {
     const uchar4 u = *reinterpret_cast<const uchar4 *>(row + c.off);
-    return clamp_quad<MODE>(make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w), c);
+    float4 v = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+    if (c.wave_has_edge) v = clamp_quad<MODE>(v, c);
+    return v;
   }
   return load_quad(row, q, width, aligned);
 }

@@ -118,11 +118,125 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
     }
   };
 
+#ifndef MT_PIPE_EPILOGUE
+#define MT_PIPE_EPILOGUE 1
+#endif
+#ifndef MT_EARLY_STORE
+#define MT_EARLY_STORE 1
+#endif
+#ifndef MT_EARLY_STORE_AT
+#define MT_EARLY_STORE_AT 10
+#endif
   if (st0 < st1) {
     gload(st0);
     lstore(0);
   }
   __syncthreads();
+#if MT_PIPE_EPILOGUE
+  // Software pipeline over the super-tiles (r03): the top-2 update of tile t-1 (128 VALU instructions on its 32 finished
+  // accumulator registers) is issued BETWEEN the MFMAs of tile t instead of after them, so a wavefront's matrix pipe
+  // never waits for its own epilogue.  Two accumulator sets alternate (the loop body is instantiated for both, no
+  // register copies): 32 more VGPRs, still 2 wavefronts per SIMD.
+  auto tile = [&](const int st, floatx16 &acc0, floatx16 &acc1, const floatx16 &prev0, const floatx16 &prev1,
+                  const bool have_prev) __attribute__((always_inline)) {
+    const int buf = (st - st0) & 1;
+    gload(min(st + 1, st1 - 1));
+    const float4 *b0 = reinterpret_cast<const float4 *>(&Bs[buf][col * MT_BSTRIDE + half * 64]);
+    const float4 *b1 = reinterpret_cast<const float4 *>(&Bs[buf][(col + 32) * MT_BSTRIDE + half * 64]);
+    acc0 = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc1 = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int pc0 = (st - 1) * MT_SUPER + col, pc1 = pc0 + 32;          // columns of the previous tile
+    const bool do0 = have_prev && pc0 < G.ncols, do1 = have_prev && pc1 < G.ncols;
+    float4 p0 = b0[0], p1 = b1[0], q0, q1;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      q0 = b0[i + 1]; q1 = b1[i + 1];
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 0], p0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 0], p1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 1], p0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 1], p1.y, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // previous tile, ascending column order within the residue class: its columns 0-31 (chain 0) during the first
+      // four slots of this tile's k-loop, columns 32-63 (chain 1) during the last four; four rows per slot
+      {
+        const int t4 = 4 * ((i >> 1) & 3);
+        if (i < 8) {
+          if (do0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) top2_update(prev0[t4 + r], pc0, mx[t4 + r], sec[t4 + r], ix[t4 + r]);
+          }
+        } else {
+          if (do1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) top2_update(prev1[t4 + r], pc1, mx[t4 + r], sec[t4 + r], ix[t4 + r]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 2], p0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 2], p1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 3], p0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 3], p1.w, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < 16) { p0 = b0[i + 2]; p1 = b1[i + 2]; }
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 4], q0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 4], q1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 5], q0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 5], q1.y, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#if MT_EARLY_STORE
+      // the next tile's operands go to the other LDS buffer in the MIDDLE of this tile's MFMA stream (the loads were
+      // issued at its start; that buffer's readers all passed the previous barrier): nothing but the barrier itself is
+      // left between the last MFMA of this tile and the first operand read of the next
+      if (i == MT_EARLY_STORE_AT) lstore(buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 6], q0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 6], q1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 7], q0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 7], q1.w, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#if !MT_EARLY_STORE
+    lstore(buf ^ 1);
+#endif
+    __syncthreads();
+  };
+  {
+    floatx16 A0, A1, B0, B1;
+    int st = st0;
+    bool have = false;
+    for (; st + 1 < st1; st += 2) {
+      tile(st, A0, A1, B0, B1, have);
+      tile(st + 1, B0, B1, A0, A1, true);
+      have = true;
+    }
+    if (st < st1) {                       // an odd tile left: it finishes B, then its own results are in A
+      tile(st, A0, A1, B0, B1, have);
+      const int c0 = st * MT_SUPER + col, c1 = c0 + 32;
+      if (c0 < G.ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) top2_update(A0[r], c0, mx[r], sec[r], ix[r]);
+      }
+      if (c1 < G.ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) top2_update(A1[r], c1, mx[r], sec[r], ix[r]);
+      }
+    } else if (have) {                    // the last tile of an even count sits in B
+      const int c0 = (st1 - 1) * MT_SUPER + col, c1 = c0 + 32;
+      if (c0 < G.ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) top2_update(B0[r], c0, mx[r], sec[r], ix[r]);
+      }
+      if (c1 < G.ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) top2_update(B1[r], c1, mx[r], sec[r], ix[r]);
+      }
+    }
+  }
+#else
   for (int st = st0; st < st1; st++) {
     const int buf = (st - st0) & 1;
     gload(min(st + 1, st1 - 1));     // unconditional (the last iteration re-fetches its own tile): no phi copies of the 32 staging registers
@@ -171,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
     __syncthreads();
   }
 
+#endif
   // ---- reduce the 4 residues of a class (lanes 4c..4c+3 of the same half): exact merge
 #pragma unroll
   for (int m = 1; m <= 2; m <<= 1) {

@@ -204,20 +204,26 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
 
   const int rs = max(y0 - 2, 0);                           // prefiltered rows rs .. re feed this segment's decimated rows
   const int re = min(y1, g.height - 1);
-  float4 w0 = hrow(rs - 4), w1 = hrow(rs - 3), w2 = hrow(rs - 2), w3 = hrow(rs - 1), w4 = hrow(rs);
-  float4 w5 = hrow(rs + 1), w6 = hrow(rs + 2), w7 = hrow(rs + 3), w8;
-  float4 raw = ldraw(rs + 4), raw1 = ldraw(rs + 5);
+  // The 9-row window of horizontally filtered rows and the three raw rows in flight rotate by NAME: the row loop is
+  // unrolled nine times (window slot of row y+k = (j+k) % 9, compile-time), so no register is ever moved.  r02's loop
+  // rotated them with 48 v_mov per row — 37 % of its 130 VALU instructions (r03: ISA count of the loop body).
+  float4 w[9], rw[3];
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[k] = hrow(rs - 4 + k);
+  rw[0] = ldraw(rs + 4);
+  rw[1] = ldraw(rs + 5);
   float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0, a4 = a0;
-  for (int y = rs; y <= re; y++) {
-    const float4 rawnext = ldraw(y + 6);
-    w8 = hfilt(raw);
-    raw = raw1;
-    raw1 = rawnext;
+  // one row: window rows y-4 .. y+3 in W0..W7, W8 receives row y+4 (= hfilt of RCUR); RNEXT receives the raw row y+6
+  auto row = [&](const int y, const float4 &W0, const float4 &W1, const float4 &W2, const float4 &W3, const float4 &W4,
+                 const float4 &W5, const float4 &W6, const float4 &W7, float4 &W8, const float4 &RCUR,
+                 float4 &RNEXT) __attribute__((always_inline)) {
+    RNEXT = ldraw(y + 6);
+    W8 = hfilt(RCUR);
     float4 o;
-    o.x = conv9_expr(k0, k1, k2, k3, k4, w4.x, w3.x + w5.x, w2.x + w6.x, w1.x + w7.x, w0.x + w8.x);
-    o.y = conv9_expr(k0, k1, k2, k3, k4, w4.y, w3.y + w5.y, w2.y + w6.y, w1.y + w7.y, w0.y + w8.y);
-    o.z = conv9_expr(k0, k1, k2, k3, k4, w4.z, w3.z + w5.z, w2.z + w6.z, w1.z + w7.z, w0.z + w8.z);
-    o.w = conv9_expr(k0, k1, k2, k3, k4, w4.w, w3.w + w5.w, w2.w + w6.w, w1.w + w7.w, w0.w + w8.w);
+    o.x = conv9_expr(k0, k1, k2, k3, k4, W4.x, W3.x + W5.x, W2.x + W6.x, W1.x + W7.x, W0.x + W8.x);
+    o.y = conv9_expr(k0, k1, k2, k3, k4, W4.y, W3.y + W5.y, W2.y + W6.y, W1.y + W7.y, W0.y + W8.y);
+    o.z = conv9_expr(k0, k1, k2, k3, k4, W4.z, W3.z + W5.z, W2.z + W6.z, W1.z + W7.z, W0.z + W8.z);
+    o.w = conv9_expr(k0, k1, k2, k3, k4, W4.w, W3.w + W5.w, W2.w + W6.w, W1.w + W7.w, W0.w + W8.w);
     if (writer && y >= y0 && y < y1) *reinterpret_cast<float4 *>(out + (size_t)y * dpitch + 4 * q) = o;
     float4 oc = o;                                         // the prefiltered row as ScaleDown's clamped reads see it:
     if (MODE == 2 && qc.edge == 2) {                       // columns past width-1 take the value of column width-1
@@ -230,7 +236,20 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
     a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = hd;
     if (y == 0) { a2 = hd; a3 = hd; }                     // rows -2, -1 clamp to row 0
     if ((y & 1) == 0 && y >= y0 + 2) emit((y - 2) >> 1, a0, a1, a2, a3, a4);
-    w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
+  };
+  int y = rs;
+  for (; y + 8 <= re; y += 9) {
+#pragma unroll
+    for (int j = 0; j < 9; j++)
+      row(y + j, w[j % 9], w[(j + 1) % 9], w[(j + 2) % 9], w[(j + 3) % 9], w[(j + 4) % 9], w[(j + 5) % 9],
+          w[(j + 6) % 9], w[(j + 7) % 9], w[(j + 8) % 9], rw[j % 3], rw[(j + 2) % 3]);
+  }
+  for (; y <= re; y++) {                                   // fewer than nine rows left: rotate the registers
+    row(y, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], rw[0], rw[2]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = w[k + 1];
+    rw[0] = rw[1];
+    rw[1] = rw[2];
   }
   // last segment of an even-height image: row `height` clamps to row height-1
   if (y1 == g.height && (g.height & 1) == 0) emit((g.height - 2) >> 1, a1, a2, a3, a4, a4);
