@@ -828,6 +828,8 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
 {
   RoctxRange range("misift_extract");
   ARG_CHECK(ctx && d_imgs && (pts || (ctx->pack_dst && ctx->opt.fused)));
+  extra(ctx)->last_lane = nullptr;      // this batch runs on the context itself: its counters / stream are the results'
+  extra(ctx)->last_done = nullptr;
   ARG_CHECK(nframes >= 1 && width >= 16 && height >= 16 && pitch >= width);
   ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);       // before the shifts below
   ARG_CHECK((width >> (num_octaves - 1)) >= 8 && (height >> (num_octaves - 1)) >= 8);
