@@ -342,6 +342,7 @@ struct misift_ctx {
 };
 
 void misift_set_error(const char *fmt, ...);
+void misift_warn_hw_queues(const char *who);   // once per process: GPU_MAX_HW_QUEUES unset or < 8 (stderr + misift_last_error)
 int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap);
 // the stream the most recent batch of `ctx` ran on (its own, or a pipeline's with batches in flight)
 hipStream_t misift_ctx_result_stream(misift_ctx *ctx);

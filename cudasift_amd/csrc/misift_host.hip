@@ -176,6 +176,23 @@ static int resolve_profile(misift_ctx *ctx)
   return MISIFT_OK;
 }
 
+// Streams of one process share HIP's hardware queues (4 by default): the communication stream then queues behind
+// the extraction stream's kernels and a pipelined gather loses ~20 %.  Say so once.
+static void warn_hw_queues_once(const char *who)
+{
+  const char *e = getenv("GPU_MAX_HW_QUEUES");
+  if (e && atoi(e) >= 8) return;
+  misift_set_error("%s: GPU_MAX_HW_QUEUES is %s; with fewer than 8 hardware queues the communication / copy streams share "
+                   "a queue with the extraction stream (set GPU_MAX_HW_QUEUES=8 before the first HIP call)", who,
+                   e ? e : "unset (HIP default: 4)");
+  if (!getenv("MISIFT_QUIET")) fprintf(stderr, "misift: warning: %s\n", misift_last_error());
+}
+void misift_warn_hw_queues(const char *who)
+{
+  static std::once_flag once;            // communicators are created from several host threads at the same time
+  std::call_once(once, warn_hw_queues_once, who);
+}
+
 // ----------------------------------------------------------------- context
 struct CtxFull {
   misift_ctx c;

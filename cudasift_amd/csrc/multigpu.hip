@@ -310,21 +310,6 @@ extern "C" int misift_loopback_world_create(int nranks, misift_loopback_world **
 
 extern "C" void misift_loopback_world_destroy(misift_loopback_world *w) { delete w; }
 
-// Streams of one process share HIP's hardware queues (4 by default): the communication stream then queues behind
-// the extraction stream's kernels and a pipelined gather loses ~20 %.  Say so once.
-static void warn_hw_queues(const char *who)
-{
-  static bool said = false;
-  if (said) return;
-  const char *e = getenv("GPU_MAX_HW_QUEUES");
-  if (e && atoi(e) >= 8) return;
-  said = true;
-  misift_set_error("%s: GPU_MAX_HW_QUEUES is %s; with fewer than 8 hardware queues the communication / copy streams share "
-                   "a queue with the extraction stream (set GPU_MAX_HW_QUEUES=8 before the first HIP call)", who,
-                   e ? e : "unset (HIP default: 4)");
-  if (!getenv("MISIFT_QUIET")) fprintf(stderr, "misift: warning: %s\n", misift_last_error());
-}
-
 extern "C" int misift_comm_unique_id(void *id128)
 {
   MG_CHECK(id128 != nullptr);
@@ -355,7 +340,7 @@ static int comm_finish_create(misift_ctx *ctx, ncclComm_t nc, bool owns, misift_
     NCCL_TRY(g_rccl.CommCount(nc, &c->nranks));
     NCCL_TRY(g_rccl.CommUserRank(nc, &c->rank));
   }
-  warn_hw_queues("misift_comm_create");
+  misift_warn_hw_queues("misift_comm_create");
   int lo = 0, hi = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));

@@ -194,6 +194,7 @@ extern "C" int misift_pipe_create(misift_ctx *ctx, int width, int height, int ba
   p->init_blur = init_blur; p->thresh = thresh; p->lowest_scale = lowest_scale;
   p->frame_elems = (size_t)width * height;
   p->s_up = p->s_compute = p->s_down = p->s_rec = nullptr;
+  misift_warn_hw_queues("misift_pipe_create");      // the upload / read-back streams want hardware queues of their own
   p->saved_stream = ctx->stream;
   p->d_scratch = nullptr; p->d_pts = nullptr;
   p->submitted = p->collected = 0;
