@@ -389,6 +389,8 @@ class StepPipeline:
         assert len(scratches) >= self.INFLIGHT, "one scratch arena per batch in flight"
         self.LAG = self.INFLIGHT + 1        # the host completes batch k-LAG: INFLIGHT batches stay queued on the GPU
         NSLOT = self.NSLOT = self.LAG + 1
+        if comm is not None and NSLOT > 8:                  # MISIFT_GATHER_SLOTS
+            raise ValueError("contexts x batches-in-flight = %d needs %d gather slots, the communicator has 8" % (self.INFLIGHT, NSLOT))
         # with a ring the results of a call are not ordered on the context stream: raw HIP events recorded behind each
         # batch (misift_ctx_record_batch) mark completion.  (No waiting side streams: a stream that waits and shares a
         # hardware queue with a pipeline holds that pipeline up.)
@@ -504,7 +506,7 @@ def emulate_ranks(args):
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     B, NB = max(1, min(args.frames_per_gpu, 4)), 2
-    steps, warm = max(3, min(args.steps, 6)), min(args.warmup, 2)
+    steps, warm = max(3, min(args.steps, 12)), min(args.warmup, 2)
     nm = min(args.match_n, 16384)
     frames_of = []
     for r in range(N):                       # every rank's own frames, generated as main() generates them
@@ -527,9 +529,13 @@ def emulate_ranks(args):
                 ctx.set_options(quiet=1)
                 comm = capi.Comm(ctx, N, rank, lw)
                 S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
-                scratch = torch.empty((B * S,), dtype=torch.float32, device=device)
+                ring = max(1, args.batches_in_flight)          # the same in-context pipelining as the real run
+                if ring > 1:
+                    ctx.set_batches_in_flight(ring)
+                scr = [torch.empty((B * S,), dtype=torch.float32, device=device) for _ in range(ring)]
                 stream.synchronize()
-                pl = StepPipeline(torch, capi, [ctx], [stream], comm, rank, N, device, frames_of[rank], B, NB, [scratch], None, False)
+                pl = StepPipeline(torch, capi, [ctx], [stream], comm, rank, N, device, frames_of[rank], B, NB, scr, None, False,
+                                  ring=ring)
                 pl.run(0, warm)
                 comm.barrier()
                 counts = pl.run(warm, steps)
@@ -583,7 +589,7 @@ def emulate_ranks(args):
         assert off == len(recs)
     m = res[0].get("match")
     out = {"mode": "emulate-ranks", "functional_only": True, "emulated_ranks": N, "n_gpus": 1, "frames_per_rank": B,
-           "steps": steps, "warmup": warm,
+           "steps": steps, "warmup": warm, "batches_in_flight": max(1, args.batches_in_flight),
            "transport": "misift_loopback_world: N communicators / contexts / host threads on ONE device, device-to-device "
                         "copies through a shared rendezvous (no RCCL); same StepPipeline and matcher_leg as --gpus N",
            "gathered_frames_last_step": int(N * B), "validated_frames": validated,
