@@ -613,9 +613,11 @@ def main():
                     help="contexts (own stream, staging and scratch arena each) the steps rotate over = batches in flight on the "
                          "GPU.  4 measures ~8 %% more frames/s (profiles/r02_bench_contexts4.json) but every kernel's duration is "
                          "then stretched by its neighbours, so the per-kernel roofline is quoted on the default, 1")
-    ap.add_argument("--batches-in-flight", type=int, default=4,
+    ap.add_argument("--batches-in-flight", type=int, default=0,
                     help="pipelines INSIDE the context (misift_ctx_set_batches_in_flight): consecutive batches overlap on the GPU "
-                         "behind ONE context.  The per-kernel roofline durations always come from a K = 1 child run")
+                         "behind ONE context.  0 = auto: 4 for runs of >= 50 timed steps, 2 for shorter ones (the timed region "
+                         "starts and ends with an empty pipeline: 20 steps measure 48.7 / 53.1 / 50.4 k frames/s at K = 1 / 2 / 4, "
+                         "100 steps 51.7 / 54.4 / 55.5 k).  The per-kernel roofline durations always come from a K = 1 child run")
     ap.add_argument("--match-n", type=int, default=100000)
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg AND the oracle self-validation")
@@ -630,6 +632,8 @@ def main():
                     help="run the N-rank driver loops (gather of SiftData, sharded matcher) end to end on ONE GPU through the "
                          "loopback transport; functional only, prints no rate")
     args = ap.parse_args()
+    if args.batches_in_flight <= 0:
+        args.batches_in_flight = 4 if args.steps >= 50 else 2
     # HIP multiplexes a process's streams onto 4 hardware queues unless told otherwise, and a stream that shares a
     # queue with the extraction stream runs BEHIND the batches queued there: the gather's communication stream then
     # completes batch k-2 only after batch k, the host cannot run ahead and the pipeline loses its depth (1 rank through
@@ -685,7 +689,6 @@ def main():
 
     # ---------------- inputs resident in HBM before the timed region: NB batches of B distinct frames per rank
     frames = torch.empty((NB * B, H, W), dtype=torch.float32, device=device)
-    gen_frames_torch(torch, NB * B, rank * NB * B, device, out=frames)
     S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
     scratches = [torch.empty((B * S,), dtype=torch.float32, device=device) for _ in range(NCTX * RING)]
     scratch = scratches[0]
@@ -708,6 +711,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The synthetic frames are generated last, after every allocation, so that the loop starts on a busy GPU.  (It does not
+    # remove the slow start of a short run: after 5 warm-up steps the first timed steps take 1.37 ms and the twentieth 1.27 —
+    # the same decay whether the GPU idled before or not; 30 warm-up steps bring a 20-step run to 1.25 ms per step.  The
+    # driver's `--steps 20 --warmup 5` therefore reads ~4 % below a 100-step run.)
+    gen_frames_torch(torch, NB * B, rank * NB * B, device, out=frames)
+    torch.cuda.synchronize()
     if args.warmup > 0:
         run(0, args.warmup)
     barrier()
@@ -735,6 +744,8 @@ def main():
         # (with a ring: the completion markers of batches k and k + batches-in-flight)
         NI = NCTX * RING
         d = np.array([step_ev[i].elapsed_time(step_ev[i + NI]) / NI for i in range(len(step_ev) - NI)])
+        if os.environ.get("BENCH_STEP_DUMP"):
+            print("step intervals (ms):", " ".join("%.3f" % v for v in d), file=sys.stderr)
         step_ms = {"p10": round(float(np.percentile(d, 10)), 4), "p50": round(float(np.percentile(d, 50)), 4),
                    "p90": round(float(np.percentile(d, 90)), 4), "samples": int(len(d)),
                    "note": "HIP-event interval between the ends of steps k and k+contexts (same stream) / contexts, "
