@@ -687,6 +687,22 @@ def main():
             dist.broadcast(idt, 0)
         comm = capi.Comm(ctx, world, rank, bytes(idt.cpu().numpy().tobytes()))
 
+    # ---------------- matcher (BASELINE config 5) — its own timed region (barrier on both sides, matcher_leg); the order of
+    # the two legs is free and does not change either number (measured both ways)
+    match = None
+    orc = None
+    if not args.no_cpu and rank == 0:
+        from oracle import pyoracle as orc
+    if not args.no_match:
+        ops = CabiMatchOps(torch, capi, ctx, comm if world > 1 else None, device, rank, world)
+        match = matcher_leg(ops, rank, world, args.match_n, msteps=3, validate_rows=100, l2=False,
+                            point_dtype=capi.POINT_DTYPE, result_dtype=capi.RESULT_DTYPE, oracle=orc)
+        m2 = matcher_leg(ops, rank, world, args.match_n, msteps=2, validate_rows=0, l2=True,
+                         point_dtype=capi.POINT_DTYPE, result_dtype=capi.RESULT_DTYPE, oracle=None)
+        match["unit_l2_variant"] = {"value": m2["value"], "ms": m2["ms"], "frac": m2["roofline"]["frac"]}
+        del ops
+        torch.cuda.empty_cache()
+
     # ---------------- inputs resident in HBM before the timed region: NB batches of B distinct frames per rank
     frames = torch.empty((NB * B, H, W), dtype=torch.float32, device=device)
     S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
@@ -711,10 +727,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The synthetic frames are generated last, after every allocation, so that the loop starts on a busy GPU.  (It does not
-    # remove the slow start of a short run: after 5 warm-up steps the first timed steps take 1.37 ms and the twentieth 1.27 —
-    # the same decay whether the GPU idled before or not; 30 warm-up steps bring a 20-step run to 1.25 ms per step.  The
-    # driver's `--steps 20 --warmup 5` therefore reads ~4 % below a 100-step run.)
+    # The synthetic frames are generated last, after every allocation.  A short run starts slow whatever precedes it (idle,
+    # the frame generator or the MFMA-bound matcher): after 5 warm-up steps the first timed steps take 1.37 ms and the
+    # twentieth 1.27.  Per-launch durations (tools/r03_ramp.sh) show why: the VALU-bound kernels speed up over the first
+    # ~30 steps (dog_scan 0.69 -> 0.57 ms, descr_all 0.33 -> 0.285) while the HBM-bound lowpass_down is flat at 0.225 —
+    # the shader clock ramps up over ~40 ms of this load.  `--steps 20 --warmup 5` therefore reads ~4 % below a 100-step run.
     gen_frames_torch(torch, NB * B, rank * NB * B, device, out=frames)
     torch.cuda.synchronize()
     if args.warmup > 0:
@@ -1034,18 +1051,7 @@ def main():
         del a, b
         roofline["copy_ceiling_GBps"] = round(copy_gbs, 1)
 
-    # ---------------- matcher (BASELINE config 5)
-    match = None
-    orc = None
-    if not args.no_cpu and rank == 0:
-        from oracle import pyoracle as orc
-    if not args.no_match:
-        ops = CabiMatchOps(torch, capi, ctx, comm if world > 1 else None, device, rank, world)
-        match = matcher_leg(ops, rank, world, args.match_n, msteps=3, validate_rows=100, l2=False,
-                            point_dtype=capi.POINT_DTYPE, result_dtype=capi.RESULT_DTYPE, oracle=orc)
-        m2 = matcher_leg(ops, rank, world, args.match_n, msteps=2, validate_rows=0, l2=True,
-                         point_dtype=capi.POINT_DTYPE, result_dtype=capi.RESULT_DTYPE, oracle=None)
-        match["unit_l2_variant"] = {"value": m2["value"], "ms": m2["ms"], "frac": m2["roofline"]["frac"]}
+    # ---------------- matcher (BASELINE config 5): measured by run_matcher_leg() before the extraction loop
 
     # ---------------- self-validation of the TIMED loop's last step + CPU baseline (rank 0, N = 1 baseline only)
     cpu, validated = None, None
