@@ -923,10 +923,15 @@ def main():
     trace, trace_note = None, "not collected (N > 1, --no-pmc or --contexts > 1): HIP-event durations"
     if rank == 0 and world == 1 and NCTX == 1 and not args.no_pmc and not args.unfused:
         torch.cuda.synchronize()
-        trace, trace_note = collect_trace(B)
+        # the child run mirrors the timed region: the same number of warm-up and timed steps (the shader clock ramps up over
+        # the first ~30 steps of this load, so a fixed short child run would quote longer durations than the timed loop saw)
+        tsteps = max(10, min(args.steps, 200)) + max(0, min(args.warmup, 50))
+        tskip = max(1, min(args.warmup, 50))
+        trace, trace_note = collect_trace(B, steps=tsteps, skip=tskip)
         if trace is not None:
-            trace_note = ("rocprofv3 --kernel-trace over a child run of 30 back-to-back steps of the timed entry point (first 5 "
-                          "dropped), collected live in this run")
+            trace_note = ("rocprofv3 --kernel-trace over a one-batch-at-a-time child run of %d back-to-back steps of the timed "
+                          "entry point (first %d dropped: the timed region's own warm-up and length), collected live in this run"
+                          % (tsteps, tskip))
             for k, e in trace.items():
                 if k in kernels:
                     kernels[k]["hip_event_ms_per_step"] = kernels[k]["ms_per_step"]
@@ -979,7 +984,7 @@ def main():
             ms1 = p1["dog_scan"]["total_ms"] / n1
             a1 = flops_step / (ms1 * 1e-3) / 1e12
             if trace is not None:                 # the same from dispatch durations (rocprofv3 --kernel-trace, MISIFT_SPLIT_TAIL=0 child)
-                t1, _ = collect_trace(B, extra_env={"MISIFT_SPLIT_TAIL": "0"})
+                t1, _ = collect_trace(B, steps=tsteps, skip=tskip, extra_env={"MISIFT_SPLIT_TAIL": "0"})
                 if t1 and "dog_scan" in t1 and t1["dog_scan"]["launches_per_step"] == 1:
                     ms1 = t1["dog_scan"]["ms_per_step"]
                     a1 = flops_step / (ms1 * 1e-3) / 1e12
