@@ -127,6 +127,16 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
 #ifndef MT_EARLY_STORE_AT
 #define MT_EARLY_STORE_AT 10
 #endif
+// timing-only experiments (wrong results): what the barrier / the LDS store / the global loads cost (tools/variants.sh)
+#ifndef MT_EXP_NOBARRIER
+#define MT_EXP_NOBARRIER 0
+#endif
+#ifndef MT_EXP_NOSTORE
+#define MT_EXP_NOSTORE 0
+#endif
+#ifndef MT_EXP_NOGLOAD
+#define MT_EXP_NOGLOAD 0
+#endif
   if (st0 < st1) {
     gload(st0);
     lstore(0);
@@ -140,7 +150,9 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
   auto tile = [&](const int st, floatx16 &acc0, floatx16 &acc1, const floatx16 &prev0, const floatx16 &prev1,
                   const bool have_prev) __attribute__((always_inline)) {
     const int buf = (st - st0) & 1;
+#if !MT_EXP_NOGLOAD
     gload(min(st + 1, st1 - 1));
+#endif
     const float4 *b0 = reinterpret_cast<const float4 *>(&Bs[buf][col * MT_BSTRIDE + half * 64]);
     const float4 *b1 = reinterpret_cast<const float4 *>(&Bs[buf][(col + 32) * MT_BSTRIDE + half * 64]);
     acc0 = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -190,7 +202,9 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
       // the next tile's operands go to the other LDS buffer in the MIDDLE of this tile's MFMA stream (the loads were
       // issued at its start; that buffer's readers all passed the previous barrier): nothing but the barrier itself is
       // left between the last MFMA of this tile and the first operand read of the next
+#if !MT_EXP_NOSTORE
       if (i == MT_EARLY_STORE_AT) lstore(buf ^ 1);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #endif
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 6], q0.z, acc0, 0, 0, 0);
@@ -202,7 +216,9 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
 #if !MT_EARLY_STORE
     lstore(buf ^ 1);
 #endif
+#if !MT_EXP_NOBARRIER
     __syncthreads();
+#endif
   };
   {
     floatx16 A0, A1, B0, B1;
