@@ -19,7 +19,11 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#define MT_ROWS_PER_BLOCK 128
+#ifndef MT_WG_WAVES
+#define MT_WG_WAVES 4              // wavefronts per workgroup (experiment: 8 = 256 rows share a staged tile, one workgroup per CU)
+#endif
+#define MT_ROWS_PER_BLOCK (32 * MT_WG_WAVES)
+#define MT_STAGE (32 / MT_WG_WAVES)   // float4 loads per thread and super-tile
 // LDS image of a 32-column tile of D2: column-major, each column split into its even-k and odd-k halves
 // ([col][half][64]) so that lane (col, half) — which feeds k = 2t + half to MFMA t — reads its 64 operands
 // as 16 contiguous ds_read_b128.  Column stride 132 floats: a b128 lane group (16 columns) then starts on
@@ -66,7 +70,7 @@ __device__ __forceinline__ void top2_merge(float &mx, float &sec, int &ix, float
 // 64 dependent v_mfma_f32_32x32x2_f32 each, interleaved, so the 64-cycle dependent-issue latency of one
 // chain is covered by the other (and by the second wavefront resident on the SIMD).
 #define MT_SUPER 64
-__global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restrict__ pts1,
+__global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kernel(const SiftPointD *__restrict__ pts1,
                                                        const SiftPointD *__restrict__ pts2, MatchGeom G,
                                                        float *__restrict__ partial)
 {
@@ -101,18 +105,18 @@ __global__ __launch_bounds__(256, 2) void match_kernel(const SiftPointD *__restr
 
   // ---- B staging: thread -> (column scol + 8j, float4 index f4), j = 0..7
   const int scol = tid >> 5, f4 = tid & 31;
-  float4 stage[8];
+  float4 stage[MT_STAGE];
   auto gload = [&](int st) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int p2 = min(st * MT_SUPER + scol + 8 * j, G.n2 - 1);
+    for (int j = 0; j < MT_STAGE; j++) {
+      const int p2 = min(st * MT_SUPER + scol + 2 * MT_WG_WAVES * j, G.n2 - 1);
       stage[j] = reinterpret_cast<const float4 *>(pts2[p2].data)[f4];
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      float *d = &Bs[buf][(scol + 8 * j) * MT_BSTRIDE + 2 * f4];       // k = 4*f4 .. 4*f4+3
+    for (int j = 0; j < MT_STAGE; j++) {
+      float *d = &Bs[buf][(scol + 2 * MT_WG_WAVES * j) * MT_BSTRIDE + 2 * f4];       // k = 4*f4 .. 4*f4+3
       *reinterpret_cast<float2 *>(d) = make_float2(stage[j].x, stage[j].z);        // even k -> half 0
       *reinterpret_cast<float2 *>(d + 64) = make_float2(stage[j].y, stage[j].w);   // odd k  -> half 1
     }
@@ -380,7 +384,7 @@ int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count
   G.ncols = ctx->opt.match_full ? n2 : MT_TILE * (n2 / MT_TILE);
   G.ntiles = (G.ncols + MT_SUPER - 1) / MT_SUPER;                 // 64-column super-tiles
   const int nrb = (row_count + MT_ROWS_PER_BLOCK - 1) / MT_ROWS_PER_BLOCK;
-  const int slots = 2 * ctx->num_cus;
+  const int slots = (8 / MT_WG_WAVES) * ctx->num_cus;
   int nchunks = (24 * slots + nrb - 1) / nrb;
   int maxchunks = G.ntiles / 2;
   if (maxchunks < 1) maxchunks = 1;
@@ -397,7 +401,7 @@ int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count
   float *partial = reinterpret_cast<float *>(ctx->d_match_tmp);
   {
     LaunchScope ls(ctx, "match_mfma");
-    hipLaunchKernelGGL(match_kernel, dim3(nrb * nchunks), dim3(256), 0, ctx->stream, pts1, pts2, G, partial);
+    hipLaunchKernelGGL(match_kernel, dim3(nrb * nchunks), dim3(64 * MT_WG_WAVES), 0, ctx->stream, pts1, pts2, G, partial);
     int rc = ls.finish();
     if (rc) return rc;
   }
