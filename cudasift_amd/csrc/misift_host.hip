@@ -403,18 +403,32 @@ extern "C" int misift_ctx_set_batches_in_flight(misift_ctx *ctx, int k)
   x->lane_done.clear();
   x->last_lane = nullptr; x->last_done = nullptr; x->ticket = 0;
   if (k == 1) return MISIFT_OK;
-  if (!x->ev_in) HIP_TRY(hipEventCreateWithFlags(&x->ev_in, hipEventDisableTiming));
-  for (int i = 0; i < k; i++) {
+  // build the whole ring or none of it: a half-built ring must never be visible to misift_extract_batch_packed_async
+  std::vector<misift_ctx *> lanes;
+  std::vector<hipEvent_t> done;
+  int rc = MISIFT_OK;
+  if (!x->ev_in && hipEventCreateWithFlags(&x->ev_in, hipEventDisableTiming) != hipSuccess) rc = MISIFT_EHIP;
+  for (int i = 0; i < k && !rc; i++) {
     misift_ctx *l = nullptr;
-    const int rc = ctx_create_physical(ctx->device, nullptr, true, &l);
-    if (rc) return rc;
-    x->lanes.push_back(l);
+    rc = ctx_create_physical(ctx->device, nullptr, true, &l);
+    if (!rc) lanes.push_back(l);
   }
-  for (int i = 0; i < 2 * k; i++) {
+  for (int i = 0; i < 2 * k && !rc; i++) {
     hipEvent_t e = nullptr;
-    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    x->lane_done.push_back(e);
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      misift_set_error("hipEventCreateWithFlags failed while building %d pipelines", k);
+      rc = MISIFT_EHIP;
+    } else {
+      done.push_back(e);
+    }
   }
+  if (rc) {
+    for (misift_ctx *l : lanes) misift_ctx_destroy(l);
+    for (hipEvent_t e : done) hipEventDestroy(e);
+    return rc;                                        // the context stays a plain in-order one
+  }
+  x->lanes.swap(lanes);
+  x->lane_done.swap(done);
   return MISIFT_OK;
 }
 
