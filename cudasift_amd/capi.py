@@ -82,6 +82,7 @@ SIGNATURES = {
     "misift_ctx_wait_batch": (_i, [_vp, _vp]),
     "misift_ctx_record_batch": (_i, [_vp, _vp]),
     "misift_test_elementary": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i]),
+    "misift_test_match_split": (_i, [_vp, _vp, _i, _vp, _i, _i, _i]),
     "misift_comm_unique_id": (_i, [_vp]),
     "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "misift_comm_adopt": (_i, [_vp, _vp, C.POINTER(_vp)]),
@@ -428,6 +429,14 @@ class Context:
             check(lib().misift_match(self.h, d1.ptr, n1, d2.ptr, n2), "misift_match")
         else:
             check(lib().misift_match_rows(self.h, d1.ptr, row_begin, row_count, d2.ptr, n2), "misift_match_rows")
+        return self.download(d1, (len(pts1),), POINT_DTYPE)
+
+    def match_split(self, pts1, n1, pts2, n2, own_tile_begin, own_tile_end):
+        """Test hook: misift_match with the column sweep cut into two launches (the sharded matcher's cut)."""
+        d1 = self.upload(pts1)
+        d2 = self.upload(pts2)
+        check(lib().misift_test_match_split(self.h, d1.ptr, n1, d2.ptr, n2, own_tile_begin, own_tile_end),
+              "misift_test_match_split")
         return self.download(d1, (len(pts1),), POINT_DTYPE)
 
     def find_homography(self, dpts_ptr, npts, num_loops=1000, min_score=0.85, max_ambiguity=0.95, thresh=5.0):

@@ -15,6 +15,7 @@
 // (matching.cu:375-390) can be reproduced exactly — or replaced by the exact second best.
 // Columns are split into chunks across workgroups to fill 256 CUs; a small merge kernel
 // combines the per-chunk class triples and writes score/match/ambiguity/match_xpos/ypos.
+#include <stdlib.h>
 #include "common.hpp"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -35,10 +36,20 @@ struct MatchGeom {
   int row_begin, row_count;      // rows of set 1 handled by this launch
   int n1_total;
   int n2, ncols;                 // set-2 size, columns that take part (32*floor(n2/32) or n2)
-  int ntiles, nchunks, tiles_per_chunk;
+  int ntiles, nchunks, tiles_per_chunk;   // super-tiles / chunks of THIS launch
+  // A launch sweeps a run of `ntiles` VIRTUAL super-tiles: virtual tile v is actual tile tile_base + v, plus hole_len
+  // from v >= hole_begin on (the sharded matcher sweeps its own shard's tiles while the rest of set 2 is still on the
+  // wire, then everything around them: multigpu.hip).  Chunk c of this launch is chunk chunk_base + c of nchunks_total.
+  int tile_base, hole_begin, hole_len;
+  int chunk_base, nchunks_total;
 };
+__device__ __forceinline__ int tile_col0(const MatchGeom &G, int v)       // first column of virtual super-tile v
+{
+  return (G.tile_base + v + (v >= G.hole_begin ? G.hole_len : 0)) * 64;
+}
 
-// partial results: [row][chunk][3][8] : max, second, index per class
+// partial results: [row][class][chunk][3] : max, second, index — one contiguous run of chunks per (row, class), which is
+// what a thread of match_merge_kernel reads
 #define MT_PART_WORDS 24
 
 __device__ __forceinline__ void top2_update(float sc, int p2, float &mx, float &sec, int &ix)
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
   auto gload = [&](int st) {
 #pragma unroll
     for (int j = 0; j < MT_STAGE; j++) {
-      const int p2 = min(st * MT_SUPER + scol + 2 * MT_WG_WAVES * j, G.n2 - 1);
+      const int p2 = min(tile_col0(G, st) + scol + 2 * MT_WG_WAVES * j, G.n2 - 1);
       stage[j] = reinterpret_cast<const float4 *>(pts2[p2].data)[f4];
     }
   };
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
     const float4 *b1 = reinterpret_cast<const float4 *>(&Bs[buf][(col + 32) * MT_BSTRIDE + half * 64]);
     acc0 = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     acc1 = floatx16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int pc0 = (st - 1) * MT_SUPER + col, pc1 = pc0 + 32;          // columns of the previous tile
+    const int pc0 = tile_col0(G, st - 1) + col, pc1 = pc0 + 32;          // columns of the previous tile
     const bool do0 = have_prev && pc0 < G.ncols, do1 = have_prev && pc1 < G.ncols;
     float4 p0 = b0[0], p1 = b1[0], q0, q1;
 #pragma unroll
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
     }
     if (st < st1) {                       // an odd tile left: it finishes B, then its own results are in A
       tile(st, A0, A1, B0, B1, have);
-      const int c0 = st * MT_SUPER + col, c1 = c0 + 32;
+      const int c0 = tile_col0(G, st) + col, c1 = c0 + 32;
       if (c0 < G.ncols) {
 #pragma unroll
         for (int r = 0; r < 16; r++) top2_update(A0[r], c0, mx[r], sec[r], ix[r]);
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
         for (int r = 0; r < 16; r++) top2_update(A1[r], c1, mx[r], sec[r], ix[r]);
       }
     } else if (have) {                    // the last tile of an even count sits in B
-      const int c0 = (st1 - 1) * MT_SUPER + col, c1 = c0 + 32;
+      const int c0 = tile_col0(G, st1 - 1) + col, c1 = c0 + 32;
       if (c0 < G.ncols) {
 #pragma unroll
         for (int r = 0; r < 16; r++) top2_update(B0[r], c0, mx[r], sec[r], ix[r]);
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
       __builtin_amdgcn_sched_barrier(0);
     }
     // ascending column order within the residue class: columns 0-31 of the super-tile first
-    const int c0 = st * MT_SUPER + col, c1 = c0 + 32;
+    const int c0 = tile_col0(G, st) + col, c1 = c0 + 32;
     if (c0 < G.ncols) {
 #pragma unroll
       for (int r = 0; r < 16; r++) top2_update(acc0[r], c0, mx[r], sec[r], ix[r]);
@@ -322,31 +333,48 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
     for (int r = 0; r < 16; r++) {
       const int rl = rb * MT_ROWS_PER_BLOCK + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (rl < G.row_count) {
-        float *p = partial + ((size_t)rl * G.nchunks + chunk) * MT_PART_WORDS;
-        p[cls] = mx[r];
-        p[8 + cls] = sec[r];
-        reinterpret_cast<int *>(p)[16 + cls] = ix[r];
+        float *p = partial + (((size_t)rl * 8 + cls) * G.nchunks_total + G.chunk_base + chunk) * 3;
+        p[0] = mx[r];
+        p[1] = sec[r];
+        reinterpret_cast<int *>(p)[2] = ix[r];
       }
     }
   }
 }
 
+// Eight threads per row, one per class: each merges its class over the chunks (a contiguous run of 12-byte triples; r02
+// had one thread per row walk a strided [chunk][24] table — 0.34 ms for 12 500 rows x 126 chunks, 13 % of that sweep),
+// then the eight classes are combined in every lane of the group exactly as before and lane 0 writes the row.
 __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict__ pts1,
                                                           const SiftPointD *__restrict__ pts2, MatchGeom G,
                                                           const float *__restrict__ partial, int exact_top2)
 {
-  const int rl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (rl >= G.row_count) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rl = t >> 3;
+  const bool live = rl < G.row_count;
+  float m = 0.0f, sd = 0.0f;
+  int ixm = -1;
+  if (live) {
+    const float *p = partial + (size_t)t * G.nchunks_total * 3;
+    int ch = 0;
+    for (; ch + 4 <= G.nchunks_total; ch += 4) {                  // four triples in flight
+      float a[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) a[k] = p[3 * ch + k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) top2_merge(m, sd, ixm, a[3 * k], a[3 * k + 1], __float_as_int(a[3 * k + 2]));
+    }
+    for (; ch < G.nchunks_total; ch++) top2_merge(m, sd, ixm, p[3 * ch], p[3 * ch + 1], __float_as_int(p[3 * ch + 2]));
+  }
   float cmax[8], csec[8];
   int cidx[8];
 #pragma unroll
-  for (int c = 0; c < 8; c++) { cmax[c] = 0.0f; csec[c] = 0.0f; cidx[c] = -1; }
-  for (int ch = 0; ch < G.nchunks; ch++) {
-    const float *p = partial + ((size_t)rl * G.nchunks + ch) * MT_PART_WORDS;
-#pragma unroll
-    for (int c = 0; c < 8; c++)
-      top2_merge(cmax[c], csec[c], cidx[c], p[c], p[8 + c], reinterpret_cast<const int *>(p)[16 + c]);
+  for (int c = 0; c < 8; c++) {
+    cmax[c] = __shfl(m, c, 8);
+    csec[c] = __shfl(sd, c, 8);
+    cidx[c] = __shfl(ixm, c, 8);
   }
+  if (!live || (t & 7) != 0) return;
   float max_score, sec_score;
   int index;
   if (exact_top2) {
@@ -375,40 +403,97 @@ __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict
   o->ambiguity = sec_score / (max_score + 1e-6f);
 }
 
-int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2)
+// Column chunks for a launch of `ntiles` super-tiles over nrb row blocks.  Measured (r03, tools/match_chunks.py,
+// profiles/r03_match_chunks.json): a CU works its workgroups off at a fixed rate, two resident at a time, so the launch
+// takes ceil(workgroups / CUs) "CU rounds" of one chunk each plus ~3/4 of a super-tile of prologue/epilogue per workgroup,
+// and what hurts is a chunk count that leaves the last round nearly empty (12 500 rows: 42 chunks = 16.08 rounds is the
+// worst of 14 counts tried, 26 chunks = 9.95 rounds the best) — r02's fixed "24 workgroups per slot" gave 2-3 tiles per
+// chunk at 16 384 x 16 384 (0.78 ms; 10 chunks: 0.61 ms).  So: the count that minimises rounds x (tiles per chunk + 3/4).
+static int match_plan_param(const char *name, int dflt)
+{
+  const char *e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : dflt;
+}
+static void plan_chunks(const misift_ctx *ctx, int nrb, int ntiles, int &nchunks, int &tiles_per_chunk)
+{
+  static const int forced = match_plan_param("MISIFT_MATCH_CHUNKS", 0);       // experiments only
+  nchunks = 1; tiles_per_chunk = ntiles > 0 ? ntiles : 1;
+  if (ntiles <= 0 || nrb <= 0) return;
+  const int ncu = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int cmax = ntiles < 256 ? ntiles : 256;
+  double best = 0.0;
+  for (int c = 1; c <= cmax; c++) {
+    const int tpc = (ntiles + c - 1) / c;
+    if ((ntiles + tpc - 1) / tpc != c) continue;                    // the same cut as a smaller count
+    const long long m = ((long long)nrb * c + ncu - 1) / ncu;      // workgroups of the most loaded CU; two run side by side,
+    const double rounds = 2.0 * (m / 2) + 1.35 * (m & 1);           // one alone does not keep the matrix pipe full
+    const double cost = rounds * (tpc + 0.75);
+    if (c == 1 || cost < best * 0.999) { best = cost; nchunks = c; tiles_per_chunk = tpc; }
+  }
+  if (forced) {
+    nchunks = forced < ntiles ? forced : ntiles;
+    tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+    nchunks = (ntiles + tiles_per_chunk - 1) / tiles_per_chunk;
+  }
+}
+
+// The sweep in up to two launches: first the super-tiles [own_t0, own_t1) read through `pts2_own` (a pointer such that
+// pts2_own[column] is valid for exactly those tiles' columns: the rank's own shard of set 2, wherever it lies), then —
+// behind `rest_ready` on the context stream — every other super-tile from pts2; one merge over the chunks of both.  The
+// per-class top-2 summaries and their exact merge do not depend on how the columns are cut (top2_merge: ties go to
+// the smaller column), so the result is the single sweep's, bit for bit.  own_t0 == own_t1: the plain single launch.
+// `phase` lets the caller post its exchange between the two launches (the chunk plan is a pure function of the arguments).
+int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2,
+                       const SiftPointD *pts2_own, int own_t0, int own_t1, hipEvent_t rest_ready, int phase)
 {
   if (row_count <= 0 || n2 <= 0) return MISIFT_OK;
   MatchGeom G;
   G.row_begin = row_begin; G.row_count = row_count; G.n1_total = row_begin + row_count;
   G.n2 = n2;
   G.ncols = ctx->opt.match_full ? n2 : MT_TILE * (n2 / MT_TILE);
-  G.ntiles = (G.ncols + MT_SUPER - 1) / MT_SUPER;                 // 64-column super-tiles
+  const int ntiles_all = (G.ncols + MT_SUPER - 1) / MT_SUPER;                 // 64-column super-tiles
   const int nrb = (row_count + MT_ROWS_PER_BLOCK - 1) / MT_ROWS_PER_BLOCK;
-  const int slots = (8 / MT_WG_WAVES) * ctx->num_cus;
-  int nchunks = (24 * slots + nrb - 1) / nrb;
-  int maxchunks = G.ntiles / 2;
-  if (maxchunks < 1) maxchunks = 1;
-  if (nchunks > maxchunks) nchunks = maxchunks;
-  if (nchunks < 1) nchunks = 1;
-  G.tiles_per_chunk = G.ntiles > 0 ? (G.ntiles + nchunks - 1) / nchunks : 1;
-  nchunks = G.ntiles > 0 ? (G.ntiles + G.tiles_per_chunk - 1) / G.tiles_per_chunk : 1;
-  G.nchunks = nchunks;
-  const size_t need = (size_t)row_count * nchunks * MT_PART_WORDS * sizeof(float);
+  if (own_t1 > ntiles_all) own_t1 = ntiles_all;
+  if (own_t0 < 0) own_t0 = 0;
+  const int n_own = own_t1 > own_t0 ? own_t1 - own_t0 : 0, n_rest = ntiles_all - n_own;
+  int ch_own = 0, tpc_own = 1, ch_rest = 0, tpc_rest = 1;
+  if (n_own) plan_chunks(ctx, nrb, n_own, ch_own, tpc_own);
+  if (n_rest || !n_own) plan_chunks(ctx, nrb, n_rest, ch_rest, tpc_rest);
+  G.nchunks_total = ch_own + ch_rest;
+  const size_t need = (size_t)row_count * G.nchunks_total * MT_PART_WORDS * sizeof(float);
   {
     int rc = misift_ensure_tmp(ctx, need);
     if (rc) return rc;
   }
   float *partial = reinterpret_cast<float *>(ctx->d_match_tmp);
-  {
+  if (n_own && phase != MATCH_PHASE_REST) {
+    G.ntiles = n_own; G.nchunks = ch_own; G.tiles_per_chunk = tpc_own;
+    G.tile_base = own_t0; G.hole_begin = 0x7fffffff; G.hole_len = 0; G.chunk_base = 0;
     LaunchScope ls(ctx, "match_mfma");
-    hipLaunchKernelGGL(match_kernel, dim3(nrb * nchunks), dim3(64 * MT_WG_WAVES), 0, ctx->stream, pts1, pts2, G, partial);
+    hipLaunchKernelGGL(match_kernel, dim3(nrb * ch_own), dim3(64 * MT_WG_WAVES), 0, ctx->stream, pts1, pts2_own, G, partial);
+    int rc = ls.finish();
+    if (rc) return rc;
+  }
+  if (phase == MATCH_PHASE_OWN) return MISIFT_OK;
+  if (rest_ready) HIP_TRY(hipStreamWaitEvent(ctx->stream, rest_ready, 0));
+  if (ch_rest) {
+    G.ntiles = n_rest; G.nchunks = ch_rest; G.tiles_per_chunk = tpc_rest;
+    G.tile_base = 0; G.hole_begin = n_own ? own_t0 : 0x7fffffff; G.hole_len = n_own; G.chunk_base = ch_own;
+    LaunchScope ls(ctx, "match_mfma");
+    hipLaunchKernelGGL(match_kernel, dim3(nrb * ch_rest), dim3(64 * MT_WG_WAVES), 0, ctx->stream, pts1, pts2, G, partial);
     int rc = ls.finish();
     if (rc) return rc;
   }
   {
     LaunchScope ls(ctx, "match_merge");
-    hipLaunchKernelGGL(match_merge_kernel, dim3((row_count + 255) / 256), dim3(256), 0, ctx->stream, pts1, pts2,
+    hipLaunchKernelGGL(match_merge_kernel, dim3((row_count * 8 + 255) / 256), dim3(256), 0, ctx->stream, pts1, pts2,
                        G, partial, ctx->opt.match_exact_top2);
     return ls.finish();
   }
+}
+
+int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2)
+{
+  return launch_match_split(ctx, pts1, row_begin, row_count, pts2, n2, nullptr, 0, 0, nullptr, MATCH_PHASE_ALL);
 }

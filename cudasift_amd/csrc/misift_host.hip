@@ -1519,6 +1519,23 @@ extern "C" int misift_match_rows(misift_ctx *ctx, void *d_pts1, int row_begin, i
   return resolve_profile(ctx);
 }
 
+// Test-only: the two-launch column split of the sharded matcher (multigpu.hip) on one set-2 buffer — super-tiles
+// [own_tile_begin, own_tile_end) first, the rest second, one merge — so its result bits and its cost can be checked
+// without a communicator.
+extern "C" int misift_test_match_split(misift_ctx *ctx, void *d_pts1, int n1, const void *d_pts2, int n2,
+                                       int own_tile_begin, int own_tile_end)
+{
+  ARG_CHECK(ctx && n1 >= 0 && n2 >= 0 && own_tile_begin >= 0 && own_tile_end >= own_tile_begin);
+  if (n1 == 0 || n2 == 0) return MISIFT_OK;
+  ARG_CHECK(d_pts1 && d_pts2);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = launch_match_split(ctx, (SiftPointD *)d_pts1, 0, n1, (const SiftPointD *)d_pts2, n2,
+                              (const SiftPointD *)d_pts2, own_tile_begin, own_tile_end, nullptr, MATCH_PHASE_ALL);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return resolve_profile(ctx);
+}
+
 extern "C" int misift_match(misift_ctx *ctx, void *d_pts1, int n1, const void *d_pts2, int n2)
 {
   return misift_match_rows(ctx, d_pts1, 0, n1, d_pts2, n2);

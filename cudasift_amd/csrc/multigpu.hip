@@ -143,6 +143,7 @@ struct misift_comm {
   int *h_all_counts;            // pinned mirror
   int cap_frames;
   std::vector<GatherSlot> slots;
+  hipEvent_t ev_fork, ev_gathered;   // sharded matcher: inputs ready on the context stream / set 2 complete on the communication stream
 };
 
 // ---- RCCL transport
@@ -329,7 +330,7 @@ static int comm_finish_create(misift_ctx *ctx, ncclComm_t nc, bool owns, misift_
   c->ctx = ctx; c->nccl = nc; c->owns_nccl = owns; c->world = world;
   c->tp = world ? &kLoopbackTransport : &kRcclTransport;
   c->rank = 0; c->nranks = 1; c->stream = nullptr;
-  c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0;
+  c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0; c->ev_gathered = nullptr; c->ev_fork = nullptr;
   c->slots.resize(MISIFT_GATHER_SLOTS);
   for (GatherSlot &s : c->slots) { memset(&s, 0, sizeof(s)); }
   *out = c;                                           // from here on misift_comm_destroy cleans up after a failure
@@ -361,6 +362,8 @@ extern "C" void misift_comm_destroy(misift_comm *c)
   if (c->stream) hipStreamDestroy(c->stream);
   for (GatherSlot &s : c->slots)
     if (s.ready) hipEventDestroy(s.ready);
+  if (c->ev_gathered) hipEventDestroy(c->ev_gathered);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->d_all_counts) hipFree(c->d_all_counts);
   if (c->h_all_counts) hipHostFree(c->h_all_counts);
   delete c;
@@ -553,15 +556,40 @@ extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_row
   const int nr = c->nranks;
   const long long n2 = (long long)shard_count * nr;
   MG_CHECK(n2 < (1ll << 31));
-  // 1. replicate set 2: all-gather of the record shards (576 B x shard_count per rank; 57.6 MB at 100k) on the context
-  //    stream — it must precede the sweep, there is nothing to overlap it with
+  // 1. replicate set 2: all-gather of the record shards (576 B x shard_count per rank; 57.6 MB at 100k).  With more than
+  //    one rank it runs on the communication stream while the context stream already sweeps the super-tiles that lie
+  //    entirely inside this rank's OWN shard (read from d_shard2 where it is); the rest of the columns follow behind the
+  //    all-gather's event.  Same result bits as one sweep (launch_match_split).
+  const long long own_begin = (long long)c->rank * shard_count, own_end = own_begin + shard_count;
+  int own_t0 = (int)((own_begin + 63) / 64), own_t1 = (int)(own_end / 64);
+  const bool split = nr > 1 && shard_count && row_count && own_t1 > own_t0 && !getenv("MISIFT_MATCH_NO_OVERLAP");
+  hipEvent_t gathered = nullptr;
   if (shard_count) {
-    int rc = c->tp->allgather(c, d_shard2, d_set2_all, (size_t)shard_count * sizeof(SiftPointD), ctx->stream);
+    if (split) {
+      if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(c->ev_fork, ctx->stream));  // the shard is written, d_set2_all's previous readers are done
+      HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+    }
+    hipStream_t ag_stream = split ? c->stream : ctx->stream;
+    if (split) {
+      // the own-shard sweep is enqueued BEFORE the exchange is posted (the loopback transport blocks the host in it)
+      int rc = launch_match_split(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2,
+                                  (const SiftPointD *)d_shard2 - own_begin, own_t0, own_t1, nullptr, MATCH_PHASE_OWN);
+      if (rc) return rc;
+    }
+    int rc = c->tp->allgather(c, d_shard2, d_set2_all, (size_t)shard_count * sizeof(SiftPointD), ag_stream);
     if (rc) return rc;
+    if (split) {
+      if (!c->ev_gathered) HIP_TRY(hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(c->ev_gathered, c->stream));
+      gathered = c->ev_gathered;
+    }
   }
-  // 2. this rank's rows against all of set 2 (fp32 MFMA sweep, same kernel as misift_match)
+  // 2. this rank's rows against (the rest of) set 2 (fp32 MFMA sweep, same kernel as misift_match) and the merge
   if (row_count && n2) {
-    int rc = launch_match(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2);
+    int rc = split ? launch_match_split(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2,
+                                        (const SiftPointD *)d_shard2 - own_begin, own_t0, own_t1, gathered, MATCH_PHASE_REST)
+                   : launch_match(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2);
     if (rc) return rc;
   }
   // 3. results: 12 B per row, all-gathered so every rank holds the whole answer (row blocks in rank order)

@@ -390,6 +390,11 @@ int misift_malloc_managed(size_t bytes, void **out);
 int misift_test_elementary(misift_ctx *ctx, int fn, const float *d_x, const float *d_y, float *d_out, float *d_out2,
                            int n);
 
+/* Test-only: MatchSiftData with the column sweep cut the way misift_match_sharded cuts it (64-column super-tiles
+ * [own_tile_begin, own_tile_end) in a first launch, all others in a second, one merge).  Same results as misift_match. */
+int misift_test_match_split(misift_ctx *ctx, void *d_pts1, int n1, const void *d_pts2, int n2, int own_tile_begin,
+                            int own_tile_end);
+
 /* ------------------------------------------------------------------- timing */
 
 /* TimerGPU (cudautils.h:61-81): event pair on the context stream. */

@@ -321,3 +321,71 @@ def test_loopback_world_reports_a_missing_rank(ctx):
     comm.close()
     c.close()
     lw.close()
+
+
+# the set-2 all-gather used to precede the whole sweep.  With more than one rank the sweep of the
+# super-tiles inside the rank's OWN shard now runs while the exchange is on the communication stream, the other columns
+# follow behind its event, one merge covers both launches.
+def _match_rank(capi, rank, world, lw, rows, shard, out, errs):
+    try:
+        c = capi.Context(0)
+        comm = capi.Comm(c, world, rank, lw)
+        n1, n2 = rows * world, shard * world
+        p1 = descriptors_to_points(synth_descriptors(n1, 41), capi.POINT_DTYPE)
+        p2 = descriptors_to_points(synth_descriptors(n2, 42), capi.POINT_DTYPE)
+        p2["data"][3 * shard // 2] = p2["data"][shard // 3]            # an exact tie across two shards: the smaller column wins
+        d1 = c.upload(p1[rank * rows:(rank + 1) * rows])
+        d2 = c.upload(p2[rank * shard:(rank + 1) * shard])
+        all2 = c.zeros(576 * n2)
+        res = c.zeros(12 * n1)
+        c.profile_enable(True)
+        for _ in range(2):                                            # twice: the buffers and events are reused
+            comm.match_sharded(d1.ptr, rows, d2.ptr, shard, all2.ptr, res.ptr)
+        prof = c.profile_read()
+        c.profile_enable(False)
+        out[rank] = dict(rows=c.download(d1, (rows,), capi.POINT_DTYPE), res=c.download(res, (n1,), capi.RESULT_DTYPE),
+                         p1=p1, p2=p2, sweeps=prof["match_mfma"]["calls"])
+        comm.close()
+        c.close()
+    except Exception as e:                         # noqa: BLE001
+        import traceback
+        errs.append("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,rows,shard,overlap", [(3, 70, 333, True), (3, 70, 333, False), (8, 40, 130, True), (2, 33, 40, True)])
+def test_loopback_match_sharded_overlaps_the_exchange(ctx, world, rows, shard, overlap):
+    """Own-shard sweep beside the all-gather + the rest behind it == one sweep over all of set 2, bit for bit (shard sizes
+    that are not multiples of 64, a partial last tile, an exact tie across shards, a shard too small to hold a super-tile)."""
+    import os
+    from cudasift_amd import capi
+    if not overlap:
+        os.environ["MISIFT_MATCH_NO_OVERLAP"] = "1"
+    try:
+        lw = capi.LoopbackWorld(world)
+        out, errs = {}, []
+        ts = [threading.Thread(target=_match_rank, args=(capi, r, world, lw, rows, shard, out, errs)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=600)
+    finally:
+        os.environ.pop("MISIFT_MATCH_NO_OVERLAP", None)
+    assert not any(t.is_alive() for t in ts), "a loopback rank is stuck"
+    assert not errs, "\n".join(errs)
+    lw.close()
+    p1, p2 = out[0]["p1"], out[0]["p2"]
+    ref = ctx.match(p1, len(p1), p2, len(p2))
+    from oracle import pyoracle
+    exp = p1.copy()
+    pyoracle.match(exp, len(exp), p2, len(p2))
+    for f in ("score", "ambiguity", "match"):
+        assert np.array_equal(ref[f], exp[f]), f
+    for r in range(world):
+        for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+            assert np.array_equal(out[r]["rows"][f], ref[f][r * rows:(r + 1) * rows]), (r, f)
+        for f in ("score", "ambiguity", "match"):
+            assert np.array_equal(out[r]["res"][f], ref[f]), (r, f)
+        lo, hi = (r * shard + 63) // 64, ((r + 1) * shard) // 64
+        two = overlap and hi > lo
+        assert out[r]["sweeps"] == (4 if two else 2), (r, out[r]["sweeps"])      # two calls: 2 launches each when split
+    record("loopback_match_overlap_%d_%d_%d" % (world, shard, overlap), ok=True)

@@ -307,6 +307,27 @@ def test_match_rows_split(ctx):
         assert np.array_equal(full[f], part[f])
 
 
+@pytest.mark.parametrize("n2,t0,t1", [(1536, 0, 24), (1536, 5, 9), (2085, 0, 3), (2085, 31, 33), (2085, 12, 12), (100, 0, 1)])
+def test_match_column_split_is_bit_identical(ctx, n2, t0, t1):
+    """The two-launch column cut of the sharded matcher (own super-tiles first, the rest around them, one merge over the
+    chunks of both) gives the single sweep's bits, ties included (duplicated columns on both sides of the cut)."""
+    o = orc()
+    n1 = 333
+    p1 = descriptors_to_points(synth_descriptors(n1, 51), o.POINT_DTYPE)
+    p2 = descriptors_to_points(synth_descriptors(n2, 52), o.POINT_DTYPE)
+    if n2 > 700:
+        p2["data"][64 * 6 + 3] = p2["data"][17]             # ties straddling the cut: the smaller column must win
+        p2["data"][64 * 2 + 1] = p2["data"][64 * 8 + 7]
+    ref = p1.copy()
+    o.match(ref, n1, p2, n2)
+    one = ctx.match(p1, n1, p2, n2)
+    two = ctx.match_split(p1, n1, p2, n2, t0, t1)
+    for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+        assert np.array_equal(one[f], two[f]), f
+    for f in ("score", "ambiguity", "match"):
+        assert np.array_equal(ref[f], two[f]), f
+
+
 def test_match_real_descriptors(ctx, stereo):
     a, na, _ = ctx.extract(stereo[0], thresh=4.5)
     b, nb, _ = ctx.extract(stereo[1], thresh=4.5)
