@@ -72,6 +72,14 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+DESC_STRIDE = 4
+
+
+def wide_1080p(left_u8):
+    """1920x1080 from the 1280x960 left.pgm by mirroring 320 columns / 60 rows outwards (np.pad reflect)."""
+    return np.pad(left_u8, ((60, 60), (320, 320)), mode="reflect").astype(np.float32)
+
+
 def sorted_records(pts, total):
     p = pts[:total]
     order = np.lexsort((p["orientation"], p["scale"], p["xpos"], p["ypos"], p["subsampling"]))
@@ -95,12 +103,20 @@ def refemul_golden(left, right, crop):
     out["sha_scaledown_odd"] = sha(ref.scaledown(odd, "fast"))
     out["sha_laplace_odd"] = sha(ref.laplace(odd, 5, 3, "fast"))
     # whole ExtractSift
-    for name, img, noct, th in (("crop", crop, 4, 3.5), ("left", left.astype(np.float32), 5, 4.5)):
-        pts, n, cnt = ref.extract(img, noct, 1.0, th, flavour="fast")
+    # "wide" = the bench workload's shape and parameters (1920x1080, 5 octaves, initBlur 1.0, thresh 3.0: mainSift.cpp:58-67)
+    # on a natural image: left.pgm mirrored outwards (integer indexing only, so the input is reproducible from the
+    # committed stereo pair); "righ" = the other image of the pair at the demo's threshold; "crop_up" = scaleUp
+    for name, img, noct, th, up in (("crop", crop, 4, 3.5, False), ("left", left.astype(np.float32), 5, 4.5, False),
+                                    ("wide", wide_1080p(left), 5, 3.0, False), ("righ", right.astype(np.float32), 5, 4.5, False),
+                                    ("crop_up", crop, 4, 3.5, True)):
+        pts, n, cnt = ref.extract(img, noct, 1.0, th, scale_up=up, flavour="fast")
         total = int(cnt[2 * noct + 1])
         out[name + "_n"] = n
         out[name + "_counters"] = cnt
-        out[name + "_records"] = sorted_records(pts, total)
+        recs = sorted_records(pts, total)
+        if name in ("wide", "righ", "crop_up"):        # keep the file small: every field of every record, but the 128-float
+            recs["data"][np.arange(total) % DESC_STRIDE != 0] = 0.0     # descriptor of every DESC_STRIDE-th (sorted) record only
+        out[name + "_records"] = recs
     # MatchSiftData on seeded descriptors (n2 % 32 != 0: the reference ignores the last n2 % 32 columns)
     a = descriptors_to_points(synth_descriptors(1000, 7), POINT_DTYPE)
     b = descriptors_to_points(synth_descriptors(1500, 8), POINT_DTYPE)

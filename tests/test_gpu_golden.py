@@ -47,19 +47,31 @@ def test_dense_stages_equal_reference_kernels(ctx, stereo, golden):
     assert sha(ctx.laplace(odd, 5, 3)) == str(golden["sha_laplace_odd"])
 
 
+def _golden_image(stereo, name):
+    crop = stereo[0][300:540, 400:720].copy()
+    if name in ("crop", "crop_up"):
+        return crop
+    if name == "wide":         # 1920x1080: left.pgm mirrored outwards (tests/golden/make_fixtures.py::wide_1080p)
+        return np.pad(stereo[0], ((60, 60), (320, 320)), mode="reflect").astype(np.float32)
+    return stereo[0] if name == "left" else stereo[1]
+
+
 @pytest.mark.parametrize("fused", [1, 0])
-@pytest.mark.parametrize("name,noct,th", [("crop", 4, 3.5), ("left", 5, 4.5)])
-def test_extract_equals_reference_kernels(ctx, stereo, golden, name, noct, th, fused):
-    img = stereo[0][300:540, 400:720].copy() if name == "crop" else stereo[0]
+@pytest.mark.parametrize("name,noct,th,up,flips", [("crop", 4, 3.5, False, 0), ("left", 5, 4.5, False, 0),
+                                                   ("wide", 5, 3.0, False, 2), ("righ", 5, 4.5, False, 2),
+                                                   ("crop_up", 4, 3.5, True, 1)])
+def test_extract_equals_reference_kernels(ctx, stereo, golden, name, noct, th, up, flips, fused):
+    """`wide` is the bench workload's shape and parameters (1920x1080, 5 octaves, initBlur 1.0, thresh 3.0)."""
+    img = _golden_image(stereo, name)
     saved = ctx.get_options()
     ctx.set_options(fused=fused)
     try:
-        pts, n, cnt = ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=th)
+        pts, n, cnt = ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=th, scale_up=up)
     finally:
         ctx.set_options(fused=saved.fused)
     assert n == int(golden[name + "_n"])
     compare_with_reference(pts, cnt, golden[name + "_records"], golden[name + "_counters"], noct,
-                           "hip_vs_reference_golden/%s_fused%d" % (name, fused), "ulp", record)
+                           "hip_vs_reference_golden/%s_fused%d" % (name, fused), "ulp", record, flip_budget=flips, desc_stride=4 if name in ("wide", "righ", "crop_up") else 1)
 
 
 def test_match_equals_reference_kernel(ctx, golden):

@@ -194,6 +194,24 @@ def test_extract_scaleup_and_lowest_scale_pinned(stereo):
 
 
 @needs_ref
+@pytest.mark.parametrize("noct,blur,th,ls", [(5, 0.0, 3.0, 0.0), (5, 0.5, 2.0, 0.0), (4, 2.0, 1.0, 0.0), (1, 1.0, 2.0, 0.0),
+                                             (6, 1.0, 1.5, 0.0), (3, 1.0, 2.0, 3.0), (2, 1.0, 0.2, 0.0)])
+def test_extract_parameter_sweep_pinned(stereo, noct, blur, th, ls):
+    """The ExtractSift argument surface on a 320x240 crop: initBlur 0 (the reference clamps sigma to 0.001: a delta
+    kernel), 0.5, 2.0; 1 and 6 octaves (coarsest level 10x7 px); lowestScale > 0; a threshold so low that a third of the
+    tiles hit the reference's 32-candidates-per-tile cap.  Counters and keypoint set identical, positions the same bits."""
+    from conftest import record
+    img = stereo[0][200:440, 300:620].copy()
+    r_pts, r_n, r_cnt = ref.extract(img, noct, blur, th, lowest_scale=ls, flavour="fast")
+    orc.stats_reset()
+    with orc.contract(1):
+        o_pts, o_n, o_cnt = orc.extract(img, noct, blur, th, lowest_scale=ls)
+    assert o_n == r_n and o_n > 40
+    compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, "refemul_sweep/o%d_b%g_t%g_l%g" % (noct, blur, th, ls), "bits",
+                           record)
+
+
+@needs_ref
 def test_matcher_pinned_to_reference_kernel(stereo):
     """MatchSiftData = CleanMatches + FindMaxCorr10 (matching.cu:289-397) on the emulator: score, ambiguity (the lossy
     8-class runner-up merge), match, match_xpos/ypos are the oracle's bits, incl. the n2 % 32 truncation."""
@@ -264,14 +282,20 @@ def test_golden_dense_stages(stereo, golden):
     assert sha(orc.laplace(odd, 5, 3)) == str(golden["sha_laplace_odd"])
 
 
-@pytest.mark.parametrize("name,noct,th", [("crop", 4, 3.5), ("left", 5, 4.5)])
-def test_golden_extract(stereo, golden, name, noct, th):
-    img = stereo[0][300:540, 400:720].copy() if name == "crop" else stereo[0]
+@pytest.mark.parametrize("name,noct,th,up,flips", [("crop", 4, 3.5, False, 0), ("left", 5, 4.5, False, 0),
+                                                   ("wide", 5, 3.0, False, 2), ("righ", 5, 4.5, False, 2),
+                                                   ("crop_up", 4, 3.5, True, 1)])
+def test_golden_extract(stereo, golden, name, noct, th, up, flips):
+    """`wide`: 1920x1080 with the bench's parameters (left.pgm mirrored outwards); `crop_up`: scaleUp."""
+    crop = stereo[0][300:540, 400:720].copy()
+    img = {"crop": crop, "crop_up": crop, "left": stereo[0], "righ": stereo[1],
+           "wide": np.pad(stereo[0], ((60, 60), (320, 320)), mode="reflect").astype(np.float32)}[name]
     orc.stats_reset()
     with orc.contract(1):
-        pts, n, cnt = orc.extract(img, noct, 1.0, th)
+        pts, n, cnt = orc.extract(img, noct, 1.0, th, scale_up=up)
     assert n == int(golden[name + "_n"])
-    compare_with_reference(pts, cnt, golden[name + "_records"], golden[name + "_counters"], noct, "golden/" + name, "bits")
+    compare_with_reference(pts, cnt, golden[name + "_records"], golden[name + "_counters"], noct, "golden/" + name, "bits",
+                           flip_budget=flips, desc_stride=4 if name in ("wide", "righ", "crop_up") else 1)
 
 
 def test_golden_match_and_homography(golden):
