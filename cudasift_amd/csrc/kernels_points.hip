@@ -1068,6 +1068,9 @@ __device__ __forceinline__ void descr_write(SiftPointD *sift, SiftPointD *pack_d
                                             unsigned dst, int lane, float o0, float o1v, const Detection &d,
                                             float orientation, float subsampling, float out_scale)
 {
+  // out_scale is 1, or 0.5 with scaleUp: the reference's RescalePositions (cudaSiftH.cu:130) folded into the write.  It
+  // covers numPts records, so the callers pass 1 for the finest octave's second orientations, which lie PAST numPts
+  // (cudaSiftH.cu:115) and keep their unscaled coordinates in the reference's device array.
   const int cell = lane >> 2;
 #pragma unroll
   for (int tgt = 0; tgt < 2; tgt++) {
@@ -1273,7 +1276,7 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
         float o0, o1v;
         descr_accumulate(buf, lane, vx, vy, ang, o0, o1v);
         descr_write(sift, pack_dst, pack_off, pack_cnt, first ? dstA : dstB, lane, o0, o1v, d, first ? d.ori1 : d.ori2,
-                    subsampling, P.out_scale);
+                    subsampling, (!first && o == P.noct) ? 1.0f : P.out_scale);
       }
     }
     wave_sync();                                          // the buffer is free (and all zero or about to be overwritten)
@@ -1322,7 +1325,7 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
       descr_core(img, L.w, L.h, L.p, Q8, d.xpos, d.ypos, d.scale, which == 0 ? d.ori1 : d.ori2, s_smp[wave], s_gauss[wave],
                  lane, o0, o1v);
       descr_write(sift, pack_dst, pack_off, pack_cnt, dst, lane, o0, o1v, d, which == 0 ? d.ori1 : d.ori2, L.subsampling,
-                  P.out_scale);
+                  (which == 1 && o == P.noct) ? 1.0f : P.out_scale);
     }
   }
 }
@@ -1435,9 +1438,10 @@ __global__ __launch_bounds__(256, 4) void descr_all_gather_kernel(const float *_
         p->data[8 * cell + (lane & 3)] = o0;
         p->data[8 * cell + (lane & 3) + 4] = o1;
         if (lane == 0) {
-          p->xpos = d.xpos * L.subsampling * P.out_scale;       // out_scale is 1 or 0.5: exact, = a later RescalePositions
-          p->ypos = d.ypos * L.subsampling * P.out_scale;
-          p->scale = d.scale * L.subsampling * P.out_scale;
+          const float os = (which == 1 && o == P.noct) ? 1.0f : P.out_scale;   // records past numPts are not rescaled
+          p->xpos = d.xpos * L.subsampling * os;       // out_scale is 1 or 0.5: exact, = a later RescalePositions
+          p->ypos = d.ypos * L.subsampling * os;
+          p->scale = d.scale * L.subsampling * os;
           p->sharpness = d.sharpness;
           p->edgeness = d.edgeness;
           p->orientation = which == 0 ? d.ori1 : d.ori2;

@@ -12,3 +12,4 @@ import json; d=json.load(open('gpurun_out/r03_split_tail_${st}_$rep.json')); r=d
 print('rep $rep split_tail=$st fps', d['value'], 'ms', d['ms_per_step'], 'frac', r['frac'], 'single', (r.get('single_launch') or {}).get('frac'), 'K', d['config'].get('batches_in_flight'))"
 done
 done
+timeout 600 python -m pytest tests/test_gpu_golden.py -q -m gpu 2>&1 | tail -4
