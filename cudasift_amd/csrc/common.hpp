@@ -142,6 +142,9 @@ __device__ __forceinline__ float4 load_quad(const float *row, int q, int width, 
 // row is ONE unconditional dwordx4 load, and the clamp-to-edge semantics for the halo quads left /
 // right of the image are restored with selects (splat of column 0 / column width-1) — no divergent
 // branches in the streaming loops.
+// Wave votes on a bool: one v_cmp + s_and (+ s_cmp) — HIP's __any(int) goes through v_cndmask 0/1 + v_cmp_ne first.
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 struct QuadCol {
   int off;      // float offset of the clamped quad within a row
   int edge;     // -1: quad lies left of the image, +1: right of it, 0: inside;

@@ -422,9 +422,39 @@ struct LdsTaps {
 #ifndef SCAN_TAP_PREFETCH
 #define SCAN_TAP_PREFETCH (!SCAN_RING)
 #endif
+// d = a - b as ONE v_sub_f32.  Written as asm because the SLP vectoriser otherwise pairs two of the row's twenty DoG
+// subtractions into a v_pk_add_f32 with a negated operand and spends three v_mov assembling its register pairs (r03 ISA:
+// 10 v_mov + 5 v_pk_add + 10 v_sub per row where 20 v_sub do).  Same IEEE subtraction.
+__device__ __forceinline__ float sub1(float a, float b)
+{
+  float r;
+  asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max(|a|, |b|, |c|) and max(m, |w|) as ONE instruction each (source modifiers): fmaxf/fabsf chains compile to twice as
+// many (separate |.| pairs plus canonicalising v_max x, x) — 22 instead of 12 per row for the five planes' maxima.
+__device__ __forceinline__ float absmax3(float a, float b, float c)
+{
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max_abs(float m, float w)
+{
+  float r;
+  asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(m), "v"(w));
+  return r;
+}
+__device__ __forceinline__ float max3v(float a, float b, float c)
+{
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 struct ScanRowCtx {
   int width, height, q;
   bool tester;
+  unsigned long long tester_mask;        // ballot of `tester`, once per strip
   float thresh;
   unsigned *cnt, *list;
   unsigned cand_cap;
@@ -455,12 +485,12 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
   asm volatile("" ::: "memory");                                 // re-read from LDS: do not pin tap pairs across the row loop
   tnext = taps_src.pair(2);
   __builtin_amdgcn_sched_barrier(0);
-  d[0] = make_float4(b0.x.y - b0.x.x, b0.y.y - b0.y.x, b0.z.y - b0.z.x, b0.w.y - b0.w.x);
+  d[0] = make_float4(sub1(b0.x.y, b0.x.x), sub1(b0.y.y, b0.y.x), sub1(b0.z.y, b0.z.x), sub1(b0.w.y, b0.w.x));
   const Pair4 b1 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 3, 4
   tcur = tnext;
   __builtin_amdgcn_sched_barrier(0);
-  d[1] = make_float4(b1.x.x - b0.x.y, b1.y.x - b0.y.y, b1.z.x - b0.z.y, b1.w.x - b0.w.y);
-  d[2] = make_float4(b1.x.y - b1.x.x, b1.y.y - b1.y.x, b1.z.y - b1.z.x, b1.w.y - b1.w.x);
+  d[1] = make_float4(sub1(b1.x.x, b0.x.y), sub1(b1.y.x, b0.y.y), sub1(b1.z.x, b0.z.y), sub1(b1.w.x, b0.w.y));
+  d[2] = make_float4(sub1(b1.x.y, b1.x.x), sub1(b1.y.y, b1.y.x), sub1(b1.z.y, b1.z.x), sub1(b1.w.y, b1.w.x));
   const Pair4 b2 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 5, 6
 #else
   // one set of tap pairs at a time (10 registers instead of 20): with four wavefronts per SIMD the LDS latency of the
@@ -471,41 +501,41 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
   asm volatile("" ::: "memory");
   tcur = taps_src.pair(1);
   __builtin_amdgcn_sched_barrier(0);
-  d[0] = make_float4(b0.x.y - b0.x.x, b0.y.y - b0.y.x, b0.z.y - b0.z.x, b0.w.y - b0.w.x);
+  d[0] = make_float4(sub1(b0.x.y, b0.x.x), sub1(b0.y.y, b0.y.x), sub1(b0.z.y, b0.z.x), sub1(b0.w.y, b0.w.x));
   const Pair4 b1 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 3, 4
   asm volatile("" ::: "memory");
   tcur = taps_src.pair(2);
   __builtin_amdgcn_sched_barrier(0);
-  d[1] = make_float4(b1.x.x - b0.x.y, b1.y.x - b0.y.y, b1.z.x - b0.z.y, b1.w.x - b0.w.y);
-  d[2] = make_float4(b1.x.y - b1.x.x, b1.y.y - b1.y.x, b1.z.y - b1.z.x, b1.w.y - b1.w.x);
+  d[1] = make_float4(sub1(b1.x.x, b0.x.y), sub1(b1.y.x, b0.y.y), sub1(b1.z.x, b0.z.y), sub1(b1.w.x, b0.w.y));
+  d[2] = make_float4(sub1(b1.x.y, b1.x.x), sub1(b1.y.y, b1.y.x), sub1(b1.z.y, b1.z.x), sub1(b1.w.y, b1.w.x));
   const Pair4 b2 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 5, 6
 #endif
-  d[3] = make_float4(b2.x.x - b1.x.y, b2.y.x - b1.y.y, b2.z.x - b1.z.y, b2.w.x - b1.w.y);
-  d[4] = make_float4(b2.x.y - b2.x.x, b2.y.y - b2.y.x, b2.z.y - b2.z.x, b2.w.y - b2.w.x);
+  d[3] = make_float4(sub1(b2.x.x, b1.x.y), sub1(b2.y.x, b1.y.y), sub1(b2.z.x, b1.z.y), sub1(b2.w.x, b1.w.y));
+  d[4] = make_float4(sub1(b2.x.y, b2.x.x), sub1(b2.y.y, b2.y.x), sub1(b2.z.y, b2.z.x), sub1(b2.w.y, b2.w.x));
   // |v| maximum of every plane (two instructions each), then of the row
   float am[NUM_SCALES];
 #pragma unroll
-  for (int p = 0; p < NUM_SCALES; p++) am[p] = fmaxf(max3f(fabsf(d[p].x), fabsf(d[p].y), fabsf(d[p].z)), fabsf(d[p].w));
-  const float amax = max3f(max3f(am[0], am[1], am[2]), am[3], am[4]);
+  for (int p = 0; p < NUM_SCALES; p++) am[p] = max_abs(absmax3(d[p].x, d[p].y, d[p].z), d[p].w);
+  const float amax = max3v(max3v(am[0], am[1], am[2]), am[3], am[4]);
   // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
   // (tester lanes only: the halo lanes' blurs see zeros beyond the wavefront and would trip the test in every row —
   //  with them masked, 99 % of the finest level's rows of a typical frame skip the extremum tests)
   if (!SCAN_DO_TEST) {                           // register-pressure probe only (tools/kres.sh -DSCAN_DO_TEST=0)
-    if (__any(tester && amax > thresh)) {
+    if (wave_any(tester && amax > thresh)) {
 #pragma unroll
       for (int p = 0; p < NUM_SCALES; p++) reinterpret_cast<float4 *>(list)[p * 64 + (q & 63)] = d[p];
     }
-  } else if (y >= 1 && y <= g.height - 2 && __any(tester && amax > thresh)) {
+  } else if (y >= 1 && y <= g.height - 2 && (__builtin_amdgcn_fcmpf(amax, thresh, 2 /* ogt */) & g.tester_mask) != 0ull) {
     unsigned mask = 0;
 #pragma unroll
     for (int s = 0; s < NUM_SCALES; s++) {
       // a row that trips the threshold usually does so in one or two planes only: the others are skipped wave-uniformly
       // (every VALU instruction costs the SIMD 3-5 cycles whatever it does; the tests were 15 % of the kernel's time)
-      if (!__any(tester && am[s] > thresh)) continue;
+      if ((__builtin_amdgcn_fcmpf(am[s], thresh, 2 /* ogt */) & g.tester_mask) == 0ull) continue;
       // in-row neighbourhood of centre plane d[s]: columns x-1, x, x+1 of d[s-1], d[s], d[s+1] (where available)
       float lo[4], hi[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+      for (int i = 0; i < 4; i++) { lo[i] = -thresh; hi[i] = thresh; }       // the threshold rides in the min/max chains
 #pragma unroll
       for (int dp = -1; dp <= 1; dp += 2) {
         if (s + dp < 0 || s + dp >= NUM_SCALES) continue;
@@ -524,7 +554,7 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
         const float nmax = max3f(hi[i], v[i], v[i + 2]);
         const float nmin = min3f(lo[i], v[i], v[i + 2]);
         const float cv = v[i + 1];
-        const bool pre = (cv > thresh && cv > nmax) || (cv < -thresh && cv < nmin);
+        const bool pre = cv > nmax || cv < nmin;          // nmax >= thresh, nmin <= -thresh: |cv| > thresh is implied
         mask |= (pre ? 1u : 0u) << (5 * i + s);
       }
     }
@@ -556,7 +586,7 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
 {
   struct { int width, height, pitch; } g = {width, height, pitch};
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
-  const ScanRowCtx rc = {width, height, q, tester, thresh, cnt, list, cand_cap, octave};
+  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave};
   const QuadCol qc = make_quadcol(q, g.width);
   auto ld = [&](int y) -> float4 {
     return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
@@ -609,7 +639,7 @@ __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int
 {
   struct { int width, height, pitch; } g = {width, height, pitch};
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
-  const ScanRowCtx rc = {width, height, q, tester, thresh, cnt, list, cand_cap, octave};
+  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave};
   const QuadCol qc = make_quadcol(q, g.width);
   auto ld = [&](int y) -> float4 {
     return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
@@ -625,9 +655,8 @@ __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int
                  p1 = add4p(mine[o3], mine[o5]), c = mine[o4];
     scan_row(taps_src, rc, c, p1, p2, p3, p4, y);
     asm volatile("" ::: "memory");
-    const float4 nn = ld(y + 6);               // next prefetch first, then park the row that has arrived:
-    mine[o0] = n;                              // row y+5 takes the slot of row y-4
-    n = nn;
+    mine[o0] = n;                              // row y+5 (loaded one row ago) takes the slot of row y-4,
+    n = ld(y + 6);                             // then ITS registers take the next prefetch: no second set, no copies
   };
 #define RING_SLOT(J, K) ((((J) + (K)) % RING_ROWS) * 64)
 #define RING_STEP(J)                                                                                                  \
