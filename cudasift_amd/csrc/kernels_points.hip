@@ -973,8 +973,19 @@ __device__ __forceinline__ void descr_samples_tile(const float *tile, int x0, in
   }
 }
 
-// 8x8 footprint of a cell, four rows at a time (8 b128 loads in flight: the fully unrolled form holds 64 registers)
-__device__ __forceinline__ float footprint_sum2(const float *base, float acc)
+// 8x8 footprint of a cell, four rows at a time (8 b128 loads in flight: the fully unrolled form holds 64 registers and
+// makes the compiler spill the prefetched window).  The 64 weights wy(row) * spatial_w(column) come from a per-wavefront
+// LDS table (footprint_weights_init; wave-uniform ds_read_b128, no VALU): the rolled loop used to select wy at run time
+// and multiply the 32 products out again in every trip — 16 v_mul + 4 v_cndmask per trip, 80 of a descriptor's ~970
+// instructions (r03).  Same products (one IEEE multiplication each), same FMA order.
+__device__ __forceinline__ void footprint_weights_init(float *wt, int lane)
+{
+  const int my = lane >> 3, mx = lane & 7;
+  const float wy = my < 4 ? (my + 0.5f) * 0.25f : (3.5f - (my - 4)) * 0.25f;       // = the old wy of row 4h + r
+  const float wx = mx < 4 ? (mx + 0.5f) * 0.25f : (7.5f - mx) * 0.25f;             // = spatial_w(mx)
+  wt[lane] = wy * wx;
+}
+__device__ __forceinline__ float footprint_sum2(const float *base, const float *wt, float acc)
 {
 #pragma unroll 1
   for (int h = 0; h < 2; h++) {
@@ -983,16 +994,16 @@ __device__ __forceinline__ float footprint_sum2(const float *base, float acc)
       const int my = 4 * h + r;
       const float4 lo = *reinterpret_cast<const float4 *>(base + my * SMP_W);
       const float4 hi = *reinterpret_cast<const float4 *>(base + my * SMP_W + 4);
-      // spatial_w(my) for my = 4h + r: (r + 0.5)/4 in the upper half, (3.5 - r)/4 in the lower one
-      const float wy = h == 0 ? (r + 0.5f) * 0.25f : (3.5f - r) * 0.25f;
-      acc = __builtin_fmaf(wy * spatial_w(0), lo.x, acc);
-      acc = __builtin_fmaf(wy * spatial_w(1), lo.y, acc);
-      acc = __builtin_fmaf(wy * spatial_w(2), lo.z, acc);
-      acc = __builtin_fmaf(wy * spatial_w(3), lo.w, acc);
-      acc = __builtin_fmaf(wy * spatial_w(4), hi.x, acc);
-      acc = __builtin_fmaf(wy * spatial_w(5), hi.y, acc);
-      acc = __builtin_fmaf(wy * spatial_w(6), hi.z, acc);
-      acc = __builtin_fmaf(wy * spatial_w(7), hi.w, acc);
+      const float4 wl = *reinterpret_cast<const float4 *>(wt + 8 * my);
+      const float4 wh = *reinterpret_cast<const float4 *>(wt + 8 * my + 4);
+      acc = __builtin_fmaf(wl.x, lo.x, acc);
+      acc = __builtin_fmaf(wl.y, lo.y, acc);
+      acc = __builtin_fmaf(wl.z, lo.z, acc);
+      acc = __builtin_fmaf(wl.w, lo.w, acc);
+      acc = __builtin_fmaf(wh.x, hi.x, acc);
+      acc = __builtin_fmaf(wh.y, hi.y, acc);
+      acc = __builtin_fmaf(wh.z, hi.z, acc);
+      acc = __builtin_fmaf(wh.w, hi.w, acc);
     }
   }
   return acc;
@@ -1001,7 +1012,7 @@ __device__ __forceinline__ float footprint_sum2(const float *base, float acc)
 // Votes -> normalised descriptor bins (8*cell + (lane&3)) and (+4).  tbl: FOUR per-bin planes [bin][20][20] over the
 // 16x16 sample grid (2-sample zero border), all zero on entry and on exit; bins 0..3 first, then the same planes are
 // re-used for bins 4..7 (see the comment above SMP_W).  Sample j of this lane sits at plane position pos_j.
-__device__ __forceinline__ void descr_accumulate(float *tbl, int lane, const float (&vx)[4], const float (&vy)[4],
+__device__ __forceinline__ void descr_accumulate(float *tbl, const float *wt, int lane, const float (&vx)[4], const float (&vy)[4],
                                                  const int (&ang)[4], float &out0, float &out1)
 {
   const int cell = lane >> 2, cx = cell & 3, cy = cell >> 2;
@@ -1023,7 +1034,7 @@ __device__ __forceinline__ void descr_accumulate(float *tbl, int lane, const flo
     if (by[j] < 4) tbl[by[j] * SMP_PLANE + pos[j]] = vy[j];
   }
   wave_sync();
-  float acc0 = footprint_sum2(mine, 0.0f);
+  float acc0 = footprint_sum2(mine, wt, 0.0f);
   wave_sync();
   // ---- bins 4..7 re-use planes 0..3 (a lane's pass-A and pass-B slots never coincide: different plane or position)
 #pragma unroll
@@ -1034,7 +1045,7 @@ __device__ __forceinline__ void descr_accumulate(float *tbl, int lane, const flo
     if (by[j] >= 4) tbl[(by[j] - 4) * SMP_PLANE + pos[j]] = vy[j];
   }
   wave_sync();
-  float acc1 = footprint_sum2(mine, 0.0f);
+  float acc1 = footprint_sum2(mine, wt, 0.0f);
   wave_sync();
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -1052,7 +1063,7 @@ __device__ __forceinline__ void descr_accumulate(float *tbl, int lane, const flo
     wave_sync();
     if ((lane & 3) == 0 && cell >= 1) {
       const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
-      acc0 = footprint_sum2(tbl + (4 * pcy) * SMP_W + 4 * pcx, acc0);
+      acc0 = footprint_sum2(tbl + (4 * pcy) * SMP_W + 4 * pcx, wt, acc0);
     }
     wave_sync();
 #pragma unroll
@@ -1132,6 +1143,7 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
     float buf[PATCH_FLOATS];      // window, then vote table
     float park[12 * 64];          // votes of a first orientation while the second is sampled
     float gauss[16];
+    float wtab[64];               // footprint weights wy(row) * wx(column)
   };
   __shared__ WaveLds s_w[WAVES_PER_BLOCK];
   static_assert(PATCH_FLOATS == 4 * SMP_PLANE, "the window and the four vote planes share one buffer");
@@ -1147,6 +1159,7 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
   float *buf = s_w[wave].buf;
   const float *gauss = s_w[wave].gauss;
   if (lane < 16) s_w[wave].gauss[lane] = det_exp(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
+  footprint_weights_init(s_w[wave].wtab, lane);
   // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
   if (blockIdx.x == 0 && threadIdx.x == 0) {             // publish the reference's counters (cudaSiftD.cu:14)
     unsigned b = 0;
@@ -1280,7 +1293,7 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
         }
         const bool first = k == 0 && doA;
         float o0, o1v;
-        descr_accumulate(buf, lane, vx, vy, ang, o0, o1v);
+        descr_accumulate(buf, s_w[wave].wtab, lane, vx, vy, ang, o0, o1v);
         descr_write(sift, pack_dst, pack_off, pack_cnt, first ? dstA : dstB, lane, o0, o1v, d, first ? d.ori1 : d.ori2,
                     subsampling, (!first && o == P.noct) ? 1.0f : P.out_scale);
       }
