@@ -1002,7 +1002,7 @@ def main():
                                                    "transcendentals": 8.5},
         "note": "tools/valu_rates, tools/scan_rates (profiles/r02_valu_rates.txt, r02_scan_rates.txt; whole-kernel times): "
                 "a SIMD is saturated from 2-3 resident wavefronts on, occupancy beyond that buys nothing.  One scan row is 96 "
-                "v_pk_fma + 24 v_pk_mul + 56 v_pk_add + 48 DPP moves + 20 v_sub + 10 v_max3 = ~1085 cycles for 35.1 kflop "
+                "v_pk_fma + 24 v_pk_mul + 56 v_pk_add + 48 DPP moves + 20 v_sub + 12 v_max/v_max3 = ~1085 cycles for 35.1 kflop "
                 "executed (isolated: 1085 measured), i.e. 0.50 of 64 flop/cycle/SIMD is the ceiling of this instruction "
                 "stream before halo lanes, segment prologues and the extremum tests; the kernel runs at ~0.88 of its own "
                 "instruction-issue bound (SQ_INSTS_VALU x cost / SIMD cycles)"}
