@@ -76,7 +76,14 @@ REWRITE="$HERE/launch_rewrite.sed"     # the two rewrites (launch syntax; the GP
 # emit one reference .cu with the rewrites applied; cudaSiftH.cu #includes cudaSiftD.cu textually: inline it in the pipe
 ref_tu() {
   sed -f "$REWRITE" "$REF/$1.cu" | while IFS= read -r LINE; do
-    if [ "$LINE" = '#include "cudaSiftD.cu"' ]; then sed -f "$REWRITE" "$REF/cudaSiftD.cu"; else printf '%s\n' "$LINE"; fi
+    if [ "$LINE" = '#include "cudaSiftD.cu"' ]; then
+      sed -f "$REWRITE" "$REF/cudaSiftD.cu"
+      # Everything of cudaSiftH.cu below this point is HOST code (ExtractSift, PrepareLaplaceKernels, the tap generators
+      # of LowPass / ScaleDown): nvcc hands it to the host compiler (g++ -O2 -msse2, CMakeLists.txt:29: no FMA
+      # instructions at all), so it is never contracted, whatever -fmad does to the kernels.  r03: with the host code
+      # contracted too, the Laplace taps of a 6th / 7th octave came out different in 5 / 10 table entries.
+      printf '%s\n' '#pragma GCC optimize ("fp-contract=off")'
+    else printf '%s\n' "$LINE"; fi
   done
 }
 # -fno-toplevel-reorder: __shared__ variables (function-local statics here) are laid out in DECLARATION order, as
