@@ -154,6 +154,15 @@ def test_dense_stages_bit_identical_to_reference_kernels(stereo, shape):
 
 
 @needs_ref
+@pytest.mark.parametrize("noct", [1, 2, 3, 4, 5, 6, 7])
+def test_laplace_taps_equal_reference_host_code(noct):
+    """PrepareLaplaceKernels (cudaSiftH.cu:439-458) is HOST code: never contracted, in either flavour of the emulated
+    build (r03: the contraction flavour used to fuse it and differed in the taps of a 6th / 7th octave)."""
+    for fl in ("fast", "off"):
+        assert np.array_equal(ref.laplace_taps(noct, fl), orc.laplace_taps(noct)), (noct, fl)
+
+
+@needs_ref
 @pytest.mark.parametrize("case", ["left", "right_crop", "synth1080", "synth_odd"])
 def test_extract_pinned_to_reference_kernels(stereo, case):
     """ExtractSift end to end: the reference's host code + six live kernels on the emulator vs the oracle.
