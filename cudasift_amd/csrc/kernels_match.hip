@@ -415,12 +415,12 @@ static int match_plan_param(const char *name, int dflt)
   const int v = e ? atoi(e) : 0;
   return v > 0 ? v : dflt;
 }
-static void plan_chunks(const misift_ctx *ctx, int nrb, int ntiles, int &nchunks, int &tiles_per_chunk)
+static void plan_chunks_cus(int ncu, int nrb, int ntiles, int &nchunks, int &tiles_per_chunk)
 {
   static const int forced = match_plan_param("MISIFT_MATCH_CHUNKS", 0);       // experiments only
   nchunks = 1; tiles_per_chunk = ntiles > 0 ? ntiles : 1;
   if (ntiles <= 0 || nrb <= 0) return;
-  const int ncu = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  if (ncu <= 0) ncu = 256;
   const int cmax = ntiles < 256 ? ntiles : 256;
   double best = 0.0;
   for (int c = 1; c <= cmax; c++) {
@@ -436,6 +436,20 @@ static void plan_chunks(const misift_ctx *ctx, int nrb, int ntiles, int &nchunks
     tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
     nchunks = (ntiles + tiles_per_chunk - 1) / tiles_per_chunk;
   }
+}
+
+static void plan_chunks(const misift_ctx *ctx, int nrb, int ntiles, int &nchunks, int &tiles_per_chunk)
+{
+  plan_chunks_cus(ctx->num_cus, nrb, ntiles, nchunks, tiles_per_chunk);
+}
+// host-only test hook (no device needed): the chunk plan for n1 rows x n2 columns on a chip of `num_cus` CUs
+extern "C" int misift_test_match_plan(int num_cus, int n1, int n2, int *nchunks, int *tiles_per_chunk, int *ntiles)
+{
+  if (!nchunks || !tiles_per_chunk || !ntiles || n1 < 0 || n2 < 0) return MISIFT_EINVAL;
+  const int ncols = MT_TILE * (n2 / MT_TILE);
+  *ntiles = (ncols + MT_SUPER - 1) / MT_SUPER;
+  plan_chunks_cus(num_cus, (n1 + MT_ROWS_PER_BLOCK - 1) / MT_ROWS_PER_BLOCK, *ntiles, *nchunks, *tiles_per_chunk);
+  return MISIFT_OK;
 }
 
 // The sweep in up to two launches: first the super-tiles [own_t0, own_t1) read through `pts2_own` (a pointer such that

@@ -395,6 +395,9 @@ int misift_test_elementary(misift_ctx *ctx, int fn, const float *d_x, const floa
 int misift_test_match_split(misift_ctx *ctx, void *d_pts1, int n1, const void *d_pts2, int n2, int own_tile_begin,
                             int own_tile_end);
 
+/* Test-only, host-only (no device needed): the matcher's column-chunk plan for n1 x n2 on a chip of num_cus CUs. */
+int misift_test_match_plan(int num_cus, int n1, int n2, int *nchunks, int *tiles_per_chunk, int *ntiles);
+
 /* ------------------------------------------------------------------- timing */
 
 /* TimerGPU (cudautils.h:61-81): event pair on the context stream. */

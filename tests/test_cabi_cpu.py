@@ -149,3 +149,29 @@ def test_header_is_plain_c99(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
                         "-fsyntax-only", str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_matcher_chunk_plan_properties():
+    """misift_test_match_plan (host-only): the column-chunk plan of the matcher covers every super-tile exactly once, has
+    no empty chunk, survives degenerate shapes (n2 < 32: no column takes part; the division by zero of an earlier
+    attempt), and for big problems stays within 5 % of the ideal number of CU rounds x tiles."""
+    import ctypes as C
+    from cudasift_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(5)
+    shapes = [(100000, 100000), (12500, 100000), (25000, 100000), (16384, 16384), (2000, 2000), (1, 33), (5, 20), (0, 100),
+              (333, 64), (70, 31), (1, 1), (128, 64), (129, 65)]
+    shapes += [(int(rng.integers(1, 200000)), int(rng.integers(1, 200000))) for _ in range(200)]
+    for n1, n2 in shapes:
+        for cus in (256, 64, 304):
+            a, b, c = C.c_int(), C.c_int(), C.c_int()
+            assert L.misift_test_match_plan(cus, n1, n2, C.byref(a), C.byref(b), C.byref(c)) == 0
+            nch, tpc, nt = a.value, b.value, c.value
+            assert nt == (32 * (n2 // 32) + 63) // 64
+            assert nch >= 1 and tpc >= 1
+            if nt > 0:
+                assert nch * tpc >= nt and (nch - 1) * tpc < nt, (n1, n2, nch, tpc, nt)
+                nrb = (n1 + 127) // 128
+                if nrb * nt >= 40 * cus and nrb > 0:          # enough work for the quantisation to be a detail
+                    rounds = -(-nrb * nch // cus)
+                    assert rounds * tpc <= 1.05 * nrb * nt / cus + tpc, (n1, n2, cus, nch, tpc)
