@@ -49,17 +49,22 @@ def main():
              ("righ.pgm thresh 3.0", R, 5, 3.0)]
     cases += [("synthetic 1920x1080 frame %d" % f, synth_frame(f), 5, 3.0) for f in range(4)]
     cases += [("synthetic 4096x3072", synth_frame(77, 4096, 3072), 5, 3.0), ("synthetic 1000x750", synth_frame(78, 1000, 750), 5, 3.0)]
-    large = os.environ.get("REFEMUL_SET") == "large"          # the long run: -> profiles/r03_refemul_report_large.json
+    large = os.environ.get("REFEMUL_SET") in ("large", "xlarge")    # the long runs: -> profiles/r03_refemul_report_large.json
+    xlarge = os.environ.get("REFEMUL_SET") == "xlarge"              #                   profiles/r03_refemul_report_xlarge.json
     if large:
         cases += [("synthetic 1920x1080 frame %d" % f, synth_frame(f), 5, 3.0) for f in range(4, 24)]
         cases += [("left.pgm mirrored to 1920x1080, thresh 3.0", np.pad(z["left"], ((60, 60), (320, 320)), mode="reflect").astype(np.float32), 5, 3.0),
                   ("righ.pgm mirrored to 1920x1080, thresh 2.0", np.pad(z["right"], ((60, 60), (320, 320)), mode="reflect").astype(np.float32), 5, 2.0),
                   ("left.pgm thresh 1.0", L, 5, 1.0), ("synthetic 2560x1440", synth_frame(79, 2560, 1440), 6, 2.5),
                   ("synthetic 641x479 (odd)", synth_frame(80, 641, 479), 4, 2.0)]
+    if xlarge:                                                # 232 more 1080p frames: 256 in all (half a bench job)
+        cases += [("synthetic 1920x1080 frame %d" % f, None, 5, 3.0) for f in range(24, 256)]
     out = {"what": "oracle (nvcc-contraction mode / plain mode) vs the reference's own kernels on the CPU SIMT emulator "
                    "(-ffp-contract=fast build), and plain oracle vs the -ffp-contract=off build", "images": []}
     pooled = {}
     for name, img, noct, th in cases:
+        if img is None:                                       # generated on demand (8 MB each)
+            img = synth_frame(int(name.split()[-1]))
         t0 = time.time()
         rp, rn, rc = ref.extract(img, noct, 1.0, th, flavour="fast")
         t_ref = time.time() - t0
@@ -87,7 +92,8 @@ def main():
                     p[kk] = p.get(kk, 0) + v
         print(name, on, rn, e["oracle_nvcc_vs_fast"]["counters_equal"], "%.1fs" % t_ref, flush=True)
     out["pooled"] = pooled
-    path = os.path.join(ROOT, "profiles", "r03_refemul_report_large.json" if large else "r03_refemul_report.json")
+    path = os.path.join(ROOT, "profiles", "r03_refemul_report_xlarge.json" if xlarge else
+                        "r03_refemul_report_large.json" if large else "r03_refemul_report.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(pooled, indent=1))
 

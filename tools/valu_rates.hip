@@ -51,6 +51,16 @@ KERNEL(k_mul_lo_u32, F8, ASM8("v_mul_lo_u32 %0, %0, %1"), OUT8)
 KERNEL(k_mad_u32_u24, F8, ASM8("v_mad_u32_u24 %0, %0, %1, %2"), OUT8)
 KERNEL(k_add_u32, F8, ASM8("v_add_u32 %0, %0, %1"), OUT8)
 KERNEL(k_lshl_add_u32, F8, ASM8("v_lshl_add_u32 %0, %0, 2, %1"), OUT8)
+// 64-bit integer multiply-add (what hipcc emits for an int index into a generic pointer: r03 found 38 in descr_all)
+#define U8 unsigned long long a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; unsigned k = (unsigned)out[0] + 3u, c = (unsigned)out[1] + 5u
+#define OUTU8 if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345678ull) out[2] = (float)a0
+#define ASMU8(ins) \
+  asm volatile(ins : "+v"(a0) : "v"(k), "v"(c) : "vcc"); asm volatile(ins : "+v"(a1) : "v"(k), "v"(c) : "vcc"); \
+  asm volatile(ins : "+v"(a2) : "v"(k), "v"(c) : "vcc"); asm volatile(ins : "+v"(a3) : "v"(k), "v"(c) : "vcc"); \
+  asm volatile(ins : "+v"(a4) : "v"(k), "v"(c) : "vcc"); asm volatile(ins : "+v"(a5) : "v"(k), "v"(c) : "vcc"); \
+  asm volatile(ins : "+v"(a6) : "v"(k), "v"(c) : "vcc"); asm volatile(ins : "+v"(a7) : "v"(k), "v"(c) : "vcc");
+KERNEL(k_mad_u64_u32, U8, ASMU8("v_mad_u64_u32 %0, vcc, %1, %2, %0"), OUTU8)
+KERNEL(k_lshl_add_u64, U8, ASMU8("v_lshl_add_u64 %0, %0, 2, %0"), OUTU8)
 KERNEL(k_max3, F8, ASM8("v_max3_f32 %0, %0, %1, %2"), OUT8)
 KERNEL(k_med3_i32, F8, ASM8("v_med3_i32 %0, %0, %1, %2"), OUT8)
 KERNEL(k_cndmask, F8, ASM8("v_cndmask_b32 %0, %0, %1, vcc"), OUT8)
@@ -124,7 +134,7 @@ int main()
 #define E(n, c) {#n, n, c}
     E(k_fma, 8), E(k_fmac, 8), E(k_mul, 8), E(k_add, 8), E(k_pk_fma, 8), E(k_pk_add, 8), E(k_pk_mul, 8), E(k_floor, 8), E(k_cvt_i32, 8),
     E(k_rcp, 8), E(k_sqrt, 8), E(k_sin, 8), E(k_exp, 8), E(k_mul_lo_u32, 8), E(k_mad_u32_u24, 8), E(k_add_u32, 8),
-    E(k_lshl_add_u32, 8), E(k_max3, 8), E(k_med3_i32, 8), E(k_cndmask, 8), E(k_cmp_cnd, 16), E(k_mov_dpp_shr, 8),
+    E(k_lshl_add_u32, 8), E(k_mad_u64_u32, 8), E(k_lshl_add_u64, 8), E(k_max3, 8), E(k_med3_i32, 8), E(k_cndmask, 8), E(k_cmp_cnd, 16), E(k_mov_dpp_shr, 8),
     E(k_mov_dpp_rowshr, 8), E(k_add_dpp_shr, 8), E(k_readlane, 16), E(k_ds_read_b32, 8), E(k_ds_read2_b32_rand, 4), E(k_fma_dep, 8),
   };
   hipEvent_t t0, t1;
