@@ -175,8 +175,8 @@ def compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, name, strict, recor
         assert st["xpos"] <= 1.5e-7 and st["ypos"] <= 1.5e-7 and st["edgeness"] == 0.0, (name, st)
     if strict:
         # flip_budget: on thousands of keypoints a histogram bin / a pair of nearly equal peaks can fall the other way
-        # under the 1-ulp difference between libm and the written-out atan2/exp (9 of 129 289 records in
-        # profiles/r03_refemul_report_large.json); the small cases of the suite allow none
+        # under the 1-ulp difference between libm and the written-out atan2/exp (28 of 613 248 records in
+        # profiles/r03_refemul_report_xlarge.json); the small cases of the suite allow none
         assert st["orientation_flips"] <= flip_budget, (name, st)
         if flip_budget == 0:
             assert st["orientation_deg"] <= 0.036, (name, st)
