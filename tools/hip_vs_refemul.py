@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""The HIP path against the reference's OWN code, no oracle in between, at scale: N synthetic 1920x1080 frames (+ the stereo
+pair) extracted by libmisift.so on the GPU and by the emulated reference (oracle/_ref/libcudasift_refemul_fast.so: the
+reference's kernels and host code on the CPU SIMT emulator, prebuilt — it travels to the GPU box) -> pooled statistics,
+gpurun_out/r03_hip_vs_refemul.json.  Test infrastructure, like tests/test_gpu_golden.py, which asserts the same on five
+committed golden cases."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from cudasift_amd import capi                      # noqa: E402
+from oracle import pyrefemul as ref                # noqa: E402
+from synth import synth_frame                      # noqa: E402
+from refemul_report import stats                   # noqa: E402
+
+N = int(os.environ.get("HVR_FRAMES", "32"))
+z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_pair_u8.npz"))
+cases = [("left.pgm thresh 3.0", z["left"].astype(np.float32), 5, 3.0), ("righ.pgm thresh 3.0", z["right"].astype(np.float32), 5, 3.0)]
+cases += [("synthetic 1920x1080 frame %d" % f, None, 5, 3.0) for f in range(N)]
+ctx = capi.Context(0)
+ctx.set_options(quiet=1)
+out = {"what": "libmisift.so (MI355X) vs the reference's own kernels and host code on the CPU SIMT emulator (-ffp-contract=fast "
+               "build), no oracle in between", "images": []}
+pooled = {}
+t_hip = t_ref = 0.0
+for name, img, noct, th in cases:
+    if img is None:
+        img = synth_frame(int(name.split()[-1]))
+    t0 = time.time()
+    hp, hn, hc = ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=th)
+    t1 = time.time()
+    rp, rn, rc = ref.extract(img, noct, 1.0, th, flavour="fast")
+    t2 = time.time()
+    t_hip += t1 - t0; t_ref += t2 - t1
+    st = stats(hp, hc, rp, rc, noct)
+    out["images"].append({"image": name, "numPts_hip": hn, "numPts_reference": rn, **{k: st[k] for k in (
+        "records", "counters_equal", "only_oracle", "only_reference", "orientation_flips", "desc_over_0.0001", "desc_over_0.001")}})
+    for kk, v in st.items():
+        if isinstance(v, bool):
+            pooled[kk] = pooled.get(kk, True) and v
+        elif kk.endswith("_max") or kk == "desc_max":
+            pooled[kk] = max(pooled.get(kk, 0.0), v)
+        elif kk == "desc_min_cos":
+            pooled[kk] = min(pooled.get(kk, 1.0), v)
+        else:
+            pooled[kk] = pooled.get(kk, 0) + v
+    print(name, hn, rn, st["counters_equal"], flush=True)
+pooled["only_hip"] = pooled.pop("only_oracle")          # stats() names its first argument "oracle"
+out["pooled_hip_vs_reference"] = pooled
+out["seconds"] = {"hip_single_frame_calls_incl_upload": round(t_hip, 2), "emulated_reference": round(t_ref, 2)}
+path = os.path.join(ROOT, "gpurun_out", "r03_hip_vs_refemul.json")
+os.makedirs(os.path.dirname(path), exist_ok=True)
+json.dump(out, open(path, "w"), indent=1)
+print(json.dumps(pooled, indent=1))
