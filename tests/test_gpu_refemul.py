@@ -45,3 +45,31 @@ def test_hip_matcher_equals_emulated_reference(ctx):
     got = ctx.match(a[:na].copy(), na, b[:nb].copy(), nb)
     for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
         assert np.array_equal(got[f], want[f]), f
+
+
+def test_match_cu_self_check_at_its_own_size(ctx):
+    """The reference's only self-checking program, match.cu:916-1081, on the MI355X: its own generator (match.cu:945-957,
+    unseeded glibc rand() = seed 1), 16 384 x 16 384 x 128, its CPU routine MatchC3 (AVX2 + OpenMP, match.cu:102-130) as
+    the judge and CheckMatches' criterion (match.cu:132-141): the number of rows whose argmax differs must be 0.  The
+    reference's routines come prebuilt from oracle/_ref/libmatchref_16384.so (compiled from /root/reference/match.cu)."""
+    from oracle import pyoracle as orc
+    from synth import descriptors_to_points
+    L = orc.ref_lib(16384)
+    if L is None:
+        pytest.skip("oracle/_ref/libmatchref_16384.so not built (needs /root/reference at build time)")
+    n = 16384
+    a, b = orc.aligned_f32(n * 128), orc.aligned_f32(n * 128)
+    L.ref_generate(a.ctypes.data, b.ctypes.data, 1)
+    s3, i3 = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    L.ref_match_c3(a.ctypes.data, b.ctypes.data, s3.ctypes.data, i3.ctypes.data)
+    p1 = descriptors_to_points(a.reshape(n, 128), orc.POINT_DTYPE)
+    p2 = descriptors_to_points(b.reshape(n, 128), orc.POINT_DTYPE)
+    got = ctx.match(p1, n, p2, n)
+    wrong = int((got["match"] != i3).sum())
+    record("match_cu_self_check_16384", incorrect_matches=wrong, score_maxabs_vs_avx2=float(np.abs(got["score"] - s3).max()))
+    assert wrong == 0                                              # "Number of incorrect matches: 0"
+    assert np.abs(got["score"] - s3).max() < 1e-4                  # AVX2 sums 8 partial chains: not the sequential bits
+    # ... and the sequential-chain bits on a sample of rows (the oracle's scalar definition = the reference's MatchC1)
+    rows = np.arange(0, n, 257)
+    so, io = orc.match_argmax(a.reshape(n, 128)[rows], b.reshape(n, 128))
+    assert np.array_equal(got["score"][rows], so) and np.array_equal(got["match"][rows], io)
