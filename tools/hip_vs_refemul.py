@@ -55,7 +55,24 @@ for name, img, noct, th in cases:
 pooled["only_hip"] = pooled.pop("only_oracle")          # stats() names its first argument "oracle"
 out["pooled_hip_vs_reference"] = pooled
 out["seconds"] = {"hip_single_frame_calls_incl_upload": round(t_hip, 2), "emulated_reference": round(t_ref, 2)}
-path = os.path.join(ROOT, "gpurun_out", "r03_hip_vs_refemul.json")
+path = os.path.join(ROOT, "gpurun_out", "r03_hip_vs_refemul.json" if N else "r03_hip_vs_refemul_match.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(pooled, indent=1))
+
+# ---- matcher: the reference's MatchSiftData (CleanMatches + FindMaxCorr10 on the emulator) vs misift_match, bit for bit
+if os.environ.get("HVR_MATCH_N"):
+    from synth import descriptors_to_points, synth_descriptors
+    n1 = int(os.environ["HVR_MATCH_N"]); n2 = n1 + 37                      # n2 % 32 != 0: the reference drops the last 5 columns
+    a = descriptors_to_points(synth_descriptors(n1, 71, l2=True), capi.POINT_DTYPE)
+    b = descriptors_to_points(synth_descriptors(n2, 72, l2=True), capi.POINT_DTYPE)
+    t0 = time.time()
+    want = a.copy()
+    ref.match(want, n1, b.copy(), n2, "fast")
+    t1 = time.time()
+    got = ctx.match(a.copy(), n1, b.copy(), n2)
+    m = {"n1": n1, "n2": n2, "emulated_reference_s": round(t1 - t0, 1),
+         **{f + "_identical": bool(np.array_equal(got[f], want[f])) for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos")}}
+    print("matcher", m)
+    out["matcher_hip_vs_reference"] = m
+    json.dump(out, open(path, "w"), indent=1)
