@@ -76,3 +76,22 @@ if os.environ.get("HVR_MATCH_N"):
     print("matcher", m)
     out["matcher_hip_vs_reference"] = m
     json.dump(out, open(path, "w"), indent=1)
+
+# ---- FindHomography: ComputeHomographies + TestHomographies on the emulator vs homography.hip, same libc rand() state
+if os.environ.get("HVR_HOMOG_N"):
+    from oracle import pyoracle as orc
+    from synth import synth_matches
+    res = []
+    for n, loops, seed in ((int(os.environ["HVR_HOMOG_N"]), 10000, 1), (5000, 4000, 7), (900, 1000, 3)):
+        m, _, _ = synth_matches(n, seed=11 + seed, dtype=capi.POINT_DTYPE)
+        t0 = time.time()
+        Hr, nr = ref.find_homography(m.copy(), n, loops, 0.85, 0.95, 5.0, seed=seed, flavour="fast")
+        t1 = time.time()
+        d = ctx.upload(m)
+        orc.srand(seed)                                        # the libc state both sides draw their samples from
+        Hh, nh = ctx.find_homography(d.ptr, n, num_loops=loops, min_score=0.85, max_ambiguity=0.95, thresh=5.0)
+        res.append({"points": n, "loops": loops, "seed": seed, "emulated_reference_s": round(t1 - t0, 1), "inliers_reference": int(nr),
+                    "inliers_hip": int(nh), "H_identical": bool(np.array_equal(Hr, Hh))})
+        print("homography", res[-1])
+    out["find_homography_hip_vs_reference"] = res
+    json.dump(out, open(path, "w"), indent=1)
