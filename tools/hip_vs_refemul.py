@@ -24,19 +24,31 @@ N = int(os.environ.get("HVR_FRAMES", "32"))
 z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_pair_u8.npz"))
 cases = [("left.pgm thresh 3.0", z["left"].astype(np.float32), 5, 3.0), ("righ.pgm thresh 3.0", z["right"].astype(np.float32), 5, 3.0)]
 cases += [("synthetic 1920x1080 frame %d" % f, None, 5, 3.0) for f in range(N)]
+cases = [c + (1.0, 0.0, False) for c in cases]                 # (name, image, octaves, thresh, initBlur, lowestScale, scaleUp)
+if os.environ.get("HVR_VARIANTS"):                             # the rest of ExtractSift's argument surface
+    cases = [("scaleUp 960x540 frame %d" % f, synth_frame(300 + f, 960, 540), 5, 3.0, 1.0, 0.0, True) for f in range(8)]
+    cases += [("initBlur 0.5, 1280x960", synth_frame(310, 1280, 960), 5, 2.0, 0.5, 0.0, False),
+              ("initBlur 2.0, 1280x960", synth_frame(311, 1280, 960), 5, 1.0, 2.0, 0.0, False),
+              ("initBlur 0 (delta), 1280x960", synth_frame(312, 1280, 960), 5, 3.0, 0.0, 0.0, False),
+              ("lowestScale 2.0, 1920x1080", synth_frame(313), 5, 2.0, 1.0, 2.0, False),
+              ("6 octaves, 2560x1440", synth_frame(79, 2560, 1440), 6, 2.5, 1.0, 0.0, False),
+              ("1 octave, 1920x1080", synth_frame(314), 1, 3.0, 1.0, 0.0, False),
+              ("4096x3072", synth_frame(77, 4096, 3072), 5, 3.0, 1.0, 0.0, False),
+              ("1917x1079 (ragged)", synth_frame(315, 1917, 1079), 5, 3.0, 1.0, 0.0, False),
+              ("scaleUp + lowestScale 1.5, left.pgm crop", z["left"][200:440, 300:620].astype(np.float32), 4, 3.0, 1.0, 1.5, True)]
 ctx = capi.Context(0)
 ctx.set_options(quiet=1)
 out = {"what": "libmisift.so (MI355X) vs the reference's own kernels and host code on the CPU SIMT emulator (-ffp-contract=fast "
                "build), no oracle in between", "images": []}
 pooled = {}
 t_hip = t_ref = 0.0
-for name, img, noct, th in cases:
+for name, img, noct, th, blur, lowest, up in cases:
     if img is None:
         img = synth_frame(int(name.split()[-1]))
     t0 = time.time()
-    hp, hn, hc = ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=th)
+    hp, hn, hc = ctx.extract(img, num_octaves=noct, init_blur=blur, thresh=th, lowest_scale=lowest, scale_up=up)
     t1 = time.time()
-    rp, rn, rc = ref.extract(img, noct, 1.0, th, flavour="fast")
+    rp, rn, rc = ref.extract(img, noct, blur, th, lowest_scale=lowest, scale_up=up, flavour="fast")
     t2 = time.time()
     t_hip += t1 - t0; t_ref += t2 - t1
     st = stats(hp, hc, rp, rc, noct)
@@ -55,7 +67,8 @@ for name, img, noct, th in cases:
 pooled["only_hip"] = pooled.pop("only_oracle")          # stats() names its first argument "oracle"
 out["pooled_hip_vs_reference"] = pooled
 out["seconds"] = {"hip_single_frame_calls_incl_upload": round(t_hip, 2), "emulated_reference": round(t_ref, 2)}
-path = os.path.join(ROOT, "gpurun_out", "r03_hip_vs_refemul.json" if N else "r03_hip_vs_refemul_match.json")
+path = os.path.join(ROOT, "gpurun_out", "r03_hip_vs_refemul_variants.json" if os.environ.get("HVR_VARIANTS") else
+                    "r03_hip_vs_refemul.json" if N else "r03_hip_vs_refemul_match.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(pooled, indent=1))
