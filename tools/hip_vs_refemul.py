@@ -52,8 +52,8 @@ for name, img, noct, th, blur, lowest, up in cases:
     t2 = time.time()
     t_hip += t1 - t0; t_ref += t2 - t1
     st = stats(hp, hc, rp, rc, noct)
-    out["images"].append({"image": name, "numPts_hip": hn, "numPts_reference": rn, **{k: st[k] for k in (
-        "records", "counters_equal", "only_oracle", "only_reference", "orientation_flips", "desc_over_0.0001", "desc_over_0.001")}})
+    out["images"].append({"image": name, "numPts_hip": hn, "numPts_reference": rn, "only_hip": st["only_oracle"], **{k: st[k] for k in (
+        "records", "counters_equal", "only_reference", "orientation_flips", "desc_over_0.0001", "desc_over_0.001")}})
     for kk, v in st.items():
         if isinstance(v, bool):
             pooled[kk] = pooled.get(kk, True) and v
