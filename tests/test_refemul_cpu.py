@@ -221,6 +221,27 @@ def test_extract_parameter_sweep_pinned(stereo, noct, blur, th, ls):
 
 
 @needs_ref
+def test_capacity_overflow_against_reference(stereo):
+    """maxPts too small (a documented deviation): the reference clamps every overflowing detection to
+    slot maxPts-1 (cudaSiftD.cu:1421 — whichever thread writes last stays; order-dependent on a GPU) and drops overflowing
+    duplicates (:1044); we drop both.  numPts is min(count, maxPts) on both sides, the records that fit are mostly the
+    same keypoints, and with maxPts == the number of points everything is identical again."""
+    img = stereo[0]
+    for mp, common in ((500, 0.9), (100, 0.7)):
+        r_pts, r_n, _ = ref.extract(img, 5, 1.0, 4.5, max_pts=mp, flavour="fast")
+        with orc.contract(1):
+            o_pts, o_n, _ = orc.extract(img, 5, 1.0, 4.5, max_pts=mp)
+        assert r_n == mp and o_n == mp
+        from util import associate
+        ia, _, _, _ = associate(o_pts[:mp], r_pts[:mp])
+        assert len(ia) >= common * mp, (mp, len(ia))
+    r_pts, r_n, r_cnt = ref.extract(img, 5, 1.0, 4.5, max_pts=1453, flavour="fast")
+    with orc.contract(1):
+        o_pts, o_n, o_cnt = orc.extract(img, 5, 1.0, 4.5, max_pts=1453)
+    assert r_n == o_n == 1453 and np.array_equal(r_cnt, o_cnt)
+
+
+@needs_ref
 def test_matcher_pinned_to_reference_kernel(stereo):
     """MatchSiftData = CleanMatches + FindMaxCorr10 (matching.cu:289-397) on the emulator: score, ambiguity (the lossy
     8-class runner-up merge), match, match_xpos/ypos are the oracle's bits, incl. the n2 % 32 truncation."""
