@@ -273,6 +273,22 @@ def test_find_homography_pinned_to_reference_kernels():
 
 
 @needs_ref
+@pytest.mark.parametrize("n", [0, 5, 7, 8, 9, 40])
+def test_find_homography_few_points_pinned(n):
+    """matching.cu:1016-1017: fewer than 8 valid points -> identity and 0 matches; from 8 on the hypotheses draw repeated
+    points.  The oracle follows the emulated reference bit for bit through the boundary."""
+    m, _, _ = synth_matches(max(n, 1), seed=3, dtype=orc.POINT_DTYPE)
+    m = m[:n]
+    m["score"], m["ambiguity"] = 0.99, 0.1
+    Hr, nr = ref.find_homography(m.copy(), n, 100, 0.85, 0.95, 5.0, seed=1, flavour="fast")
+    orc.srand(1)
+    Ho, no, _ = orc.find_homography(m.copy(), n, 100, 0.85, 0.95, 5.0)
+    assert nr == no and np.array_equal(Hr, Ho)
+    if n < 8:
+        assert no == 0 and np.array_equal(Ho, np.eye(3, dtype=np.float32))
+
+
+@needs_ref
 def test_reference_demo_program_runs_on_the_emulator(tmp_path, stereo):
     """mainSift.cpp + geomFuncs.cpp + the emulated library: the reference's whole program without a GPU.  Its feature
     counts are the oracle's; its match counts are what the golden file recorded."""
