@@ -130,7 +130,10 @@ size_t misift_scratch_floats(int width, int height, int num_octaves, int scale_u
  * d_scratch: misift_scratch_floats() floats, or NULL to allocate per call.
  * d_pts: max_pts records.  *num_pts_out follows the reference's rule
  * numPts = min(counter[2*num_octaves], max_pts) (cudaSiftH.cu:115-116).
- * One host<->device sync (the count read-back), like the reference. */
+ * One host<->device sync (the count read-back), like the reference.
+ * Input limit (ours, not the reference's): width, height >= 16 and the coarsest pyramid level >= 8 px in both directions
+ * (width >> (num_octaves - 1) >= 8, after the doubling of scale_up), else MISIFT_EINVAL.  The reference accepts such
+ * images and finds next to nothing in them (tests/test_gpu_refemul.py). */
 int misift_extract(misift_ctx *ctx, const float *d_img, int width, int height, int pitch,
                    int num_octaves, float init_blur, float thresh, float lowest_scale,
                    int scale_up, float *d_scratch, void *d_pts, int max_pts,

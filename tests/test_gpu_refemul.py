@@ -34,6 +34,28 @@ def test_hip_equals_emulated_reference_on_fresh_frames(ctx, seed, w, h, noct, th
                            flip_budget=2)
 
 
+@pytest.mark.parametrize("w,h,noct,th", [(64, 48, 3, 1.0), (40, 30, 2, 0.5), (31, 17, 1, 0.3), (16, 16, 1, 0.1), (33, 65, 3, 0.5),
+                                         (130, 37, 3, 0.8), (257, 19, 2, 0.5), (17, 200, 2, 0.5)])
+def test_hip_equals_emulated_reference_on_small_images(ctx, w, h, noct, th):
+    """White noise down to 16x16 (coarsest pyramid level 8 px): the clamp paths of every kernel."""
+    from util import compare_tiny
+    ref = _ref()
+    img = np.random.default_rng(9 + w).uniform(0, 255, (h, w)).astype(np.float32)
+    r_pts, r_n, r_cnt = ref.extract(img, noct, 1.0, th, flavour="fast")
+    pts, n, cnt = ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=th)
+    compare_tiny(pts, n, cnt, r_pts, r_n, r_cnt, noct)
+
+
+@pytest.mark.parametrize("w,h,noct", [(9, 9, 1), (48, 36, 4), (12, 200, 2)])
+def test_images_below_the_minimum_size_are_refused(ctx, w, h, noct):
+    """A documented input limit (include/misift.h, DESIGN section 2 deviations): images under 16x16, or whose coarsest
+    pyramid level would be under 8 px, are refused with MISIFT_EINVAL — the reference runs them (and finds next to nothing)."""
+    from cudasift_amd.capi import MisiftError
+    img = np.random.default_rng(1).uniform(0, 255, (h, w)).astype(np.float32)
+    with pytest.raises(MisiftError, match="invalid argument"):
+        ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=0.5)
+
+
 def test_hip_matcher_equals_emulated_reference(ctx):
     """MatchSiftData on real descriptors of two fresh frames: the reference's FindMaxCorr10 on the emulator vs match_kernel."""
     ref = _ref()

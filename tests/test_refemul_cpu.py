@@ -222,6 +222,20 @@ def test_extract_parameter_sweep_pinned(stereo, noct, blur, th, ls):
 
 
 @needs_ref
+@pytest.mark.parametrize("w,h,noct,th", [(64, 48, 3, 1.0), (48, 36, 4, 0.5), (40, 30, 2, 0.5), (31, 17, 1, 0.3), (16, 16, 1, 0.1),
+                                         (9, 9, 1, 0.1), (33, 65, 3, 0.5), (257, 19, 4, 0.5), (12, 200, 2, 0.5)])
+def test_extract_tiny_images_pinned(w, h, noct, th):
+    """White-noise images down to 9x9 (pyramid levels down to 6x4): every clamp path of the reference's kernels at once.
+    numPts and detection counters identical, duplicate counters within one keypoint, positions to 3e-7."""
+    from util import compare_tiny
+    img = np.random.default_rng(9 + w).uniform(0, 255, (h, w)).astype(np.float32)
+    r_pts, r_n, r_cnt = ref.extract(img, noct, 1.0, th, flavour="fast")
+    with orc.contract(1):
+        o_pts, o_n, o_cnt = orc.extract(img, noct, 1.0, th)
+    compare_tiny(o_pts, o_n, o_cnt, r_pts, r_n, r_cnt, noct)
+
+
+@needs_ref
 def test_capacity_overflow_against_reference(stereo):
     """maxPts too small (a documented deviation): the reference clamps every overflowing detection to
     slot maxPts-1 (cudaSiftD.cu:1421 — whichever thread writes last stays; order-dependent on a GPU) and drops overflowing
