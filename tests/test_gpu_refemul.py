@@ -69,6 +69,25 @@ def test_hip_matcher_equals_emulated_reference(ctx):
         assert np.array_equal(got[f], want[f]), f
 
 
+def test_hip_matcher_with_nan_inf_zero_and_negative_descriptors(ctx):
+    """NaN rows / columns (the reference's own descriptors can be NaN, Appendix B #7), inf, all-zero and all-negative
+    descriptors through the MFMA sweep and the v_med3 top-2 update: the emulated FindMaxCorr10's answers, bit for bit."""
+    from cudasift_amd.capi import POINT_DTYPE as DT
+    from synth import descriptors_to_points, synth_descriptors
+    ref = _ref()
+    n1, n2 = 300, 416
+    a = descriptors_to_points(synth_descriptors(n1, 5, l2=True), DT)
+    b = descriptors_to_points(synth_descriptors(n2, 6, l2=True), DT)
+    a["data"][7] = np.nan; a["data"][8, 5] = np.nan; b["data"][100] = np.nan; b["data"][200, 3] = np.inf
+    a["data"][9] = 0; b["data"][300] = 0; a["data"][10] *= -1
+    want = a.copy()
+    ref.match(want, n1, b.copy(), n2, "fast")
+    got = ctx.match(a.copy(), n1, b.copy(), n2)
+    for f in ("score", "ambiguity", "match_xpos", "match_ypos"):
+        assert np.array_equal(got[f], want[f], equal_nan=True), f
+    assert np.array_equal(got["match"], want["match"])
+
+
 def test_match_cu_self_check_at_its_own_size(ctx):
     """The reference's only self-checking program, match.cu:916-1081, on the MI355X: its own generator (match.cu:945-957,
     unseeded glibc rand() = seed 1), 16 384 x 16 384 x 128, its CPU routine MatchC3 (AVX2 + OpenMP, match.cu:102-130) as

@@ -275,6 +275,24 @@ def test_matcher_pinned_to_reference_kernel(stereo):
 
 
 @needs_ref
+def test_matcher_with_nan_inf_zero_and_negative_descriptors():
+    """The reference's own descriptors can be NaN (Appendix B #7): a NaN row matches nothing (score 0, match -1), a NaN or
+    inf column never wins, all-negative rows never win.  Oracle == the emulated FindMaxCorr10, NaNs included."""
+    DT = orc.POINT_DTYPE
+    n1, n2 = 300, 416
+    a = descriptors_to_points(synth_descriptors(n1, 5, l2=True), DT)
+    b = descriptors_to_points(synth_descriptors(n2, 6, l2=True), DT)
+    a["data"][7] = np.nan; a["data"][8, 5] = np.nan; b["data"][100] = np.nan; b["data"][200, 3] = np.inf
+    a["data"][9] = 0; b["data"][300] = 0; a["data"][10] *= -1
+    r = a.copy(); ref.match(r, n1, b.copy(), n2, "fast")
+    o = a.copy(); orc.match(o, n1, b.copy(), n2)
+    for f in ("score", "ambiguity", "match_xpos", "match_ypos"):
+        assert np.array_equal(r[f], o[f], equal_nan=True), f
+    assert np.array_equal(r["match"], o["match"])
+    assert (o["match"][7:11] == -1).all() and (o["score"][7:11] == 0).all()
+
+
+@needs_ref
 def test_find_homography_pinned_to_reference_kernels():
     """FindHomography (matching.cu:1000-1087: host rand() sampling, ComputeHomographies, TestHomographies with
     __fmul_rz) on the emulator vs the oracle: same 8 coefficients, same inlier count."""
