@@ -108,3 +108,27 @@ if os.environ.get("HVR_HOMOG_N"):
         print("homography", res[-1])
     out["find_homography_hip_vs_reference"] = res
     json.dump(out, open(path, "w"), indent=1)
+
+# ---- the BATCH entry point (misift_extract_batch: all frames in one set of launches, the bench's kernels) vs the reference
+if os.environ.get("HVR_BATCH"):
+    import util
+    B = int(os.environ["HVR_BATCH"])
+    frames = np.stack([synth_frame(500 + f) for f in range(B)])
+    pts, counts = ctx.extract_batch(frames, thresh=3.0)
+    res = {"frames": B, "numPts_equal": 0, "records": 0, "only_hip": 0, "only_reference": 0, "field_relerr_max": 0.0,
+           "orientation_flips": 0, "desc_over_1e-4": 0}
+    for f in range(B):
+        rp, rn, rc = ref.extract(frames[f], 5, 1.0, 3.0, flavour="fast")
+        n = int(counts[f])
+        res["numPts_equal"] += int(n == rn)
+        ia, ib, oh, orr = util.associate(pts[f][:n], rp[:rn])
+        A, Rr = pts[f][:n][ia], rp[:rn][ib]
+        res["records"] += n; res["only_hip"] += len(oh); res["only_reference"] += len(orr)
+        res["field_relerr_max"] = max(res["field_relerr_max"], *[float(util.rel_err(A[k], Rr[k]).max()) for k in ("xpos", "ypos", "scale", "sharpness", "edgeness")])
+        od = util.circ_diff_deg(A["orientation"], Rr["orientation"])
+        res["orientation_flips"] += int((od > 0.036).sum())
+        ok = ~np.isnan(Rr["data"]).any(axis=1) & (od <= 0.036)
+        res["desc_over_1e-4"] += int((np.abs(A["data"][ok].astype(np.float64) - Rr["data"][ok]).max(axis=1) > 1e-4).sum())
+    print("batch", res)
+    out["batch_entry_point_hip_vs_reference"] = res
+    json.dump(out, open(path, "w"), indent=1)
