@@ -13,7 +13,7 @@ HIPSRCS  := $(CSRC)/kernels_pyramid.hip $(CSRC)/kernels_dog.hip $(CSRC)/kernels_
             $(CSRC)/multigpu.hip
 HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
-all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so cudasift_amd/libcudasift_managed.so oracle dropin build/pmc_calib build/valu_rates build/scan_rates
+all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so cudasift_amd/libcudasift_managed.so oracle dropin build/pmc_calib build/valu_rates build/scan_rates build/single_call
 
 $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
 	@mkdir -p $(BUILD)
@@ -39,6 +39,11 @@ build/valu_rates: tools/valu_rates.hip
 build/scan_rates: tools/scan_rates.hip
 	@mkdir -p $(BUILD)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o $@ $<
+
+# the reference demo's inner loop on synthetic frames through the drop-in API (tools/single_call.sh: BASELINE configs 2-3)
+build/single_call: tools/single_call.cpp include/cudaSift.h include/cudaImage.h cudasift_amd/libcudasift.so
+	@mkdir -p $(BUILD)
+	$(CXX) -O2 -std=c++17 -Iinclude -o $@ tools/single_call.cpp -Lcudasift_amd -lcudasift -lmisift -Wl,-rpath,'$$ORIGIN/../cudasift_amd'
 
 # the MANAGEDMEM flavour of the drop-in API (cudaSift.h:27-32: SiftData holds ONE managed pointer, m_data)
 cudasift_amd/libcudasift_managed.so: $(CSRC)/shim_cudasift.cpp include/cudaSift.h include/cudaImage.h include/misift.h cudasift_amd/libmisift.so

@@ -24,6 +24,7 @@
 #define CNT_PTOVF  29         // points dropped because maxPts was reached
 #define CNT_DET    32         // CNT_DET + octave : detections of that octave (merged-octave pipeline)
 #define CNT_DUP    40         // CNT_DUP + octave : second-orientation duplicates of that octave
+#define CNT_TICKET 49         // frame 0's block only: workgroups of the last kernel that have finished (host export)
 
 struct alignas(16) SiftPointD {   // device view of the 576-byte record
   float xpos, ypos, scale, sharpness, edgeness, orientation, score, ambiguity;
@@ -48,6 +49,7 @@ struct OctaveInfo {
 struct PyramidInfo {
   int noct, nframes;
   float out_scale;                 // 0.5 when the frames were up-sampled first (RescalePositions, cudaSiftH.cu:130), else 1
+  int fix_numpts;                  // options.fix_numpts: the finest octave's second orientations lie INSIDE numPts (and are rescaled)
   long long frame_stride;          // floats between frames' arenas
   OctaveInfo o[MISIFT_MAX_OCTAVES + 1];
 };
@@ -335,6 +337,15 @@ struct misift_ctx {
   int orient_blocks_per_cu;
   int point_blocks_per_cu;                     // grid sizing of the per-keypoint kernels
   int strip_waves_per_cu, scan_waves_per_cu;   // segment sizing targets of the streaming kernels
+  // small batches / the single-call path (r04): bound by dependent dispatches, so fewer and wider launches
+  int chain_max_frames;         // <= this many frames: coarse ScaleDowns as chained launches (MISIFT_CHAIN_FRAMES)
+  int bin_min_frames;           // >= this many frames: bin_detections runs (MISIFT_BIN_MIN_FRAMES)
+  int small_frames;             // <= this many frames: short scan segments, wide refine / per-keypoint grids (MISIFT_SMALL_FRAMES)
+  int scan_rows_small;          // rows per scan segment for such batches (MISIFT_SCAN_ROWS_SMALL)
+  int cur_binned;               // this call's per-keypoint kernels read d_det_sorted (set by misift_extract_enqueue)
+  int want_export, exported;    // host export of the counters by the last kernel: asked for by misift_extract_sync / done
+  unsigned export_seq;          // sequence number the exporting kernel stores behind the counters
+  int host_spin;                // 1 = poll the exported flag instead of hipStreamSynchronize (MISIFT_HOST_SPIN=0 disables)
   int alloc_gen;                // bumped whenever a context-owned device buffer is reallocated (invalidates captured graphs)
   hipEvent_t ev0, ev1;
   // per-kernel profiling (HIP events on the context stream)
@@ -382,11 +393,14 @@ struct LaunchScope {
 };
 
 // kernel launch wrappers (defined in the .hip files)
+// zero_cnt (both prefilter launchers): the frames' counter blocks to clear, or nullptr
 int launch_lowpass(misift_ctx *ctx, const void *src, int src_u8, const StripGeom &g, float *dst, int dpitch,
-                   long long dst_frame_stride, const float k9[9]);
+                   long long dst_frame_stride, const float k9[9], unsigned *zero_cnt);
 int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const StripGeom &g, float *dst, int dpitch,
                         long long dst_frame_stride, const float k9[9], float *dst2, int dpitch2,
-                        long long dst2_frame_stride, const float k5[5], int *done);
+                        long long dst2_frame_stride, const float k5[5], int *done, unsigned *zero_cnt);
+int launch_scaledown_chain(misift_ctx *ctx, float *scratch, long long frame_stride, int nframes, const int (*dims)[3],
+                           const long long *offs, int nlev, const float k5[5]);
 int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,
                      long long dst_frame_stride, const float k5[5]);
 int launch_scaleup(misift_ctx *ctx, const void *src, int src_u8, int w, int h, int spitch, long long src_frame_stride,

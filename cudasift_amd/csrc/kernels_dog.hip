@@ -459,11 +459,74 @@ struct ScanRowCtx {
   unsigned *cnt, *list;
   unsigned cand_cap;
   int octave;
+  unsigned *wq;                          // this wavefront's candidate queue (LDS, CQ_CAP words)
 };
+// ---- candidate queue (r04).  Every appended candidate used to cost its lane an atomicAdd-with-return on ONE word per
+// (frame, octave): harmless in a 64-frame batch (64 x 5 words, four wavefronts per SIMD to hide the round trip) but the
+// single-call path has ONE frame — a few thousand same-address atomics serialise at the memory side and every
+// appending row stalls its lone wavefront for the round trip (r04 single-call sweep: dog_scan 30 us with candidates,
+// 18 us without).  Now a wavefront parks its codes in LDS and asks for list space once per CQ_CAP candidates, and at the
+// end of its segment once per WORKGROUP (scan_queue_finish).
+#define CQ_CAP 64
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// write the first qn queued codes to list[base ...] (qn <= CQ_CAP = the wavefront's width)
+__device__ __forceinline__ void scan_queue_store(const unsigned *wq, unsigned qn, unsigned base, unsigned *cnt,
+                                                 unsigned *list, unsigned cand_cap)
+{
+  const unsigned lane = threadIdx.x & 63;
+  wave_lds_fence();
+  if (lane < qn) {
+    const unsigned idx = base + lane;
+    if (idx < cand_cap) list[idx] = wq[lane];
+    else atomicAdd(&cnt[CNT_CANDOVF], 1u);
+  }
+  wave_lds_fence();                                      // the queue may be refilled from here on
+}
+__device__ __forceinline__ void scan_queue_flush(const ScanRowCtx &g, unsigned &qn)
+{
+  if (qn == 0) return;
+  unsigned base = 0;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(&g.cnt[CNT_CAND + g.octave], qn);
+  base = __builtin_amdgcn_readfirstlane(base);
+  scan_queue_store(g.wq, qn, base, g.cnt, g.list, g.cand_cap);
+  qn = 0;
+}
+// End of a workgroup's scan: the wavefronts that still hold candidates for the same (frame, octave) counter share ONE
+// atomic.  Every wavefront of the workgroup must call this (qn = 0 and ctr = nullptr when it had no item).
+__device__ __forceinline__ void scan_queue_finish(const unsigned *wq, unsigned qn, unsigned *ctr, unsigned *cnt,
+                                                  unsigned *list, unsigned cand_cap)
+{
+  __shared__ unsigned s_qn[WAVES_PER_BLOCK], s_qbase[WAVES_PER_BLOCK];
+  __shared__ unsigned *s_ctr[WAVES_PER_BLOCK];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_qn[wave] = qn; s_ctr[wave] = ctr; }
+  __syncthreads();
+  if (lane == 0 && qn) {
+    bool leader = true;
+    unsigned sum = 0;
+    for (int w = 0; w < WAVES_PER_BLOCK; w++)
+      if (s_ctr[w] == ctr && s_qn[w]) {
+        if (w < wave) leader = false;
+        sum += s_qn[w];
+      }
+    if (leader) {
+      unsigned run = atomicAdd(ctr, sum);
+      for (int w = 0; w < WAVES_PER_BLOCK; w++)
+        if (s_ctr[w] == ctr && s_qn[w]) { s_qbase[w] = run; run += s_qn[w]; }
+    }
+  }
+  __syncthreads();
+  if (qn) scan_queue_store(wq, qn, s_qbase[wave], cnt, list, cand_cap);
+}
 // One row of the scan from the centre row `c` and the four vertical pair sums p1..p4 of its 9-row window.
 template <typename TAPS>
 __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx &g, const float4 c, const float4 p1,
-                                         const float4 p2, const float4 p3, const float4 p4, const int y)
+                                         const float4 p2, const float4 p3, const float4 p4, const int y, unsigned &qn)
 {
   const bool tester = g.tester;
   const int q = g.q;
@@ -471,6 +534,7 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
   unsigned *const cnt = g.cnt, *const list = g.list;
   const unsigned cand_cap = g.cand_cap;
   const int octave = g.octave;
+  (void)list; (void)cand_cap;
   // Only blurs 1..6 are computed here: they give the five centre DoG planes d[0..4] (= reference planes
   // 1..5), which is all the necessary condition below needs; the outermost planes 0 and 6 (blurs 0 and 7)
   // are evaluated only for the survivors, by refine.  A quarter of the blur work of the dense path is saved.
@@ -564,16 +628,39 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (4 * q + i >= g.width - 1) mask &= ~(31u << (5 * i));
-    if (mask) {
+    if (__builtin_amdgcn_ballot_w64(mask != 0) != 0ull) {       // wave-uniform: some lane holds a candidate
+      // exclusive prefix of the lanes' candidate counts (<= 20 each) from five ballots; the total is scalar
       const unsigned n = __popc(mask);
-      unsigned idx = atomicAdd(&cnt[CNT_CAND + octave], n);
-      while (mask) {
-        const int b = __ffs(mask) - 1;
-        mask &= mask - 1;
-        const unsigned code = (unsigned)(4 * q + b / 5) | ((unsigned)y << 14) | ((unsigned)(b % 5) << 28);
-        if (idx < cand_cap) list[idx] = code;
-        else atomicAdd(&cnt[CNT_CANDOVF], 1u);
-        idx++;
+      unsigned excl = 0, total = 0;
+#pragma unroll
+      for (int b = 0; b < 5; b++) {
+        const unsigned long long bl = __builtin_amdgcn_ballot_w64(((n >> b) & 1u) != 0u);
+        excl += __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, 0u)) << b;
+        total += (unsigned)__builtin_popcountll(bl) << b;
+      }
+      if (total > CQ_CAP) {
+        // more candidates in ONE row of a strip than the queue holds (white noise, tiny thresholds): straight to the list
+        scan_queue_flush(g, qn);
+        if (mask) {
+          unsigned idx = atomicAdd(&cnt[CNT_CAND + octave], n);
+          while (mask) {
+            const int b = __ffs(mask) - 1;
+            mask &= mask - 1;
+            const unsigned code = (unsigned)(4 * q + b / 5) | ((unsigned)y << 14) | ((unsigned)(b % 5) << 28);
+            if (idx < cand_cap) list[idx] = code;
+            else atomicAdd(&cnt[CNT_CANDOVF], 1u);
+            idx++;
+          }
+        }
+      } else {
+        if (qn + total > CQ_CAP) scan_queue_flush(g, qn);
+        unsigned pos = qn + excl;
+        while (mask) {
+          const int b = __ffs(mask) - 1;
+          mask &= mask - 1;
+          g.wq[pos++] = (unsigned)(4 * q + b / 5) | ((unsigned)y << 14) | ((unsigned)(b % 5) << 28);
+        }
+        qn += total;
       }
     }
   }
@@ -582,11 +669,12 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
 template <int FAST, typename TAPS>
 __device__ __forceinline__ void scan_strip(const float *img, int width, int height, int pitch, int q, int lane,
                                            int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
-                                           unsigned *list, unsigned cand_cap, int octave, bool al)
+                                           unsigned *list, unsigned cand_cap, int octave, bool al, unsigned *wq,
+                                           unsigned &qn)
 {
   struct { int width, height, pitch; } g = {width, height, pitch};
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
-  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave};
+  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave, wq};
   const QuadCol qc = make_quadcol(q, g.width);
   auto ld = [&](int y) -> float4 {
     return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
@@ -600,7 +688,7 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
     // re-read the taps from LDS every row instead of pinning 80 VGPRs across the loop
     asm volatile("" ::: "memory");
     const float4 c = r4, p1 = add4p(r3, r5), p2 = add4p(r2, r6), p3 = add4p(r1, r7), p4 = add4p(r0, r8);
-    scan_row(taps_src, rc, c, p1, p2, p3, p4, y);
+    scan_row(taps_src, rc, c, p1, p2, p3, p4, y, qn);
   };
   int y = y0;
 #if SCAN_UNROLL3
@@ -635,11 +723,12 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
 template <int FAST, typename TAPS>      // 0 = generic loads, 1 = fast (width % 4 == 0), 2 = fast with ragged widths
 __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int height, int pitch, int q, int lane,
                                                 int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
-                                                unsigned *list, unsigned cand_cap, int octave, bool al, float4 *mine)
+                                                unsigned *list, unsigned cand_cap, int octave, bool al, float4 *mine,
+                                                unsigned *wq, unsigned &qn)
 {
   struct { int width, height, pitch; } g = {width, height, pitch};
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
-  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave};
+  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave, wq};
   const QuadCol qc = make_quadcol(q, g.width);
   auto ld = [&](int y) -> float4 {
     return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
@@ -653,7 +742,7 @@ __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int
     asm volatile("" ::: "memory");
     const float4 p4 = add4p(mine[o0], mine[o8]), p3 = add4p(mine[o1], mine[o7]), p2 = add4p(mine[o2], mine[o6]),
                  p1 = add4p(mine[o3], mine[o5]), c = mine[o4];
-    scan_row(taps_src, rc, c, p1, p2, p3, p4, y);
+    scan_row(taps_src, rc, c, p1, p2, p3, p4, y, qn);
     asm volatile("" ::: "memory");
     mine[o0] = n;                              // row y+5 (loaded one row ago) takes the slot of row y-4,
     n = ld(y + 6);                             // then ITS registers take the next prefetch: no second set, no copies
@@ -690,25 +779,31 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
                                                             unsigned *__restrict__ cand, unsigned cand_cap, int aligned)
 {
   __shared__ v2f s_taps[NUM_SCAN_PAIRS * 5];
+  __shared__ unsigned s_cq[WAVES_PER_BLOCK][CQ_CAP];
   if (threadIdx.x < NUM_SCAN_PAIRS * 5) s_taps[threadIdx.x] = scan_pair_tap(taps, threadIdx.x);
   __syncthreads();
   const ItemCoord it = decode_item(g);
-  if (!it.valid) return;
-  const int lane = threadIdx.x & 63;
-  // lanes 0,63: blur halo; lanes 1,62: DoG column-neighbour halo; lanes 2..61 test their quads
-  const int q = it.strip * (OUT_LANES - 2) + lane - 2;
-  const int y0 = it.seg * g.seg_rows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned qn = 0;
+  unsigned *cnt = nullptr, *list = nullptr;
+  if (it.valid) {
+    // lanes 0,63: blur halo; lanes 1,62: DoG column-neighbour halo; lanes 2..61 test their quads
+    const int q = it.strip * (OUT_LANES - 2) + lane - 2;
+    const int y0 = it.seg * g.seg_rows;
+    cnt = counters + (size_t)it.frame * CNT_STRIDE;
+    list = cand + (size_t)it.frame * cand_cap;
 #if SCAN_RING
-  __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
-  scan_strip_ring<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
-                        min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh,
-                        counters + (size_t)it.frame * CNT_STRIDE, cand + (size_t)it.frame * cand_cap, cand_cap, octave,
-                        aligned != 0, &s_win[threadIdx.x >> 6][lane]);
+    __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
+    scan_strip_ring<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
+                          min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh, cnt, list, cand_cap, octave,
+                          aligned != 0, &s_win[wave][lane], s_cq[wave], qn);
 #else
-  scan_strip<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
-                   min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh, counters + (size_t)it.frame * CNT_STRIDE,
-                   cand + (size_t)it.frame * cand_cap, cand_cap, octave, aligned != 0);
+    scan_strip<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
+                     min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh, cnt, list, cand_cap, octave, aligned != 0,
+                     s_cq[wave], qn);
 #endif
+  }
+  scan_queue_finish(s_cq[wave], qn, it.valid ? cnt + CNT_CAND + octave : nullptr, cnt, list, cand_cap);
 }
 
 // ---- merged-octave scan: ONE launch walks the strips of every pyramid level of every frame.
@@ -741,35 +836,44 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   long long item = (long long)lb * WAVES_PER_BLOCK + wave;
-  if (item >= G.total_items) return;
-  int lev = 0;
-  for (int k = 1; k < G.nlev; k++)
-    if (item >= G.o[k].item_begin) lev = k;
-  lev = __builtin_amdgcn_readfirstlane(lev);
-  const ScanOct &L = G.o[lev];
-  item -= L.item_begin;
-  const int seg = (int)(item % L.nsegs);
-  const long long r = item / L.nsegs;
-  const int strip = (int)(r % L.nstrips);
-  const int frame = (int)(r / L.nstrips);
-  // this wavefront's private copy of its octave's tap pairs
-  if (lane < NUM_SCAN_PAIRS * 5) s_taps[wave][lane] = scan_pair_tap(taps.t[L.octave], lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int q = strip * (OUT_LANES - 2) + lane - 2;
-  const int y0 = seg * L.seg_rows;
+  const bool valid = item < G.total_items;       // (no early return: scan_queue_finish is a workgroup barrier)
+  __shared__ unsigned s_cq[WAVES_PER_BLOCK][CQ_CAP];
+  unsigned qn = 0;
+  unsigned *cnt = nullptr, *list = nullptr;
+  unsigned cand_cap = 0;
+  int octave = 0;
+  if (valid) {
+    int lev = 0;
+    for (int k = 1; k < G.nlev; k++)
+      if (item >= G.o[k].item_begin) lev = k;
+    lev = __builtin_amdgcn_readfirstlane(lev);
+    const ScanOct &L = G.o[lev];
+    item -= L.item_begin;
+    const int seg = (int)(item % L.nsegs);
+    const long long r = item / L.nsegs;
+    const int strip = (int)(r % L.nstrips);
+    const int frame = (int)(r / L.nstrips);
+    // this wavefront's private copy of its octave's tap pairs
+    if (lane < NUM_SCAN_PAIRS * 5) s_taps[wave][lane] = scan_pair_tap(taps.t[L.octave], lane);
+    wave_lds_fence();
+    const int q = strip * (OUT_LANES - 2) + lane - 2;
+    const int y0 = seg * L.seg_rows;
+    cnt = counters + (size_t)frame * CNT_STRIDE;
+    list = cand + (size_t)frame * G.cand_stride + L.cand_off;
+    cand_cap = L.cand_cap;
+    octave = L.octave;
 #if SCAN_RING
-  __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
-  scan_strip_ring<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
-                        min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, counters + (size_t)frame * CNT_STRIDE,
-                        cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true,
-                        &s_win[wave][lane]);
+    __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
+    scan_strip_ring<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
+                          min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, cnt, list, cand_cap, octave, true,
+                          &s_win[wave][lane], s_cq[wave], qn);
 #else
-  scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
-                   min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, counters + (size_t)frame * CNT_STRIDE,
-                   cand + (size_t)frame * G.cand_stride + L.cand_off, L.cand_cap, L.octave, true);
+    scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
+                     min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, cnt, list, cand_cap, octave, true,
+                     s_cq[wave], qn);
 #endif
+  }
+  scan_queue_finish(s_cq[wave], qn, valid ? cnt + CNT_CAND + octave : nullptr, cnt, list, cand_cap);
 }
 
 // ------------------------------------------------------------------- refine
@@ -1014,8 +1118,11 @@ __global__ __launch_bounds__(256) void refine_all_kernel(const float *__restrict
     ncand[k] = k <= P.noct ? __builtin_amdgcn_readfirstlane(min(cnt[CNT_CAND + k], P.o[k].cand_cap)) : 0u;
     total += ncand[k];
   }
-  const unsigned rounds = (total + ngroups - 1) / ngroups;       // wave-uniform trip count (DPP needs all lanes)
-  for (unsigned it = 0; it < rounds; it++) {
+  __shared__ unsigned s_n[MISIFT_MAX_OCTAVES + 1], s_base[MISIFT_MAX_OCTAVES + 1];
+  if (threadIdx.x <= MISIFT_MAX_OCTAVES) s_n[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned rounds = (total + ngroups - 1) / ngroups;       // workgroup-uniform trip count (DPP needs all lanes, the
+  for (unsigned it = 0; it < rounds; it++) {                     //  slot hand-out below all wavefronts)
     const unsigned fi = it * ngroups + group;
     const bool live = fi < total;
     int o = P.noct;
@@ -1071,10 +1178,25 @@ __global__ __launch_bounds__(256) void refine_all_kernel(const float *__restrict
         dd[p][dy][1] = d[p][dy];
         dd[p][dy][2] = row_dpp<ROW_SHL(1)>(d[p][dy]);
       }
-    if (!(live && c == 5)) continue;
     Refined rr;
-    if (!refine_math(dd, x, y, s, R.thresh, R.edge_limit, R.factor, P.o[o].lowest_scale, R.scmul, rr)) continue;
-    const unsigned idx = atomicAdd(&cnt[CNT_DET + o], 1u);
+    const bool ok = live && c == 5 &&
+                    refine_math(dd, x, y, s, R.thresh, R.edge_limit, R.factor, P.o[o].lowest_scale, R.scmul, rr);
+    // Staging slots are handed out per WORKGROUP and octave: the survivors of a round take a rank from an LDS counter
+    // and one thread per octave asks the frame's counter for that many slots.  (One atomicAdd-with-return per survivor
+    // on the same word serialises at the memory side: ~2000 of them were 17 us of a single frame's 22 us refine, r04.)
+    unsigned rank = 0;
+    if (ok) rank = atomicAdd(&s_n[o], 1u);
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x <= MISIFT_MAX_OCTAVES) {
+      const unsigned n = s_n[threadIdx.x];
+      if (n) {
+        s_base[threadIdx.x] = atomicAdd(&cnt[CNT_DET + threadIdx.x], n);
+        s_n[threadIdx.x] = 0;
+      }
+    }
+    __syncthreads();
+    if (!ok) continue;
+    const unsigned idx = s_base[o] + rank;
     if (idx >= (unsigned)R.max_pts) { atomicAdd(&cnt[CNT_PTOVF], 1u); continue; }
     Detection *pd = &fdet[(size_t)(o - 1) * R.max_pts + idx];
     pd->xpos = rr.xpos;
@@ -1194,8 +1316,14 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
     if (want < 1) want = 1;
     int seg = (int)((L.h + want - 1) / want);
 #if SCAN_RING
-    seg = (seg + RING_ROWS - 1) / RING_ROWS * RING_ROWS;     // whole turns of the nine-row ring
-    if (seg < 2 * RING_ROWS) seg = 2 * RING_ROWS;
+    if (P.nframes <= ctx->small_frames) {
+      // a frame or two: the launch is latency-bound (rows per wavefront x ~1 us), so short segments on every SIMD
+      if (seg < ctx->scan_rows_small) seg = ctx->scan_rows_small;
+      if (seg > RING_ROWS) seg = (seg + RING_ROWS - 1) / RING_ROWS * RING_ROWS;
+    } else {
+      seg = (seg + RING_ROWS - 1) / RING_ROWS * RING_ROWS;     // whole turns of the nine-row ring
+      if (seg < 2 * RING_ROWS) seg = 2 * RING_ROWS;
+    }
     if (seg > 14 * RING_ROWS) seg = 14 * RING_ROWS;
 #else
     seg = (seg + 7) / 8 * 8;
@@ -1236,7 +1364,10 @@ int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
   R.cand_stride = cand_stride;
   const AllTaps at = pack_taps(taps, P.noct);
   LaunchScope ls(ctx, "refine");
-  hipLaunchKernelGGL(refine_all_kernel, dim3(64, P.nframes), dim3(256), 0, ctx->stream, scratch, P, at, R,
+  // 16 candidates per workgroup and round: a batch keeps 64 workgroups per frame busy for many rounds; a single frame
+  // wants its ~10 k candidates done in one (every round is a dependent chain of 11 loads)
+  const int gx = P.nframes <= ctx->small_frames ? 1024 / P.nframes : 64;
+  hipLaunchKernelGGL(refine_all_kernel, dim3(gx, P.nframes), dim3(256), 0, ctx->stream, scratch, P, at, R,
                      ctx->d_counters, ctx->d_cand, ctx->d_det);
   return ls.finish();
 }

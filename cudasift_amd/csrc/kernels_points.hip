@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
         float o0, o1v;
         descr_accumulate(buf, s_w[wave].wtab, lane, vx, vy, ang, o0, o1v);
         descr_write(sift, pack_dst, pack_off, pack_cnt, first ? dstA : dstB, lane, o0, o1v, d, first ? d.ori1 : d.ori2,
-                    subsampling, (!first && o == P.noct) ? 1.0f : P.out_scale);
+                    subsampling, (!first && o == P.noct && !P.fix_numpts) ? 1.0f : P.out_scale);
       }
     }
     wave_sync();                                          // the buffer is free (and all zero or about to be overwritten)
@@ -1317,28 +1317,19 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
   }
 }
 
-// The few keypoints descr_all_kernel deferred (window larger than 40x40 texels): bilinear fetches from global memory.
 template <bool Q8>
-__global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict__ scratch, PyramidInfo P,
-                                                        const unsigned *__restrict__ counters,
-                                                        const Detection *__restrict__ det,
-                                                        SiftPointD *__restrict__ pts, int max_pts,
-                                                        const int *__restrict__ pack_offsets,
-                                                        SiftPointD *__restrict__ pack_dst,
-                                                        const unsigned *__restrict__ big_list, unsigned big_stride)
+__device__ __forceinline__ void descr_big_frame(const float *__restrict__ scratch, const PyramidInfo &P,
+                                                const unsigned *__restrict__ cnt, const Detection *__restrict__ det,
+                                                SiftPointD *__restrict__ pts, int max_pts,
+                                                const int *__restrict__ pack_offsets, SiftPointD *__restrict__ pack_dst,
+                                                const unsigned *__restrict__ big_list, unsigned big_stride, unsigned nbig,
+                                                float *s_smp_w, float *s_gauss_w, int wave, int lane, int frame)
 {
-  __shared__ __attribute__((aligned(16))) float s_smp[WAVES_PER_BLOCK][DESCR_TBL];
-  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int frame = blockIdx.y;
-  const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
-  const unsigned nbig = min(cnt[CNT_BIG], big_stride);
-  if (nbig == 0) return;
   const Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
   SiftPointD *sift = pts ? pts + (size_t)frame * max_pts : nullptr;
   const int pack_off = pack_dst ? pack_offsets[frame] : 0;
   const unsigned pack_cnt = pack_dst ? (unsigned)(pack_offsets[frame + 1] - pack_off) : 0u;
-  descr_init(s_smp[wave], s_gauss[wave], lane);
+  descr_init(s_smp_w, s_gauss_w, lane);
   for (unsigned t = blockIdx.x * WAVES_PER_BLOCK + wave; t < nbig; t += gridDim.x * WAVES_PER_BLOCK) {
     const unsigned code = big_list[(size_t)frame * big_stride + t];
     const int o = (int)(code >> 24), i = (int)(code & 0xffffffu);
@@ -1353,12 +1344,51 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
       const unsigned dst = which == 0 ? bdet + (unsigned)i : bdup + (unsigned)d.dupslot;
       if (dst >= (unsigned)max_pts) continue;
       float o0, o1v;
-      descr_core(img, L.w, L.h, L.p, Q8, d.xpos, d.ypos, d.scale, which == 0 ? d.ori1 : d.ori2, s_smp[wave], s_gauss[wave],
+      descr_core(img, L.w, L.h, L.p, Q8, d.xpos, d.ypos, d.scale, which == 0 ? d.ori1 : d.ori2, s_smp_w, s_gauss_w,
                  lane, o0, o1v);
       descr_write(sift, pack_dst, pack_off, pack_cnt, dst, lane, o0, o1v, d, which == 0 ? d.ori1 : d.ori2, L.subsampling,
-                  (which == 1 && o == P.noct) ? 1.0f : P.out_scale);
+                  (which == 1 && o == P.noct && !P.fix_numpts) ? 1.0f : P.out_scale);
     }
   }
+}
+
+// The few keypoints descr_all_kernel deferred (window larger than 40x40 texels): bilinear fetches from global memory.
+template <bool Q8>
+__global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                        const unsigned *__restrict__ counters,
+                                                        const Detection *__restrict__ det,
+                                                        SiftPointD *__restrict__ pts, int max_pts,
+                                                        const int *__restrict__ pack_offsets,
+                                                        SiftPointD *__restrict__ pack_dst,
+                                                        const unsigned *__restrict__ big_list, unsigned big_stride,
+                                                        unsigned *__restrict__ host_out, unsigned host_seq)
+{
+  __shared__ __attribute__((aligned(16))) float s_smp[WAVES_PER_BLOCK][DESCR_TBL];
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  const unsigned nbig = min(cnt[CNT_BIG], big_stride);
+  if (nbig != 0) descr_big_frame<Q8>(scratch, P, cnt, det, pts, max_pts, pack_offsets, pack_dst, big_list, big_stride, nbig,
+                                     s_smp[wave], s_gauss[wave], wave, lane, frame);
+  // ---- last kernel of an extraction: hand the counter blocks to the host (misift_extract_sync).  The workgroup that
+  // draws the last ticket copies every frame's counters into pinned host memory and then stores the call's sequence
+  // number behind them — the host polls that word instead of queueing a blocking copy behind the kernel (r04
+  // single-call budget: the copy was a blit kernel of its own plus a stream synchronisation).
+  if (!host_out) return;
+  __shared__ unsigned s_last;
+  __threadfence_system();                       // records written above are visible before the ticket is drawn
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = atomicAdd(const_cast<unsigned *>(counters) + CNT_TICKET, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();                              // the other workgroups' counter updates (none today) before the copy
+  const unsigned nwords = gridDim.y * CNT_STRIDE;
+  for (unsigned w = threadIdx.x; w < nwords; w += blockDim.x) host_out[w] = __builtin_nontemporal_load(counters + w);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_out + nwords, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- the r01 forms of the two merged-octave kernels: bilinear fetches straight from global memory (no staged
@@ -1469,7 +1499,7 @@ __global__ __launch_bounds__(256, 4) void descr_all_gather_kernel(const float *_
         p->data[8 * cell + (lane & 3)] = o0;
         p->data[8 * cell + (lane & 3) + 4] = o1;
         if (lane == 0) {
-          const float os = (which == 1 && o == P.noct) ? 1.0f : P.out_scale;   // records past numPts are not rescaled
+          const float os = (which == 1 && o == P.noct && !P.fix_numpts) ? 1.0f : P.out_scale;   // records past numPts are not rescaled
           p->xpos = d.xpos * L.subsampling * os;       // out_scale is 1 or 0.5: exact, = a later RescalePositions
           p->ypos = d.ypos * L.subsampling * os;
           p->scale = d.scale * L.subsampling * os;
@@ -1575,7 +1605,10 @@ static inline int points_grid_x(misift_ctx *ctx, int nframes, int blocks_per_cu 
   // the total near a few waves per SIMD when many frames are batched
   int per_frame = (ctx->num_cus * blocks_per_cu + nframes - 1) / nframes;
   if (per_frame < 8) per_frame = 8;
-  if (per_frame > 512) per_frame = 512;
+  // (batches: 512 workgroups per frame at most; a frame or two: 1024, i.e. one wavefront per keypoint up to 4096 — a
+  //  second keypoint per wavefront doubles the latency of the whole launch)
+  const int cap = nframes <= ctx->small_frames ? 1024 : 512;
+  if (per_frame > cap) per_frame = cap;
   return per_frame;
 }
 
@@ -1624,7 +1657,7 @@ int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
 {
   (void)pts;
   LaunchScope ls(ctx, "orient_all");
-  Detection *det = (ctx->bin_detections || ctx->opt.deterministic) ? ctx->d_det_sorted : ctx->d_det;
+  Detection *det = ctx->cur_binned ? ctx->d_det_sorted : ctx->d_det;
   const dim3 grid(points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu), P.nframes);
   if (ctx->tile_orient) LAUNCH_Q8(orient_all_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
   else LAUNCH_Q8(orient_all_gather_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
@@ -1635,7 +1668,7 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
                      const int *pack_offsets, SiftPointD *pack_dst)
 {
   LaunchScope ls(ctx, "descr_all");
-  const Detection *det = (ctx->bin_detections || ctx->opt.deterministic) ? ctx->d_det_sorted : ctx->d_det;
+  const Detection *det = ctx->cur_binned ? ctx->d_det_sorted : ctx->d_det;
   const dim3 grid(points_grid_x(ctx, P.nframes), P.nframes);
   if (ctx->tile_descr) {
     // keypoints too large for the LDS window go to a per-frame list in the (by now idle) candidate buffer
@@ -1647,8 +1680,15 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
     if (ctx->descr_occ >= 4) { if (q8) DESCR_LAUNCH(true, 4); else DESCR_LAUNCH(false, 4); }
     else { if (q8) DESCR_LAUNCH(true, 3); else DESCR_LAUNCH(false, 3); }
 #undef DESCR_LAUNCH
+    // the last kernel of the call: on request it also hands the counter blocks to the host (see descr_big_kernel)
+    unsigned *host_out = nullptr;
+    if (ctx->want_export && !ctx->in_capture) {
+      host_out = ctx->h_counters;
+      ctx->export_seq++;
+      ctx->exported = 1;
+    }
     LAUNCH_Q8(descr_big_kernel, dim3(2, P.nframes), dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts,
-              pack_offsets, pack_dst, ctx->d_cand, big_stride);
+              pack_offsets, pack_dst, ctx->d_cand, big_stride, host_out, ctx->export_seq);
   } else
     LAUNCH_Q8(descr_all_gather_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts, 0, pack_offsets,
               pack_dst);

@@ -325,6 +325,16 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_POINT_BLOCKS")) ctx->point_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 8;
   if (const char *e = getenv("MISIFT_STRIP_WAVES")) ctx->strip_waves_per_cu = atoi(e) > 0 ? atoi(e) : 16;
   if (const char *e = getenv("MISIFT_SCAN_WAVES")) ctx->scan_waves_per_cu = atoi(e) > 0 ? atoi(e) : 16;
+  ctx->chain_max_frames = 4;
+  if (const char *e = getenv("MISIFT_CHAIN_FRAMES")) ctx->chain_max_frames = atoi(e);
+  ctx->bin_min_frames = 4;
+  if (const char *e = getenv("MISIFT_BIN_MIN_FRAMES")) ctx->bin_min_frames = atoi(e);
+  ctx->small_frames = 4;
+  if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
+  ctx->scan_rows_small = 9;
+  if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL")) ctx->scan_rows_small = atoi(e) > 0 ? atoi(e) : 9;
+  ctx->host_spin = 1;
+  if (const char *e = getenv("MISIFT_HOST_SPIN")) ctx->host_spin = atoi(e) != 0;
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
   int rc = misift_ensure_frames(ctx, 1, 65536);
@@ -552,9 +562,10 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
     ctx->d_counters = nullptr; ctx->h_counters = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes));
     ctx->alloc_gen++;
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, hipHostMallocDefault));
+    // one block more than frames: the word behind the last frame's counters is the host-export flag (descr_big_kernel)
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + 1), hipHostMallocDefault));
     HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, ctx->stream));
-    memset(ctx->h_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes);
+    memset(ctx->h_counters, 0, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + 1));
   }
   if (nframes > ctx->cap_frames || cand_cap > ctx->cand_cap) {
     const int nf = nframes > ctx->cap_frames ? nframes : ctx->cap_frames;
@@ -883,7 +894,8 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     }
     d_scratch = ctx->d_own_scratch;
   }
-  HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, ctx->stream));
+  // (the frames' counter blocks are cleared by the prefilter kernel — the first kernel of every path below)
+  ctx->exported = 0;
 
   float table[8 * 12 * 16];
   misift_laplace_taps(num_octaves, table);          // cudaSiftH.cu:109-111
@@ -927,12 +939,13 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     if (num_octaves >= 2 && ctx->opt.fused) {
       const Level &D = lv[num_octaves - 1];
       StripGeom g = make_geom(ctx, W, H, pre_pitch, pre_frames, pre_stride, W, H, 60);
-      rc = launch_lowpass_down(ctx, pre_src, pre_u8, g, L.img, L.p, SS, k9, D.img, D.p, SS, k5, &first_down_done);
+      rc = launch_lowpass_down(ctx, pre_src, pre_u8, g, L.img, L.p, SS, k9, D.img, D.p, SS, k5, &first_down_done,
+                               ctx->d_counters);
       if (rc) return rc;
     }
     if (!first_down_done) {
       StripGeom g = make_geom(ctx, W, H, pre_pitch, pre_frames, pre_stride, W, H, 62);
-      rc = launch_lowpass(ctx, pre_src, pre_u8, g, L.img, L.p, SS, k9);
+      rc = launch_lowpass(ctx, pre_src, pre_u8, g, L.img, L.p, SS, k9, ctx->d_counters);
       if (rc) return rc;
     }
   }
@@ -942,6 +955,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   std::vector<LaplaceTaps> tapsv(num_octaves + 1);
   if (ctx->opt.fused) {
     P.noct = num_octaves; P.nframes = nframes; P.frame_stride = SS;
+    P.fix_numpts = ctx->opt.fix_numpts ? 1 : 0;
     P.out_scale = scale_up ? 0.5f : 1.0f;             // RescalePositions (cudaSiftH.cu:130) folded into the record write
     unsigned off = 0;
     for (int o = 1; o <= num_octaves; o++) {
@@ -989,12 +1003,29 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     scanned = true;
   }
   // --- pyramid (ScaleDown chain of cudaSiftH.cu:153-160), finest to coarsest
-  for (int o = num_octaves; o >= 2 && !scanned; o--) {
-    if (o == num_octaves && first_down_done) continue;
+  // Small batches (a single frame above all) are bound by the number of DEPENDENT dispatches, not by their work: up to
+  // three levels per launch (scaledown_chain_kernel).  Batches keep one streamed launch per level.
+  const bool chained = !scanned && nframes <= ctx->chain_max_frames;
+  for (int o = num_octaves; o >= 2 && !scanned;) {
+    if (o == num_octaves && first_down_done) { o--; continue; }
+    if (chained) {
+      const int nlev = (o - 1) < 3 ? (o - 1) : 3;
+      int dims[4][3];
+      long long offs[4];
+      for (int k = 0; k <= nlev; k++) {
+        dims[k][0] = lv[o - k].w; dims[k][1] = lv[o - k].h; dims[k][2] = lv[o - k].p;
+        offs[k] = (long long)(lv[o - k].img - d_scratch);
+      }
+      rc = launch_scaledown_chain(ctx, d_scratch, SS, nframes, dims, offs, nlev, k5);
+      if (rc) return rc;
+      o -= nlev;
+      continue;
+    }
     const Level &src = lv[o], &dst = lv[o - 1];
     StripGeom g = make_geom(ctx, src.w, src.h, src.p, nframes, SS, dst.w, dst.h, 62);
     rc = launch_scaledown(ctx, src.img, g, dst.img, dst.p, SS, k5);
     if (rc) return rc;
+    o--;
   }
   if (ctx->opt.fused) {
     // scan / refine / orient / descr each run ONCE over all pyramid levels; the final array is laid out in the
@@ -1005,7 +1036,10 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     }
     rc = launch_refine_all(ctx, d_scratch, P, tapsv.data(), thresh, 10.0f, 1.0f / NUM_SCALES, max_pts);
     if (rc) return rc;
-    const bool binned = ctx->bin_detections || ctx->opt.deterministic;
+    // (a counting sort per (octave, frame) is one workgroup each: for a frame or two it is a dependent dispatch that buys
+    //  nothing — the keypoints of one frame share the caches anyway)
+    const bool binned = (ctx->bin_detections && nframes >= ctx->bin_min_frames) || ctx->opt.deterministic;
+    ctx->cur_binned = binned ? 1 : 0;
     if (binned) {                       // spatial order for the per-keypoint kernels (L1/L2 reuse between neighbours);
       rc = launch_bin_detections(ctx, P, max_pts);      // deterministic mode: a total order
       if (rc) return rc;
@@ -1053,9 +1087,36 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
 static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *num_pts_out,
                        bool *cand_overflow)
 {
-  HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes,
-                         hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->exported) {
+    // the last kernel of the call has written the counter blocks into h_counters and stores export_seq behind them
+    // when it is done: poll that word (a few hundred ns after the store) instead of a blocking copy + synchronise
+    volatile unsigned *flag = ctx->h_counters + (size_t)nframes * CNT_STRIDE;
+    bool seen = false;
+    if (ctx->host_spin) {
+      for (unsigned spins = 0; !seen; spins++) {
+        seen = *flag == ctx->export_seq;
+        if (!seen && (spins & 0x3fff) == 0x3fff) {           // every ~16 k polls: is the stream still alive?
+          const hipError_t q = hipStreamQuery(ctx->stream);
+          if (q == hipSuccess) { seen = *flag == ctx->export_seq; break; }
+          if (q != hipErrorNotReady) HIP_TRY(q);
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      // keep the runtime's bookkeeping of finished commands bounded
+      if ((ctx->export_seq & 63u) == 0) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (!seen) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (*flag != ctx->export_seq) {
+        misift_set_error("counter export did not arrive (flag %u, expected %u)", *flag, ctx->export_seq);
+        return MISIFT_EHIP;
+      }
+    }
+  } else {
+    HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes,
+                           hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
   const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
   for (int f = 0; f < nframes; f++) {
     const unsigned c = ctx->h_counters[(size_t)f * CNT_STRIDE + slot];
@@ -1150,9 +1211,14 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
       key.frame_stride = frame_stride; key.init_blur = init_blur; key.thresh = thresh; key.lowest_scale = lowest_scale;
       queued = enqueue_via_graph(ctx, key, d_imgs, frame_stride, d_scratch, pts);
     }
-    if (!queued)
+    if (!queued) {
+      ctx->want_export = 1;              // the last kernel hands the counters to the host (paths that cannot leave it 0)
       rc = misift_extract_enqueue(ctx, d_imgs, src_u8, nframes, frame_stride, width, height, pitch, num_octaves,
                                   init_blur, thresh, lowest_scale, scale_up, d_scratch, pts, max_pts);
+      ctx->want_export = 0;
+    } else {
+      ctx->exported = 0;                 // a replayed graph carries no fresh sequence number
+    }
     bool ovf = false;
     if (!rc) rc = read_counts(ctx, nframes, num_octaves, max_pts, num_pts_out, &ovf);
     if (rc) { ctx->opt.fused = fused_saved; return rc; }
@@ -1343,7 +1409,7 @@ extern "C" int misift_lowpass(misift_ctx *ctx, const float *d_src, int width, in
   float k9[9];
   lowpass_taps(sigma, k9);
   StripGeom g = make_geom(ctx, width, height, spitch, 1, 0, width, height, 62);
-  int rc = launch_lowpass(ctx, d_src, 0, g, d_dst, dpitch, 0, k9);
+  int rc = launch_lowpass(ctx, d_src, 0, g, d_dst, dpitch, 0, k9, nullptr);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return resolve_profile(ctx);
@@ -1359,7 +1425,7 @@ extern "C" int misift_lowpass_scaledown(misift_ctx *ctx, const float *d_src, int
   scaledown_taps(0.5f, k5);
   StripGeom g = make_geom(ctx, width, height, spitch, 1, 0, width, height, 60);
   int done = 0;
-  int rc = launch_lowpass_down(ctx, d_src, 0, g, d_dst, dpitch, 0, k9, d_dst2, dpitch2, 0, k5, &done);
+  int rc = launch_lowpass_down(ctx, d_src, 0, g, d_dst, dpitch, 0, k9, d_dst2, dpitch2, 0, k5, &done, nullptr);
   if (rc) return rc;
   if (!done) {
     misift_set_error("misift_lowpass_scaledown: shape not supported by the fused kernel (width %% 4, alignment)");
