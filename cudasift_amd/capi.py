@@ -61,6 +61,7 @@ SIGNATURES = {
     "misift_extract_batch": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _ip]),
     "misift_extract_batch_async": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp]),
     "misift_get_counters": (_i, [_vp, _i, _up]),
+    "misift_get_counter_block": (_i, [_vp, _i, _up]),
     "misift_set_counters": (_i, [_vp, _i, _up]),
     "misift_lowpass": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f]),
     "misift_scaledown": (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
@@ -265,6 +266,12 @@ class Context:
     def get_counters(self, frame=0):
         c = (C.c_uint * 17)()
         check(lib().misift_get_counters(self.h, frame, c), "misift_get_counters")
+        return np.array(list(c), np.uint32)
+
+    def get_counter_block(self, frame=0):
+        """All 64 words of a frame's counter block (diagnostic: candidate / detection / duplicate counts per octave)."""
+        c = (C.c_uint * 64)()
+        check(lib().misift_get_counter_block(self.h, frame, c), "misift_get_counter_block")
         return np.array(list(c), np.uint32)
 
     def set_counters(self, counters, frame=0):

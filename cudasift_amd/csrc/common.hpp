@@ -24,6 +24,7 @@
 #define CNT_PTOVF  29         // points dropped because maxPts was reached
 #define CNT_DET    32         // CNT_DET + octave : detections of that octave (merged-octave pipeline)
 #define CNT_DUP    40         // CNT_DUP + octave : second-orientation duplicates of that octave
+#define CNT_SPARE_BLOCKS 9    // counter blocks behind the last frame's: flags and ticket words of the call (dog_scan_all_kernel)
 #define CNT_TICKET 49         // frame 0's block only: workgroups of the last kernel that have finished (host export)
 
 struct alignas(16) SiftPointD {   // device view of the 576-byte record
@@ -339,13 +340,18 @@ struct misift_ctx {
   int strip_waves_per_cu, scan_waves_per_cu;   // segment sizing targets of the streaming kernels
   // small batches / the single-call path (r04): bound by dependent dispatches, so fewer and wider launches
   int chain_max_frames;         // <= this many frames: coarse ScaleDowns as chained launches (MISIFT_CHAIN_FRAMES)
+  int chain_embed;              // 1 = that chain runs inside the scan launch when one chain covers all levels (MISIFT_CHAIN_EMBED)
   int bin_min_frames;           // >= this many frames: bin_detections runs (MISIFT_BIN_MIN_FRAMES)
   int small_frames;             // <= this many frames: short scan segments, wide refine / per-keypoint grids (MISIFT_SMALL_FRAMES)
+  int strip_rows_small;         // rows per prefilter / ScaleDown segment for such batches, even (MISIFT_STRIP_ROWS_SMALL)
   int scan_rows_small;          // rows per scan segment for such batches (MISIFT_SCAN_ROWS_SMALL)
   int cur_binned;               // this call's per-keypoint kernels read d_det_sorted (set by misift_extract_enqueue)
   int want_export, exported;    // host export of the counters by the last kernel: asked for by misift_extract_sync / done
   unsigned export_seq;          // sequence number the exporting kernel stores behind the counters
   int host_spin;                // 1 = poll the exported flag instead of hipStreamSynchronize (MISIFT_HOST_SPIN=0 disables)
+  unsigned *d_flags, *h_flags;  // 64 words each: device ticket words / pinned host flags of synchronous calls (matcher)
+  int want_match_flag, match_flagged;
+  unsigned match_seq;
   int alloc_gen;                // bumped whenever a context-owned device buffer is reallocated (invalidates captured graphs)
   hipEvent_t ev0, ev1;
   // per-kernel profiling (HIP events on the context stream)
@@ -431,8 +437,12 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
 int launch_export_counts_staged(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *counts_out,
                                 int *offsets_out);
 struct ScanAll;
+struct ChainGeom;
+// chain (optional): the ScaleDown chain that produces the coarse levels runs in the first workgroups of the same launch
 int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
-                        float thresh, int lev_begin, int lev_end);
+                        float thresh, int lev_begin, int lev_end, const ChainGeom *chain = nullptr,
+                        const float *k5 = nullptr);
+int make_chain_geom(ChainGeom *G, long long frame_stride, const int (*dims)[3], const long long *offs, int nlev, int tile);
 int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
                       float thresh, float edge_limit, float factor, int max_pts);
 int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2);

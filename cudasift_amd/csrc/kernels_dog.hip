@@ -23,6 +23,7 @@
 #include <string.h>
 #include <math.h>
 #include "common.hpp"
+#include "chain.hpp"
 
 #define WAVES_PER_BLOCK 4
 #define OUT_LANES 62
@@ -815,6 +816,7 @@ struct ScanOct {
 };
 struct ScanAllGeom {
   int nlev, nframes;
+  int wait_lev;                               // CHAIN: levels (index into o[]) from here on wait for the embedded chain
   long long frame_stride, total_items;
   unsigned cand_stride;                       // candidate words per frame (all octaves)
   ScanOct o[MISIFT_MAX_OCTAVES];              // o[0] = finest level: the long items are dispatched first
@@ -823,18 +825,95 @@ struct ScanAllGeom {
 #ifndef SCAN_OCC
 #define SCAN_OCC (SCAN_RING ? 4 : 3)
 #endif
-template <int FAST>
+// CHAIN (small batches, r04): the first `nchain` workgroups of the launch are the ScaleDown chain that PRODUCES the
+// coarse pyramid levels; the scan items of the two finest levels do not depend on it, those of the coarse levels
+// (G.wait_lev on) wait for its completion count.  Workgroups are dispatched in index order and the whole grid is
+// resident, so the chain is always running before anything waits for it; by the time the coarse items (the last of
+// the grid) start, it has long finished — one dependent dispatch and the chain's own duration leave the critical path.
+#ifndef SCAN_STAMPS
+#define SCAN_STAMPS 0            // developer build (tools/variants.sh -DSCAN_STAMPS=1): 100 MHz time stamps of the embedded chain
+#endif
+#if SCAN_STAMPS
+#define STAMP_MAX(slot) do { if ((threadIdx.x & 63) == 0) atomicMax(&counters[(size_t)G.nframes * CNT_STRIDE + (slot)], (unsigned)wall_clock64()); } while (0)
+#else
+#define STAMP_MAX(slot) do { } while (0)
+#endif
+template <int FAST, bool CHAIN>
 __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float *__restrict__ scratch, ScanAllGeom G,
                                                               AllTaps taps, float thresh,
                                                               unsigned *__restrict__ counters,
-                                                              unsigned *__restrict__ cand)
+                                                              unsigned *__restrict__ cand, ChainGeom C, Taps5 k5,
+                                                              int nchain)
 {
   __shared__ v2f s_taps[WAVES_PER_BLOCK][NUM_SCAN_PAIRS * 5];
+#if SCAN_RING
+  __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
+  static_assert(sizeof(float4) * WAVES_PER_BLOCK * RING_FLOAT4S >= sizeof(float) * CHAIN_LDS_FLOATS_EMBED,
+                "the chain borrows the scan's row ring");
+#else
+  static_assert(!CHAIN, "the embedded chain borrows the LDS ring of SCAN_RING");
+#endif
   // no XCD remap here: items of different levels cost differently, and the hardware's round-robin
   // block -> XCD placement is what keeps the eight XCDs evenly loaded across the level boundaries
-  const unsigned lb = blockIdx.x;
+  unsigned lb = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
+#if SCAN_RING
+  if (CHAIN) {
+#if SCAN_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[(size_t)G.nframes * CNT_STRIDE + 8] = (unsigned)wall_clock64();
+    if (threadIdx.x == 0) STAMP_MAX(14);        // start of the last workgroup to start
+    if (threadIdx.x == 0 && lb + 1 == gridDim.x) STAMP_MAX(16);     // start of the workgroup with the highest index
+    if (threadIdx.x == 0 && lb == (unsigned)nchain) STAMP_MAX(17);  // start of the first scan workgroup
+#endif
+    if (lb < (unsigned)nchain) {                  // workgroup-uniform
+      const int tiles = C.tiles_x * C.tiles_y;
+      scaledown_chain_block(const_cast<float *>(scratch), C, k5, (int)(lb % tiles), (int)(lb / tiles),
+                            reinterpret_cast<float *>(&s_win[0][0]));
+      // the chain's stores are write-through (chain.hpp): once they have been acknowledged they are in memory, where
+      // every XCD finds them — no L2 write-back (an agent-scope release fence per workgroup: +45 us per frame, r04)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      STAMP_MAX(9);
+      // Completion count in two levels: 16 ticket words in cache lines of their own, then one more for the workgroups
+      // that drew the last ticket of theirs; the very last raises the flag the coarse items poll.  Same-address atomics
+      // are served one at a time (10-50 ns each): 510 tickets on ONE word held the flag back by 14 us, and polling the
+      // ticket word itself starves the tickets (r04, SCAN_STAMPS).  All of it lives in the spare counter blocks behind
+      // the last frame's (cleared by the prefilter).
+      if (threadIdx.x == 0) {
+        unsigned *spare = counters + (size_t)G.nframes * CNT_STRIDE;
+        const unsigned sub = lb & 15u, members = ((unsigned)nchain - sub + 15u) / 16u;
+        if (atomicAdd(&spare[64 + 32 * sub], 1u) == members - 1u) {
+          const unsigned nsub = (unsigned)nchain < 16u ? (unsigned)nchain : 16u;
+          if (atomicAdd(&spare[32], 1u) == nsub - 1u) {
+            __hip_atomic_fetch_or(&spare[0], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            STAMP_MAX(18);
+          }
+        }
+      }
+      STAMP_MAX(19);
+      return;
+    }
+    lb -= (unsigned)nchain;
+    // a workgroup that holds an item of a coarse level waits for the flag: ONE lane polls, the others sit at the barrier
+    if (G.wait_lev < G.nlev && (long long)lb * WAVES_PER_BLOCK + (WAVES_PER_BLOCK - 1) >= G.o[G.wait_lev].item_begin) {
+      STAMP_MAX(15);
+      if (threadIdx.x == 0)
+        // (a read-modify-write: it is performed at the memory side.  An agent-scope atomic LOAD may be served from this
+        //  XCD's L2, which is not coherent with the other XCDs' — the first poll caches the line and the loop then spins on
+        //  the stale copy until it happens to be evicted: 40 us, measured with SCAN_STAMPS)
+        //  — and an add of ZERO is folded into such a load by the compiler: every poll adds one, the flag is the top bit)
+        while ((__hip_atomic_fetch_add(&counters[(size_t)G.nframes * CNT_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                0x80000000u) == 0u)
+          __builtin_amdgcn_s_sleep(8);
+      __syncthreads();
+      STAMP_MAX(13);
+      // nothing of the coarse levels can be in this XCD's L2 yet (caches are invalidated at kernel start and only
+      // wavefronts behind this wait read those levels): a compiler-level acquire is all that is needed
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+#endif
   long long item = (long long)lb * WAVES_PER_BLOCK + wave;
   const bool valid = item < G.total_items;       // (no early return: scan_queue_finish is a workgroup barrier)
   __shared__ unsigned s_cq[WAVES_PER_BLOCK][CQ_CAP];
@@ -842,11 +921,14 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   unsigned *cnt = nullptr, *list = nullptr;
   unsigned cand_cap = 0;
   int octave = 0;
+  bool stamp_coarse = false;
+  (void)stamp_coarse;
   if (valid) {
     int lev = 0;
     for (int k = 1; k < G.nlev; k++)
       if (item >= G.o[k].item_begin) lev = k;
     lev = __builtin_amdgcn_readfirstlane(lev);
+    stamp_coarse = lev >= G.wait_lev;
     const ScanOct &L = G.o[lev];
     item -= L.item_begin;
     const int seg = (int)(item % L.nsegs);
@@ -863,7 +945,6 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
     cand_cap = L.cand_cap;
     octave = L.octave;
 #if SCAN_RING
-    __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
     scan_strip_ring<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
                           min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, cnt, list, cand_cap, octave, true,
                           &s_win[wave][lane], s_cq[wave], qn);
@@ -873,6 +954,9 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
                      s_cq[wave], qn);
 #endif
   }
+#if SCAN_STAMPS
+  if (CHAIN && valid) { if (stamp_coarse) STAMP_MAX(12); else STAMP_MAX(11); }
+#endif
   scan_queue_finish(s_cq[wave], qn, valid ? cnt + CNT_CAND + octave : nullptr, cnt, list, cand_cap);
 }
 
@@ -1291,7 +1375,7 @@ static AllTaps pack_taps(const LaplaceTaps *taps, int noct)
 
 // lev_begin..lev_end: pyramid levels to scan, 0 = finest (all levels: 0, P.noct)
 int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
-                        float thresh, int lev_begin, int lev_end)
+                        float thresh, int lev_begin, int lev_end, const ChainGeom *chain, const float *k5)
 {
   ScanAllGeom G;
   memset(&G, 0, sizeof(G));
@@ -1339,17 +1423,34 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
   }
   G.total_items = items;
   const AllTaps at = pack_taps(taps, P.noct);
-  const dim3 grid((unsigned)((items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+  ChainGeom C;
+  Taps5 t5;
+  memset(&C, 0, sizeof(C));
+  memset(&t5, 0, sizeof(t5));
+  int nchain = 0;
+  if (chain) {
+    // the chain's outputs are the levels below its source: scan items of those levels wait for it
+    C = *chain;
+    for (int j = 0; j < 5; j++) t5.k[j] = k5[j];
+    nchain = C.tiles_x * C.tiles_y * P.nframes;
+    G.wait_lev = 0;                                        // (source not among the scanned levels: everything waits)
+    for (int k = 0; k < G.nlev; k++)
+      if (G.o[k].img_off == C.lv[0].off) G.wait_lev = k + 1;
+  }
+  const dim3 grid((unsigned)((items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK) + (unsigned)nchain);
   LaunchScope ls(ctx, "dog_scan");
-  if (fast && !ragged)
-    hipLaunchKernelGGL(dog_scan_all_kernel<1>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
-                       ctx->d_counters, ctx->d_cand);
-  else if (fast)          // pyramid levels are ours (pitch % 128 == 0): ragged widths keep the dwordx4 row loads (r03)
-    hipLaunchKernelGGL(dog_scan_all_kernel<2>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
-                       ctx->d_counters, ctx->d_cand);
-  else
-    hipLaunchKernelGGL(dog_scan_all_kernel<0>, grid, dim3(256), 0, ctx->stream, scratch, G, at, thresh,
-                       ctx->d_counters, ctx->d_cand);
+#define SCAN_LAUNCH(F, CH) hipLaunchKernelGGL((dog_scan_all_kernel<F, CH>), grid, dim3(256), 0, ctx->stream, scratch, G, at, \
+                                              thresh, ctx->d_counters, ctx->d_cand, C, t5, nchain)
+  if (chain) {
+    if (fast && !ragged) SCAN_LAUNCH(1, true);
+    else if (fast) SCAN_LAUNCH(2, true);
+    else SCAN_LAUNCH(0, true);
+  } else {
+    if (fast && !ragged) SCAN_LAUNCH(1, false);
+    else if (fast) SCAN_LAUNCH(2, false);        // pyramid levels are ours (pitch % 128 == 0): ragged widths keep the dwordx4 row loads (r03)
+    else SCAN_LAUNCH(0, false);
+  }
+#undef SCAN_LAUNCH
   return ls.finish();
 }
 

@@ -16,6 +16,7 @@
 // Columns are split into chunks across workgroups to fill 256 CUs; a small merge kernel
 // combines the per-chunk class triples and writes score/match/ambiguity/match_xpos/ypos.
 #include <stdlib.h>
+#include <string.h>
 #include "common.hpp"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -151,6 +152,9 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
 #endif
 #ifndef MT_EXP_NOGLOAD
 #define MT_EXP_NOGLOAD 0
+#endif
+#if (MT_EXP_NOBARRIER || MT_EXP_NOSTORE || MT_EXP_NOGLOAD) && !defined(MISIFT_TIMING_ONLY_BUILD)
+#error "MT_EXP_* are timing-only experiments that compute WRONG results: build them with -DMISIFT_TIMING_ONLY_BUILD (tools/variants.sh), never into libmisift.so"
 #endif
   if (st0 < st1) {
     gload(st0);
@@ -347,7 +351,9 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
 // then the eight classes are combined in every lane of the group exactly as before and lane 0 writes the row.
 __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict__ pts1,
                                                           const SiftPointD *__restrict__ pts2, MatchGeom G,
-                                                          const float *__restrict__ partial, int exact_top2)
+                                                          const float *__restrict__ partial, int exact_top2,
+                                                          unsigned *__restrict__ ticket, unsigned *__restrict__ host_flag,
+                                                          unsigned host_seq)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int rl = t >> 3;
@@ -374,33 +380,47 @@ __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict
     csec[c] = __shfl(sd, c, 8);
     cidx[c] = __shfl(ixm, c, 8);
   }
-  if (!live || (t & 7) != 0) return;
-  float max_score, sec_score;
-  int index;
-  if (exact_top2) {
-    max_score = cmax[0]; sec_score = csec[0]; index = cidx[0];
-#pragma unroll
-    for (int c = 1; c < 8; c++) top2_merge(max_score, sec_score, index, cmax[c], csec[c], cidx[c]);
-  } else {
-    // the reference's final merge, literally (matching.cu:375-390)
-    max_score = cmax[0]; sec_score = csec[0]; index = cidx[0];
-#pragma unroll
-    for (int y = 0; y < 8; y++)
-      if (index != cidx[y]) {
-        if (cmax[y] > max_score) {
-          sec_score = fmaxf(max_score, sec_score);
-          max_score = cmax[y];
-          index = cidx[y];
-        } else if (cmax[y] > sec_score)
-          sec_score = cmax[y];
-      }
+  if (live && (t & 7) == 0) {
+    float max_score, sec_score;
+    int index;
+    if (exact_top2) {
+      max_score = cmax[0]; sec_score = csec[0]; index = cidx[0];
+  #pragma unroll
+      for (int c = 1; c < 8; c++) top2_merge(max_score, sec_score, index, cmax[c], csec[c], cidx[c]);
+    } else {
+      // the reference's final merge, literally (matching.cu:375-390)
+      max_score = cmax[0]; sec_score = csec[0]; index = cidx[0];
+  #pragma unroll
+      for (int y = 0; y < 8; y++)
+        if (index != cidx[y]) {
+          if (cmax[y] > max_score) {
+            sec_score = fmaxf(max_score, sec_score);
+            max_score = cmax[y];
+            index = cidx[y];
+          } else if (cmax[y] > sec_score)
+            sec_score = cmax[y];
+        }
+    }
+    SiftPointD *o = &pts1[G.row_begin + rl];
+    o->score = max_score;
+    o->match = index;
+    o->match_xpos = index >= 0 ? pts2[index].xpos : 0.0f;   // never reads sift2[-1] (Appendix B #9)
+    o->match_ypos = index >= 0 ? pts2[index].ypos : 0.0f;
+    o->ambiguity = sec_score / (max_score + 1e-6f);
   }
-  SiftPointD *o = &pts1[G.row_begin + rl];
-  o->score = max_score;
-  o->match = index;
-  o->match_xpos = index >= 0 ? pts2[index].xpos : 0.0f;   // never reads sift2[-1] (Appendix B #9)
-  o->match_ypos = index >= 0 ? pts2[index].ypos : 0.0f;
-  o->ambiguity = sec_score / (max_score + 1e-6f);
+  // Synchronous callers (misift_match): the workgroup that draws the last ticket stores the call's sequence number in
+  // pinned host memory, which the host polls instead of synchronising the stream (r04 single-call budget: ~5 us of the
+  // 39 us a 2000 x 2000 MatchSiftData took).  The ticket word is left at zero for the next call.
+  if (!host_flag) return;
+  __shared__ unsigned s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // Column chunks for a launch of `ntiles` super-tiles over nrb row blocks.  Measured (r03, tools/match_chunks.py,
@@ -463,6 +483,7 @@ int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row
 {
   if (row_count <= 0 || n2 <= 0) return MISIFT_OK;
   MatchGeom G;
+  memset(&G, 0, sizeof(G));                    // (phases that skip a launch still pass G by value to the merge)
   G.row_begin = row_begin; G.row_count = row_count; G.n1_total = row_begin + row_count;
   G.n2 = n2;
   G.ncols = ctx->opt.match_full ? n2 : MT_TILE * (n2 / MT_TILE);
@@ -501,8 +522,14 @@ int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row
   }
   {
     LaunchScope ls(ctx, "match_merge");
+    unsigned *host_flag = nullptr;
+    if (ctx->want_match_flag && ctx->h_flags && ctx->d_flags) {
+      host_flag = ctx->h_flags;
+      ctx->match_seq++;
+      ctx->match_flagged = 1;
+    }
     hipLaunchKernelGGL(match_merge_kernel, dim3((row_count * 8 + 255) / 256), dim3(256), 0, ctx->stream, pts1, pts2,
-                       G, partial, ctx->opt.match_exact_top2);
+                       G, partial, ctx->opt.match_exact_top2, ctx->d_flags, host_flag, ctx->match_seq);
     return ls.finish();
   }
 }

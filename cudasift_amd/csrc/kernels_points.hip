@@ -1141,23 +1141,20 @@ __device__ __forceinline__ void descr_write(SiftPointD *sift, SiftPointD *pack_d
 #ifndef DESCR_UNROLL_SAMPLES
 #define DESCR_UNROLL_SAMPLES 1
 #endif
-template <bool Q8, int OCC>
-__global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
-                                                        unsigned *__restrict__ counters,
-                                                        const Detection *__restrict__ det,
-                                                        SiftPointD *__restrict__ pts, int max_pts, int frac8,
-                                                        const int *__restrict__ pack_offsets,
-                                                        SiftPointD *__restrict__ pack_dst,
-                                                        unsigned *__restrict__ big_list, unsigned big_stride)
+// one LDS record per wavefront, so that every access is one lane-offset register plus an immediate offset
+struct alignas(16) DescrWaveLds {
+  float buf[PATCH_FLOATS];      // window, then vote table
+  float park[12 * 64];          // votes of a first orientation while the second is sampled
+  float gauss[16];
+  float wtab[64];               // footprint weights wy(row) * wx(column)
+};
+template <bool Q8>
+__device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch, const PyramidInfo &P,
+                                               unsigned *__restrict__ counters, const Detection *__restrict__ det,
+                                               SiftPointD *__restrict__ pts, int max_pts,
+                                               const int *__restrict__ pack_offsets, SiftPointD *__restrict__ pack_dst,
+                                               unsigned *__restrict__ big_list, unsigned big_stride, DescrWaveLds *s_w)
 {
-  // one LDS record per wavefront, so that every access is one lane-offset register plus an immediate offset
-  struct alignas(16) WaveLds {
-    float buf[PATCH_FLOATS];      // window, then vote table
-    float park[12 * 64];          // votes of a first orientation while the second is sampled
-    float gauss[16];
-    float wtab[64];               // footprint weights wy(row) * wx(column)
-  };
-  __shared__ WaveLds s_w[WAVES_PER_BLOCK];
   static_assert(PATCH_FLOATS == 4 * SMP_PLANE, "the window and the four vote planes share one buffer");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.y;
@@ -1174,13 +1171,13 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
   footprint_weights_init(s_w[wave].wtab, lane);
   // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
   if (blockIdx.x == 0 && threadIdx.x == 0) {             // publish the reference's counters (cudaSiftD.cu:14)
-    unsigned b = 0;
+    unsigned b = 0;                                      // (write-through: a workgroup on another XCD may export them)
     for (int k = 1; k <= P.noct; k++) {
-      cnt[2 * k - 1] = b;
+      __hip_atomic_store(&cnt[2 * k - 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       b += cnt[CNT_DET + k];
-      cnt[2 * k] = b;
+      __hip_atomic_store(&cnt[2 * k], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       b += cnt[CNT_DUP + k];
-      cnt[2 * k + 1] = b;
+      __hip_atomic_store(&cnt[2 * k + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   const int stride = gridDim.x * WAVES_PER_BLOCK;
@@ -1258,7 +1255,8 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
     if (!g.fits) {
       if (lane == 0 && (doA || doB)) {                    // too large for the window: descr_big_kernel takes it
         const unsigned slot = atomicAdd(&cnt[CNT_BIG], 1u);
-        if (slot < big_stride) big_list[(size_t)frame * big_stride + slot] = ((unsigned)o << 24) | (unsigned)i;
+        if (slot < big_stride)
+          big_list[(size_t)frame * big_stride + slot] = ((unsigned)o << 24) | (unsigned)i;
       }
     } else if (doA || doB) {
       // one set of vote registers: when a keypoint has both orientations, the first one's votes wait in LDS (s_park)
@@ -1323,14 +1321,15 @@ __device__ __forceinline__ void descr_big_frame(const float *__restrict__ scratc
                                                 SiftPointD *__restrict__ pts, int max_pts,
                                                 const int *__restrict__ pack_offsets, SiftPointD *__restrict__ pack_dst,
                                                 const unsigned *__restrict__ big_list, unsigned big_stride, unsigned nbig,
-                                                float *s_smp_w, float *s_gauss_w, int wave, int lane, int frame)
+                                                float *s_smp_w, float *s_gauss_w, int lane, int frame, unsigned first,
+                                                unsigned step)
 {
   const Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
   SiftPointD *sift = pts ? pts + (size_t)frame * max_pts : nullptr;
   const int pack_off = pack_dst ? pack_offsets[frame] : 0;
   const unsigned pack_cnt = pack_dst ? (unsigned)(pack_offsets[frame + 1] - pack_off) : 0u;
   descr_init(s_smp_w, s_gauss_w, lane);
-  for (unsigned t = blockIdx.x * WAVES_PER_BLOCK + wave; t < nbig; t += gridDim.x * WAVES_PER_BLOCK) {
+  for (unsigned t = first; t < nbig; t += step) {
     const unsigned code = big_list[(size_t)frame * big_stride + t];
     const int o = (int)(code >> 24), i = (int)(code & 0xffffffu);
     const OctaveInfo &L = P.o[o];
@@ -1352,7 +1351,51 @@ __device__ __forceinline__ void descr_big_frame(const float *__restrict__ scratc
   }
 }
 
+// Hand the counter blocks of all frames to the host (misift_extract_sync): called by ONE workgroup once every other
+// workgroup of the call's last kernel has finished.  The counters go into pinned host memory, the call's sequence
+// number behind them — the host polls that word instead of queueing a blocking copy behind the kernel (r04 single-call
+// budget: the copy was a blit kernel of its own plus a stream synchronisation).
+__device__ __forceinline__ void export_counters_host(const unsigned *counters, unsigned nframes, unsigned *host_out,
+                                                     unsigned host_seq)
+{
+  const unsigned nwords = nframes * CNT_STRIDE;
+  // (agent-scope atomic loads: the counters were written by other workgroups — atomics, or the write-through stores of
+  //  publish_counters — and must not be served from this XCD's L2)
+  for (unsigned w = threadIdx.x; w < nwords; w += blockDim.x)
+    host_out[w] = __hip_atomic_load(counters + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_out + nwords, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// true in exactly one workgroup of the launch: the one that draws the last ticket.  NO device-scope fence per workgroup:
+// on this multi-XCD part a release at agent scope writes the whole L2 back, and a thousand workgroups doing that cost a
+// single frame 80 us (r04, profiles/r04_single_call_sweep_step3.txt).  What the last workgroup reads from the others
+// must therefore have been written with agent-scope atomics (write-through).
+__device__ __forceinline__ bool last_workgroup(unsigned *counters)
+{
+  __shared__ unsigned s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this workgroup's stores have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(counters + CNT_TICKET, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+  __syncthreads();
+  return s_last != 0;
+}
+
+template <bool Q8, int OCC>
+__global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                        unsigned *__restrict__ counters,
+                                                        const Detection *__restrict__ det,
+                                                        SiftPointD *__restrict__ pts, int max_pts, int frac8,
+                                                        const int *__restrict__ pack_offsets,
+                                                        SiftPointD *__restrict__ pack_dst,
+                                                        unsigned *__restrict__ big_list, unsigned big_stride)
+{
+  __shared__ DescrWaveLds s_w[WAVES_PER_BLOCK];
+  descr_all_body<Q8>(scratch, P, counters, det, pts, max_pts, pack_offsets, pack_dst, big_list, big_stride, s_w);
+}
+
 // The few keypoints descr_all_kernel deferred (window larger than 40x40 texels): bilinear fetches from global memory.
+// Last kernel of a batch's extraction: on request the workgroup that finishes last also exports the counters.
 template <bool Q8>
 __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                         const unsigned *__restrict__ counters,
@@ -1369,26 +1412,13 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
   const int frame = blockIdx.y;
   const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   const unsigned nbig = min(cnt[CNT_BIG], big_stride);
-  if (nbig != 0) descr_big_frame<Q8>(scratch, P, cnt, det, pts, max_pts, pack_offsets, pack_dst, big_list, big_stride, nbig,
-                                     s_smp[wave], s_gauss[wave], wave, lane, frame);
-  // ---- last kernel of an extraction: hand the counter blocks to the host (misift_extract_sync).  The workgroup that
-  // draws the last ticket copies every frame's counters into pinned host memory and then stores the call's sequence
-  // number behind them — the host polls that word instead of queueing a blocking copy behind the kernel (r04
-  // single-call budget: the copy was a blit kernel of its own plus a stream synchronisation).
+  if (nbig != 0)
+    descr_big_frame<Q8>(scratch, P, cnt, det, pts, max_pts, pack_offsets, pack_dst, big_list, big_stride, nbig,
+                        s_smp[wave], s_gauss[wave], lane, frame, blockIdx.x * WAVES_PER_BLOCK + wave,
+                        gridDim.x * WAVES_PER_BLOCK);
   if (!host_out) return;
-  __shared__ unsigned s_last;
-  __threadfence_system();                       // records written above are visible before the ticket is drawn
-  __syncthreads();
-  if (threadIdx.x == 0)
-    s_last = atomicAdd(const_cast<unsigned *>(counters) + CNT_TICKET, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();                              // the other workgroups' counter updates (none today) before the copy
-  const unsigned nwords = gridDim.y * CNT_STRIDE;
-  for (unsigned w = threadIdx.x; w < nwords; w += blockDim.x) host_out[w] = __builtin_nontemporal_load(counters + w);
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(host_out + nwords, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (!last_workgroup(const_cast<unsigned *>(counters))) return;
+  export_counters_host(counters, gridDim.y, host_out, host_seq);
 }
 
 // ---- the r01 forms of the two merged-octave kernels: bilinear fetches straight from global memory (no staged
@@ -1674,19 +1704,21 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
     // keypoints too large for the LDS window go to a per-frame list in the (by now idle) candidate buffer
     unsigned big_stride = 0;
     for (int o = 1; o <= P.noct; o++) big_stride += P.o[o].cand_cap;
-#define DESCR_LAUNCH(Q, O) hipLaunchKernelGGL((descr_all_kernel<Q, O>), grid, dim3(256), 0, ctx->stream, scratch, P, ctx->d_counters, \
-                                              det, pts, max_pts, 0, pack_offsets, pack_dst, ctx->d_cand, big_stride)
-    const bool q8 = ctx->opt.texfrac_bits == 8;
-    if (ctx->descr_occ >= 4) { if (q8) DESCR_LAUNCH(true, 4); else DESCR_LAUNCH(false, 4); }
-    else { if (q8) DESCR_LAUNCH(true, 3); else DESCR_LAUNCH(false, 3); }
-#undef DESCR_LAUNCH
-    // the last kernel of the call: on request it also hands the counter blocks to the host (see descr_big_kernel)
+    // the last kernel of the call: on request it also hands the counter blocks to the host (export_counters_host)
     unsigned *host_out = nullptr;
     if (ctx->want_export && !ctx->in_capture) {
       host_out = ctx->h_counters;
       ctx->export_seq++;
       ctx->exported = 1;
     }
+#define DESCR_LAUNCH(Q, O) hipLaunchKernelGGL((descr_all_kernel<Q, O>), grid, dim3(256), 0, ctx->stream, scratch, P, ctx->d_counters, \
+                                              det, pts, max_pts, 0, pack_offsets, pack_dst, ctx->d_cand, big_stride)
+    const bool q8 = ctx->opt.texfrac_bits == 8;
+    if (ctx->descr_occ >= 4) { if (q8) DESCR_LAUNCH(true, 4); else DESCR_LAUNCH(false, 4); }
+    else { if (q8) DESCR_LAUNCH(true, 3); else DESCR_LAUNCH(false, 3); }
+#undef DESCR_LAUNCH
+    // (r04 tried folding this launch into descr_all's last workgroup by ticket: a thousand same-address tickets and the
+    //  extra registers cost more than the 4 us dispatch — profiles/r04_single_call_sweep_step4.txt)
     LAUNCH_Q8(descr_big_kernel, dim3(2, P.nframes), dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts,
               pack_offsets, pack_dst, ctx->d_cand, big_stride, host_out, ctx->export_seq);
   } else

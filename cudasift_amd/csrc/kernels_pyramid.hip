@@ -19,6 +19,7 @@
 // the CPU SIMT emulator (oracle/_ref/libcudasift_refemul_fast.so, tests/test_refemul_cpu.py).
 #include <string.h>
 #include "common.hpp"
+#include "chain.hpp"
 
 #define WAVES_PER_BLOCK 4
 #define OUT_LANES 62
@@ -53,9 +54,14 @@ __device__ __forceinline__ ItemCoord decode_item(const StripGeom &g)
 // The prefilter is the first kernel of an extraction: the wavefront that owns a frame's first item also clears the
 // frame's counter block (CNT_STRIDE = 64 words, one per lane), which the scan — a later kernel of the same stream — is
 // the first to touch.  Replaces a hipMemsetAsync: one dependent dispatch less per call (r04 single-call budget).
-__device__ __forceinline__ void zero_frame_counters(unsigned *zero_cnt, const ItemCoord &it, int lane)
+// (frame 0's wavefront also clears the spare blocks behind the last frame's: flags of the call, see dog_scan_all_kernel)
+__device__ __forceinline__ void zero_frame_counters(unsigned *zero_cnt, const ItemCoord &it, int lane, int nframes)
 {
-  if (zero_cnt && it.strip == 0 && it.seg == 0) zero_cnt[(size_t)it.frame * CNT_STRIDE + lane] = 0u;
+  if (zero_cnt && it.strip == 0 && it.seg == 0) {
+    zero_cnt[(size_t)it.frame * CNT_STRIDE + lane] = 0u;
+    if (it.frame == 0)
+      for (int b = 0; b < CNT_SPARE_BLOCKS; b++) zero_cnt[(size_t)(nframes + b) * CNT_STRIDE + lane] = 0u;
+  }
 }
 
 __device__ __forceinline__ void store_quad(float *row, int q, int width, bool aligned, float4 v)
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256, 4) void lowpass_kernel(const SRC *__restrict__
   const ItemCoord it = decode_item(g);
   if (!it.valid) return;
   const int lane = threadIdx.x & 63;
-  zero_frame_counters(zero_cnt, it, lane);
+  zero_frame_counters(zero_cnt, it, lane, g.nframes);
   const int q = it.strip * OUT_LANES + lane - 1;
   const SRC *img = src + (long long)it.frame * g.frame_stride;
   float *out = dst + (long long)it.frame * dst_frame_stride;
@@ -155,12 +161,12 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
   const ItemCoord it = decode_item(g);
   if (!it.valid) return;
   const int lane = threadIdx.x & 63;
-  zero_frame_counters(zero_cnt, it, lane);
+  zero_frame_counters(zero_cnt, it, lane, g.nframes);
   const int q = it.strip * FUSED_OUT_LANES + lane - 2;
   const SRC *img = src + (long long)it.frame * g.frame_stride;
   float *out = dst + (long long)it.frame * dst_frame_stride;
   float *out2 = dst2 + (long long)it.frame * dst2_frame_stride;
-  const int y0 = it.seg * g.seg_rows;                      // seg_rows is a multiple of 8
+  const int y0 = it.seg * g.seg_rows;                      // seg_rows is even
   const int y1 = min(y0 + g.seg_rows, g.height);
   const int h2 = g.height / 2;
   const float k0 = t.k[0], k1 = t.k[1], k2 = t.k[2], k3 = t.k[3], k4 = t.k[4];
@@ -338,82 +344,11 @@ __global__ __launch_bounds__(256) void scaledown_kernel(const float *__restrict_
   }
 }
 
-// ------------------------------------------------- ScaleDown chain (small batches)
-// Up to three consecutive ScaleDowns in ONE launch: a workgroup owns a T x T tile of the LAST level of the chain and
-// computes the cone of pixels under it on every level in LDS (level k region = 2 * level k+1 region + 3 per axis), so
-// the coarse pyramid of a frame costs one dependent dispatch instead of three (a single 1080p frame: 37 us -> one
-// launch; r04 single-call budget, profiles/r04_single_call_*).  Every output pixel is the scaledown_kernel expression
-// on the same operands (horizontal pass on clamped source rows, then vertical: bit-identical); pixels in the overlap of
-// neighbouring cones are computed by both workgroups and stored by the one whose tile they lie under.  The redundant
-// arithmetic (1.4-1.8x per level, one pixel per lane instead of DPP quads) makes it the wrong tool for a 64-frame
-// batch, where the extraction is bound by VALU issue: those keep the three streamed launches beside the fine scan.
-#define CHAIN_MAX_LEVELS 3
-#define CHAIN_N0_MAX 85               // source region edge for T * 2^K = 64: 64 + 3 * (2^K - 1) <= 85
-struct ChainLevel { int w, h, p; long long off; };       // off: float offset inside a frame's arena
-struct ChainGeom {
-  int K, T, tiles_x, tiles_y;
-  long long frame_stride;
-  ChainLevel lv[CHAIN_MAX_LEVELS + 1];                     // lv[0] = source, lv[1..K] = outputs
-};
-
+// ------------------------------------------------- ScaleDown chain (small batches): see chain.hpp
 __global__ __launch_bounds__(1024) void scaledown_chain_kernel(float *__restrict__ scratch, ChainGeom G, Taps5 t)
 {
-  __shared__ float s_a[CHAIN_N0_MAX * CHAIN_N0_MAX];       // region of level k-1 (k odd) / level k (k even)
-  __shared__ float s_h[CHAIN_N0_MAX * 41];                 // horizontal pass: rows of level k-1, columns of level k
-  __shared__ float s_b[41 * 41];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
-  float *frame = scratch + (long long)blockIdx.y * G.frame_stride;
-  const float k0 = t.k[0], k1 = t.k[1], k2 = t.k[2];
-  // region of level k: [ax(k), ax(k) + n(k)) x [ay(k), ay(k) + n(k)); a(k-1) = 2 a(k) - 2 and n(k-1) = 2 n(k) + 3 in closed
-  // form (a - 2 and n + 3 double per level), so nothing is indexed dynamically
-  auto ax = [&](int k) -> int { return (tx * G.T - 2) * (1 << (G.K - k)) + 2; };
-  auto ay = [&](int k) -> int { return (ty * G.T - 2) * (1 << (G.K - k)) + 2; };
-  auto n = [&](int k) -> int { return ((G.T + 3) << (G.K - k)) - 3; };
-  {                                                         // stage the source region (clamp-to-edge)
-    const ChainLevel &S = G.lv[0];
-    const float *src = frame + S.off;
-    const int n0 = n(0), ax0 = ax(0), ay0 = ay(0);
-    for (int j = wave; j < n0; j += nwaves) {
-      const float *row = src + (size_t)clampi(ay0 + j, 0, S.h - 1) * S.p;
-      for (int i = lane; i < n0; i += 64) s_a[j * n0 + i] = row[clampi(ax0 + i, 0, S.w - 1)];
-    }
-  }
-  __syncthreads();
-  float *cur = s_a, *nxt = s_b;
-  for (int k = 1; k <= G.K; k++) {
-    const ChainLevel &L = G.lv[k];
-    const int ns = n(k - 1), nd = n(k), axk = ax(k), ayk = ay(k), axs = ax(k - 1), ays = ay(k - 1);
-    // horizontal: every row of the source region, columns of this level (an out-of-image column holds the value of
-    // the clamped one, like the region it is read from)
-    for (int j = wave; j < ns; j += nwaves)
-      for (int i = lane; i < nd; i += 64) {
-        const int cx = clampi(axk + i, 0, L.w - 1);
-        const float *r = cur + j * ns + (2 * cx - axs);      // source column 2 * cx
-        const float s = __builtin_fmaf(k0, r[-2] + r[2], k1 * (r[-1] + r[1]));
-        s_h[j * nd + i] = __builtin_fmaf(k2, r[0], s);
-      }
-    __syncthreads();
-    // vertical + store of the pixels under this workgroup's tile
-    const int sh = G.K - k;                                 // own block of level k: tile * T << sh
-    const int ox0 = (tx * G.T) << sh, oy0 = (ty * G.T) << sh;
-    const int ox1 = tx == G.tiles_x - 1 ? L.w : min(((tx + 1) * G.T) << sh, L.w);
-    const int oy1 = ty == G.tiles_y - 1 ? L.h : min(((ty + 1) * G.T) << sh, L.h);
-    float *dst = frame + L.off;
-    for (int j = wave; j < nd; j += nwaves) {
-      const int y = ayk + j, cy = clampi(y, 0, L.h - 1);
-      const float *c = s_h + (2 * cy - ays) * nd;    // source row 2 * cy
-      for (int i = lane; i < nd; i += 64) {
-        float v = __builtin_fmaf(k2, c[i], k0 * (c[i - 2 * nd] + c[i + 2 * nd]));
-        v = __builtin_fmaf(k1, c[i - nd] + c[i + nd], v);
-        nxt[j * nd + i] = v;
-        const int x = axk + i;
-        if (x >= ox0 && x < ox1 && y >= oy0 && y < oy1) dst[(size_t)y * L.p + x] = v;
-      }
-    }
-    __syncthreads();
-    float *tmp = cur; cur = nxt; nxt = tmp;
-  }
+  __shared__ float s_lds[CHAIN_LDS_FLOATS_MAX];
+  scaledown_chain_block(scratch, G, t, (int)blockIdx.x, (int)blockIdx.y, s_lds);
 }
 
 // ------------------------------------------------------------------ ScaleUp
@@ -482,7 +417,7 @@ int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const Stri
                         long long dst2_frame_stride, const float k5[5], int *done, unsigned *zero_cnt)
 {
   *done = 0;
-  if (g.height < 8 || (g.seg_rows & 7)) return MISIFT_OK;
+  if (g.height < 8 || (g.seg_rows & 1)) return MISIFT_OK;      // (segments start on even rows: the decimation's phase)
   const int dal = is_aligned16(dst, dpitch) && (dst_frame_stride & 3) == 0;
   const int d2al = (((uintptr_t)dst2) & 7) == 0 && (dpitch2 & 1) == 0 && (dst2_frame_stride & 1) == 0;
   int sal;
@@ -535,21 +470,28 @@ int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, floa
 
 // ScaleDowns of pyramid levels src -> dst[0] -> dst[1] -> ... (nlev <= CHAIN_MAX_LEVELS) in one launch; levels are
 // given as {w, h, pitch, float offset inside a frame's arena} with lv[0] the source.
+int make_chain_geom(ChainGeom *G, long long frame_stride, const int (*dims)[3], const long long *offs, int nlev, int tile)
+{
+  if (nlev < 1 || nlev > CHAIN_MAX_LEVELS) {
+    misift_set_error("scaledown chain: %d levels", nlev);
+    return MISIFT_EINVAL;
+  }
+  memset(G, 0, sizeof(*G));
+  G->K = nlev;
+  G->T = tile << (CHAIN_MAX_LEVELS - nlev);            // T << K = 8 * tile whatever K (tile 8: source region <= 85 x 85)
+  G->frame_stride = frame_stride;
+  for (int k = 0; k <= nlev; k++) { G->lv[k].w = dims[k][0]; G->lv[k].h = dims[k][1]; G->lv[k].p = dims[k][2]; G->lv[k].off = offs[k]; }
+  G->tiles_x = (G->lv[nlev].w + G->T - 1) / G->T;
+  G->tiles_y = (G->lv[nlev].h + G->T - 1) / G->T;
+  return MISIFT_OK;
+}
+
 int launch_scaledown_chain(misift_ctx *ctx, float *scratch, long long frame_stride, int nframes, const int (*dims)[3],
                            const long long *offs, int nlev, const float k5[5])
 {
-  if (nlev < 1 || nlev > CHAIN_MAX_LEVELS) {
-    misift_set_error("launch_scaledown_chain: %d levels", nlev);
-    return MISIFT_EINVAL;
-  }
   ChainGeom G;
-  memset(&G, 0, sizeof(G));
-  G.K = nlev;
-  G.T = 8 << (CHAIN_MAX_LEVELS - nlev);                // T * 2^K = 64 whatever K: the source region is <= 85 x 85
-  G.frame_stride = frame_stride;
-  for (int k = 0; k <= nlev; k++) { G.lv[k].w = dims[k][0]; G.lv[k].h = dims[k][1]; G.lv[k].p = dims[k][2]; G.lv[k].off = offs[k]; }
-  G.tiles_x = (G.lv[nlev].w + G.T - 1) / G.T;
-  G.tiles_y = (G.lv[nlev].h + G.T - 1) / G.T;
+  const int rc = make_chain_geom(&G, frame_stride, dims, offs, nlev, 8);
+  if (rc) return rc;
   Taps5 t;
   for (int j = 0; j < 5; j++) t.k[j] = k5[j];
   LaunchScope ls(ctx, "scaledown_chain");

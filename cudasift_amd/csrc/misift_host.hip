@@ -15,6 +15,7 @@
 #include <mutex>
 #include <vector>
 #include "common.hpp"
+#include "chain.hpp"
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -182,10 +183,12 @@ static void warn_hw_queues_once(const char *who)
 {
   const char *e = getenv("GPU_MAX_HW_QUEUES");
   if (e && atoi(e) >= 8) return;
-  misift_set_error("%s: GPU_MAX_HW_QUEUES is %s; with fewer than 8 hardware queues the communication / copy streams share "
-                   "a queue with the extraction stream (set GPU_MAX_HW_QUEUES=8 before the first HIP call)", who,
-                   e ? e : "unset (HIP default: 4)");
-  if (!getenv("MISIFT_QUIET")) fprintf(stderr, "misift: warning: %s\n", misift_last_error());
+  // a warning, not an error: stderr only — misift_last_error() of a successful call stays empty
+  if (!getenv("MISIFT_QUIET"))
+    fprintf(stderr, "misift: warning: %s: GPU_MAX_HW_QUEUES is %s; with fewer than 8 hardware queues the communication / "
+                    "copy streams share a queue with the extraction stream (set GPU_MAX_HW_QUEUES=8 before the first HIP "
+                    "call, or create the first misift context before any other HIP call: it sets it)\n", who,
+            e ? e : "unset (HIP default: 4)");
 }
 void misift_warn_hw_queues(const char *who)
 {
@@ -203,8 +206,18 @@ static CtxExtra *extra(misift_ctx *ctx) { return &reinterpret_cast<CtxFull *>(ct
 // MISIFT_DEVICES="2,3" (SURVEY section 5): device i of this library = HIP device list[i], the others do not exist for
 // it — like HIP_VISIBLE_DEVICES but for libmisift.so only (a process that shares the GPUs with another runtime keeps
 // its own numbering).  Unset or empty: every HIP device, identity.  Read once.
+// HIP reads GPU_MAX_HW_QUEUES when it initialises; a C++ caller that never heard of it gets 4 hardware queues and loses
+// ~20 % through a communicator or a host-fed pipe.  If the variable is unset when the library makes its
+// first HIP call (device enumeration), set it — it takes effect when this is also the process's first HIP call (the normal case for
+// a program that uses the library through cudaSift.h), and is harmless otherwise.  Never overrides the caller's value.
+static void default_hw_queues_once(void)
+{
+  if (!getenv("GPU_MAX_HW_QUEUES") && !getenv("MISIFT_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 static std::vector<int> build_device_map(void)
 {
+  default_hw_queues_once();            // before the library's first HIP call
   std::vector<int> m;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
@@ -327,16 +340,24 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_SCAN_WAVES")) ctx->scan_waves_per_cu = atoi(e) > 0 ? atoi(e) : 16;
   ctx->chain_max_frames = 4;
   if (const char *e = getenv("MISIFT_CHAIN_FRAMES")) ctx->chain_max_frames = atoi(e);
+  ctx->chain_embed = 1;
+  if (const char *e = getenv("MISIFT_CHAIN_EMBED")) ctx->chain_embed = atoi(e) != 0;
   ctx->bin_min_frames = 4;
   if (const char *e = getenv("MISIFT_BIN_MIN_FRAMES")) ctx->bin_min_frames = atoi(e);
   ctx->small_frames = 4;
   if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
+  ctx->strip_rows_small = 8;
+  if (const char *e = getenv("MISIFT_STRIP_ROWS_SMALL")) ctx->strip_rows_small = atoi(e) >= 2 ? atoi(e) / 2 * 2 : 8;
   ctx->scan_rows_small = 9;
   if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL")) ctx->scan_rows_small = atoi(e) > 0 ? atoi(e) : 9;
   ctx->host_spin = 1;
   if (const char *e = getenv("MISIFT_HOST_SPIN")) ctx->host_spin = atoi(e) != 0;
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
+  HIP_TRY(hipMalloc((void **)&ctx->d_flags, sizeof(unsigned) * 64));
+  HIP_TRY(hipMemsetAsync(ctx->d_flags, 0, sizeof(unsigned) * 64, ctx->stream));
+  HIP_TRY(hipHostMalloc((void **)&ctx->h_flags, sizeof(unsigned) * 64, hipHostMallocDefault));
+  memset(ctx->h_flags, 0, sizeof(unsigned) * 64);
   int rc = misift_ensure_frames(ctx, 1, 65536);
   if (rc) return rc;
   return launch_selftest(ctx);
@@ -385,8 +406,13 @@ extern "C" int misift_ctx_create(int device, void *stream, misift_ctx **out)
   int rc = ctx_create_physical(device, stream, false, out);
   if (rc) return rc;
   if (const char *e = getenv("MISIFT_BATCHES_IN_FLIGHT")) {
-    rc = misift_ctx_set_batches_in_flight(*out, atoi(e));
-    if (rc) { misift_ctx_destroy(*out); *out = nullptr; }
+    const int k = atoi(e);
+    if (k < 1 || k > 8) {                       // a bad value must not make context creation fail
+      if (!getenv("MISIFT_QUIET")) fprintf(stderr, "misift: warning: MISIFT_BATCHES_IN_FLIGHT=%s ignored (1..8)\n", e);
+    } else {
+      rc = misift_ctx_set_batches_in_flight(*out, k);
+      if (rc) { misift_ctx_destroy(*out); *out = nullptr; }
+    }
   }
   return rc;
 }
@@ -503,6 +529,8 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   for (auto e : x->pool) hipEventDestroy(e);
   if (ctx->d_counters) hipFree(ctx->d_counters);
   if (ctx->h_counters) hipHostFree(ctx->h_counters);
+  if (ctx->d_flags) hipFree(ctx->d_flags);
+  if (ctx->h_flags) hipHostFree(ctx->h_flags);
   if (ctx->d_cand) hipFree(ctx->d_cand);
   if (ctx->d_det) hipFree(ctx->d_det);
   if (ctx->d_det_sorted) hipFree(ctx->d_det_sorted);
@@ -560,11 +588,12 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
     if (ctx->d_counters) HIP_TRY(hipFree(ctx->d_counters));
     if (ctx->h_counters) HIP_TRY(hipHostFree(ctx->h_counters));
     ctx->d_counters = nullptr; ctx->h_counters = nullptr;
-    HIP_TRY(hipMalloc((void **)&ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes));
+    // (CNT_SPARE_BLOCKS more than frames: the call's flags and ticket words live behind the last frame's counters)
+    HIP_TRY(hipMalloc((void **)&ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + CNT_SPARE_BLOCKS)));
     ctx->alloc_gen++;
     // one block more than frames: the word behind the last frame's counters is the host-export flag (descr_big_kernel)
     HIP_TRY(hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + 1), hipHostMallocDefault));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + CNT_SPARE_BLOCKS), ctx->stream));
     memset(ctx->h_counters, 0, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + 1));
   }
   if (nframes > ctx->cap_frames || cand_cap > ctx->cand_cap) {
@@ -815,8 +844,13 @@ static StripGeom make_geom(misift_ctx *ctx, int w, int h, int pitch, int nframes
   long long want = (target + (long long)nframes * g.nstrips - 1) / ((long long)nframes * g.nstrips);
   if (want < 1) want = 1;
   int seg = (int)((out_rows + want - 1) / want);
-  seg = (seg + 7) / 8 * 8;
-  if (seg < 8) seg = 8;
+  if (nframes <= ctx->small_frames) {         // a frame or two: latency-bound, short (even) segments on every SIMD
+    seg = (seg + 1) / 2 * 2;
+    if (seg < ctx->strip_rows_small) seg = ctx->strip_rows_small;
+  } else {
+    seg = (seg + 7) / 8 * 8;
+    if (seg < 8) seg = 8;
+  }
   if (seg > 128) seg = 128;
   g.seg_rows = seg;
   g.nsegs = (out_rows + seg - 1) / seg;
@@ -1006,7 +1040,22 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   // Small batches (a single frame above all) are bound by the number of DEPENDENT dispatches, not by their work: up to
   // three levels per launch (scaledown_chain_kernel).  Batches keep one streamed launch per level.
   const bool chained = !scanned && nframes <= ctx->chain_max_frames;
-  for (int o = num_octaves; o >= 2 && !scanned;) {
+  // ... and when ONE chain covers every remaining level, it rides in the first workgroups of the scan launch
+  ChainGeom embed;
+  bool embedded = false;
+  if (chained && ctx->opt.fused && ctx->chain_embed && first_down_done && num_octaves >= 3 && num_octaves - 2 <= 3) {
+    const int o = num_octaves - 1, nlev = o - 1;
+    int dims[4][3];
+    long long offs[4];
+    for (int k = 0; k <= nlev; k++) {
+      dims[k][0] = lv[o - k].w; dims[k][1] = lv[o - k].h; dims[k][2] = lv[o - k].p;
+      offs[k] = (long long)(lv[o - k].img - d_scratch);
+    }
+    rc = make_chain_geom(&embed, SS, dims, offs, nlev, 4);
+    if (rc) return rc;
+    embedded = true;
+  }
+  for (int o = num_octaves; o >= 2 && !scanned && !embedded;) {
     if (o == num_octaves && first_down_done) { o--; continue; }
     if (chained) {
       const int nlev = (o - 1) < 3 ? (o - 1) : 3;
@@ -1031,7 +1080,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     // scan / refine / orient / descr each run ONCE over all pyramid levels; the final array is laid out in the
     // reference's segment order by descr_all_kernel
     if (!scanned) {
-      rc = launch_dog_scan_all(ctx, d_scratch, P, tapsv.data(), thresh, 0, num_octaves);
+      rc = launch_dog_scan_all(ctx, d_scratch, P, tapsv.data(), thresh, 0, num_octaves, embedded ? &embed : nullptr, k5);
       if (rc) return rc;
     }
     rc = launch_refine_all(ctx, d_scratch, P, tapsv.data(), thresh, 10.0f, 1.0f / NUM_SCALES, max_pts);
@@ -1084,34 +1133,44 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   return MISIFT_OK;
 }
 
+// Wait until a kernel of the context stream has stored `seq` into a word of pinned host memory: poll it (a few hundred
+// ns after the store) instead of a blocking copy + hipStreamSynchronize.  The records themselves are complete for
+// every later operation on the context's stream; a consumer on ANOTHER stream or device calls misift_ctx_sync first
+// (include/misift.h).  MISIFT_HOST_SPIN=0: plain hipStreamSynchronize.
+static int wait_host_flag(misift_ctx *ctx, unsigned *word, unsigned seq)
+{
+  volatile unsigned *flag = word;
+  bool seen = false;
+  if (ctx->host_spin) {
+    for (unsigned spins = 0; !seen; spins++) {
+      seen = *flag == seq;
+      if (!seen && (spins & 0x3fff) == 0x3fff) {           // every ~16 k polls: is the stream still alive?
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) { seen = *flag == seq; break; }
+        if (q != hipErrorNotReady) HIP_TRY(q);
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    // keep the runtime's bookkeeping of finished commands bounded
+    if ((seq & 63u) == 0) HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (!seen) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (*flag != seq) {
+      misift_set_error("the kernel's completion flag did not arrive (flag %u, expected %u)", *flag, seq);
+      return MISIFT_EHIP;
+    }
+  }
+  return MISIFT_OK;
+}
+
 static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *num_pts_out,
                        bool *cand_overflow)
 {
   if (ctx->exported) {
     // the last kernel of the call has written the counter blocks into h_counters and stores export_seq behind them
-    // when it is done: poll that word (a few hundred ns after the store) instead of a blocking copy + synchronise
-    volatile unsigned *flag = ctx->h_counters + (size_t)nframes * CNT_STRIDE;
-    bool seen = false;
-    if (ctx->host_spin) {
-      for (unsigned spins = 0; !seen; spins++) {
-        seen = *flag == ctx->export_seq;
-        if (!seen && (spins & 0x3fff) == 0x3fff) {           // every ~16 k polls: is the stream still alive?
-          const hipError_t q = hipStreamQuery(ctx->stream);
-          if (q == hipSuccess) { seen = *flag == ctx->export_seq; break; }
-          if (q != hipErrorNotReady) HIP_TRY(q);
-        }
-      }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      // keep the runtime's bookkeeping of finished commands bounded
-      if ((ctx->export_seq & 63u) == 0) HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    if (!seen) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      if (*flag != ctx->export_seq) {
-        misift_set_error("counter export did not arrive (flag %u, expected %u)", *flag, ctx->export_seq);
-        return MISIFT_EHIP;
-      }
-    }
+    const int rc = wait_host_flag(ctx, ctx->h_counters + (size_t)nframes * CNT_STRIDE, ctx->export_seq);
+    if (rc) return rc;
   } else {
     HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes,
                            hipMemcpyDeviceToHost, ctx->stream));
@@ -1389,6 +1448,20 @@ extern "C" int misift_get_counters(misift_ctx *ctx, int frame, unsigned int *cou
   return MISIFT_OK;
 }
 
+// Diagnostic: all CNT_STRIDE (64) words of one frame's counter block — the reference's 17 counters, then the library's
+// own (candidates / detections / duplicates per octave, overflow flags); frame == number of frames of the last call
+// reads the spare block that holds the call's flags.
+extern "C" int misift_get_counter_block(misift_ctx *ctx, int frame, unsigned int *words64)
+{
+  ARG_CHECK(ctx != nullptr);
+  ctx = result_ctx(ctx);
+  ARG_CHECK(words64 && frame >= 0 && frame <= ctx->cap_frames);
+  HIP_TRY(hipMemcpyAsync(words64, ctx->d_counters + (size_t)frame * CNT_STRIDE, sizeof(unsigned) * CNT_STRIDE,
+                         hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MISIFT_OK;
+}
+
 extern "C" int misift_set_counters(misift_ctx *ctx, int frame, const unsigned int *counters17)
 {
   ARG_CHECK(ctx && counters17 && frame >= 0 && frame < ctx->cap_frames);
@@ -1579,9 +1652,14 @@ extern "C" int misift_match_rows(misift_ctx *ctx, void *d_pts1, int row_begin, i
   ARG_CHECK(d_pts1 && d_pts2);
   RoctxRange range("misift_match");
   HIP_TRY(hipSetDevice(ctx->device));
+  ctx->want_match_flag = 1;
+  ctx->match_flagged = 0;
   int rc = launch_match(ctx, (SiftPointD *)d_pts1, row_begin, row_count, (const SiftPointD *)d_pts2, n2);
+  ctx->want_match_flag = 0;
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));              // matching.cu:1191
+  if (ctx->match_flagged) rc = wait_host_flag(ctx, ctx->h_flags, ctx->match_seq);      // matching.cu:1191
+  else HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (rc) return rc;
   return resolve_profile(ctx);
 }
 

@@ -131,6 +131,11 @@ size_t misift_scratch_floats(int width, int height, int num_octaves, int scale_u
  * d_pts: max_pts records.  *num_pts_out follows the reference's rule
  * numPts = min(counter[2*num_octaves], max_pts) (cudaSiftH.cu:115-116).
  * One host<->device sync (the count read-back), like the reference.
+ * Completion (r04): the call returns as soon as the last kernel has handed the counts to the host through pinned
+ * memory, i.e. when every record has been written; the records are complete for everything that is enqueued on the
+ * context's stream afterwards (misift_match, misift_copy_d2h, the cudaSift.h shim's read-back, ...).  A consumer on
+ * ANOTHER stream or device calls misift_ctx_sync() first.  MISIFT_HOST_SPIN=0 restores a full stream synchronisation
+ * inside the call.  The same holds for misift_match / misift_match_rows.
  * Input limit (ours, not the reference's): width, height >= 16 and the coarsest pyramid level >= 8 px in both directions
  * (width >> (num_octaves - 1) >= 8, after the doubling of scale_up), else MISIFT_EINVAL.  The reference accepts such
  * images and finds next to nothing in them (tests/test_gpu_refemul.py). */
@@ -222,6 +227,9 @@ int misift_host_free(void *ptr);
 /* Per-frame point counters of the last extraction, 17 per frame, in the
  * reference's layout (cudaSiftD.cu:14, protocol cudaSiftD.cu:1297-1300). */
 int misift_get_counters(misift_ctx *ctx, int frame, unsigned int *counters17);
+/* Diagnostic: all 64 words of one frame's counter block (the 17 reference counters, then per-octave candidate /
+ * detection / duplicate counts and overflow flags); frame == frames of the last call: the call's flag block. */
+int misift_get_counter_block(misift_ctx *ctx, int frame, unsigned int *words64);
 int misift_set_counters(misift_ctx *ctx, int frame, const unsigned int *counters17);
 
 /* ------------------------------------------------- stage-level entry points

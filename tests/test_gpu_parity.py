@@ -220,6 +220,22 @@ def test_extract_scaleup(ctx, stereo):
     compare_points(ref[:nref], got[:ngot], "extract_scaleup", record)
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_extract_scaleup_with_fix_numpts(ctx, stereo, fused):
+    """options.fix_numpts puts the finest octave's second orientations INSIDE numPts: with scale_up they must be
+    rescaled like every other returned record (r03 advisor finding: the fused kernels skipped them)."""
+    img = stereo[0][300:540, 400:720]
+    ctx.set_options(fix_numpts=1, fused=fused)
+    try:
+        ref, nref, cref = orc().extract(img, num_octaves=4, thresh=3.0, scale_up=True, fix_numpts=True)
+        got, ngot, cgot = ctx.extract(img, num_octaves=4, thresh=3.0, scale_up=True)
+    finally:
+        ctx.set_options(fix_numpts=0, fused=1)
+    assert np.array_equal(cref, cgot), (cref, cgot)
+    assert nref == ngot == int(cref[2 * 4 + 1]) and int(cref[9]) > int(cref[8]), cref     # the case needs duplicates
+    compare_points(ref[:nref], got[:ngot], "extract_scaleup_fixnum_%d" % fused, record)
+
+
 def test_extract_batch_equals_single(ctx):
     imgs = np.stack([synth_frame(10 + f, 640, 360) for f in range(5)])
     pts, n = ctx.extract_batch(imgs, num_octaves=4, thresh=3.0, max_pts=8192)

@@ -19,7 +19,7 @@ for cfg in "$@"; do
     case $kv in thresh=*) thresh=${kv#thresh=};; *) envs="$envs $kv";; esac
   done
   echo "##### [$cfg]" >> $out
-  env GPU_MAX_HW_QUEUES=8 $envs build/single_call /tmp/frame0_1920x1080.f32 /tmp/frame1_1920x1080.f32 1920 1080 200 5 $thresh 0 | grep '^{' | head -1 >> $out
+  env GPU_MAX_HW_QUEUES=8 $envs build/single_call /tmp/frame0_1920x1080.f32 /tmp/frame1_1920x1080.f32 1920 1080 200 5 $thresh 0 | grep '^{' >> $out
   (cd /tmp && rm -rf /tmp/sw && env $envs timeout 300 rocprofv3 --kernel-trace --hip-trace --memory-copy-trace -d /tmp/sw -o sw --output-format csv -- \
      $R/build/single_call /tmp/frame0_1920x1080.f32 /tmp/frame1_1920x1080.f32 1920 1080 100 5 $thresh 0 > /dev/null 2>&1)
   python tools/single_call_budget.py /tmp/sw 100 2>&1 | sed -n '1,/^GPU span/p' | grep -v "^==" >> $out
