@@ -370,6 +370,11 @@ def matcher_leg(ops, rank, world, nm, msteps=3, validate_rows=100, l2=False, poi
     return out
 
 
+def np_clip0(a):
+    import numpy as np
+    return np.maximum(a, 0)
+
+
 class StepPipeline:
     """The software-pipelined step loop of ONE rank, the same for every N: batch k is extracted AND packed on the device
     (misift_extract_batch_packed_async, nothing synchronises), then the host completes batch k-LAG: reads its per-frame
@@ -379,8 +384,13 @@ class StepPipeline:
     overlapped."""
 
     def __init__(self, torch, capi, ctxs, ctx_streams, comm, rank, world, device, frames, B, NB, scratches, pts, unfused,
-                 ring=1):
+                 ring=1, root_mode="fixed"):
         self.torch, self.capi, self.ctxs, self.ctx_streams, self.comm = torch, capi, ctxs, ctx_streams, comm
+        # root of the gather of batch k: 0 ("fixed", BASELINE config 4 as written) or k % world ("rotate": every rank's
+        # xGMI ingress takes its turn — 7 senders x ~77 MB per step into ONE GPU is more than its links carry at today's
+        # per-GPU rate, DESIGN.md section 6).  May be switched between run() calls.
+        self.root_mode = root_mode
+        self.gather_s, self.gather_calls, self.wire_bytes = 0.0, 0, 0
         self.rank, self.world, self.frames, self.B, self.NB, self.scratches = rank, world, frames, B, NB, scratches
         self.pts, self.unfused = pts, unfused
         NCTX = self.NCTX = len(ctxs)
@@ -398,8 +408,9 @@ class StepPipeline:
         self.packed = [torch.empty((B * REC_CAP * 576,), dtype=torch.uint8, device=device) for _ in range(NSLOT)]
         self.cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(NSLOT)]
         self.done_ev = [None] * NSLOT
+        # every rank that can be a root holds a receive buffer (rotating root: all of them)
         self.recv = (torch.empty((world * B * REC_CAP * 576,), dtype=torch.uint8, device=device)
-                     if (comm and rank == 0) else None)
+                     if (comm and (rank == 0 or world > 1)) else None)
         # normal priority: high-priority streams share ONE hardware queue with the contexts' coarse-level streams
         # (2 contexts: 49 k -> 54 k frames/s)
         self.rb_stream = torch.cuda.Stream(device=device)
@@ -437,8 +448,16 @@ class StepPipeline:
         torch, B = self.torch, self.B
         slot = k % self.NSLOT
         if self.comm is not None:
-            c, _ = self.comm.gather_complete(slot, B, 0, self.recv.data_ptr() if self.recv is not None else None,
+            root = (k % self.world) if self.root_mode == "rotate" else 0
+            tg = time.perf_counter()
+            c, _ = self.comm.gather_complete(slot, B, root, self.recv.data_ptr() if (self.recv is not None and root == self.rank) else None,
                                              self.world * B * self.REC_CAP)
+            self.gather_s += time.perf_counter() - tg
+            self.gather_calls += 1
+            # bytes that crossed the links for this batch: every sender's valid records into the root, plus the per-frame
+            # counts every rank gets from every other (the all-gather in front of the point-to-point messages)
+            valid = np_clip0(c)
+            self.wire_bytes += int(valid.sum() - valid[root].sum()) * 576 + (self.world - 1) * self.world * B * 4
             return c
         with torch.cuda.stream(self.rb_stream):             # count read-back beside the running extraction
             if self.RING > 1:
@@ -507,6 +526,7 @@ def emulate_ranks(args):
     torch.cuda.set_device(0)
     B, NB = max(1, min(args.frames_per_gpu, 4)), 2
     steps, warm = max(3, min(args.steps, 12)), min(args.warmup, 2)
+    root_last = ((warm + steps - 1) % N) if args.gather_root == "rotate" else 0      # root of the LAST batch's gather
     nm = min(args.match_n, 16384)
     frames_of = []
     for r in range(N):                       # every rank's own frames, generated as main() generates them
@@ -535,14 +555,14 @@ def emulate_ranks(args):
                 scr = [torch.empty((B * S,), dtype=torch.float32, device=device) for _ in range(ring)]
                 stream.synchronize()
                 pl = StepPipeline(torch, capi, [ctx], [stream], comm, rank, N, device, frames_of[rank], B, NB, scr, None, False,
-                                  ring=ring)
+                                  ring=ring, root_mode=args.gather_root)
                 pl.run(0, warm)
                 comm.barrier()
                 counts = pl.run(warm, steps)
                 comm.barrier()
                 stream.synchronize()
                 out = {"counts": counts}
-                if rank == 0:                # the root holds every rank's records of the LAST batch, rank after rank
+                if rank == root_last:        # the root holds every rank's records of the LAST batch, rank after rank
                     total = int(np.maximum(counts, 0).sum())
                     out["records"] = pl.recv[: total * 576].cpu().numpy().view(capi.POINT_DTYPE).copy()
                     out["last_batch"] = (warm + steps - 1) % NB
@@ -575,8 +595,8 @@ def emulate_ranks(args):
     validated = None
     if orc is not None:                      # every rank's frames of the last batch, as gathered on rank 0, vs the oracle
         from util import compare_points
-        recs, off, validated = res[0]["records"], 0, 0
-        b0 = res[0]["last_batch"] * B
+        recs, off, validated = res[root_last]["records"], 0, 0
+        b0 = res[root_last]["last_batch"] * B
         for r in range(N):
             host = frames_of[r][b0:b0 + B].cpu().numpy()
             ref, nref, _ = orc.extract_batch(host, NUM_OCTAVES, INIT_BLUR, THRESH, max_pts=8192)
@@ -592,6 +612,7 @@ def emulate_ranks(args):
            "steps": steps, "warmup": warm, "batches_in_flight": max(1, args.batches_in_flight),
            "transport": "misift_loopback_world: N communicators / contexts / host threads on ONE device, device-to-device "
                         "copies through a shared rendezvous (no RCCL); same StepPipeline and matcher_leg as --gpus N",
+           "gather_root": args.gather_root, "root_of_last_step": root_last,
            "gathered_frames_last_step": int(N * B), "validated_frames": validated,
            "keypoints_per_frame": round(float(np.mean(counts)), 1),
            "match": None if m is None else {"n1": m["n1"], "n2": m["n2"], "split": m["split"],
@@ -602,6 +623,86 @@ def emulate_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------------ main
+# ------------------------------------------------------------------------------------------------ self-spawned ranks
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def visible_gpus():
+    """Devices this process could use (no context is created)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count()) if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+def spawn_ranks(ngpus, argv, need_gpus=True):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  N children of this same command, one per
+    visible device, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment (exactly what
+    torch.distributed.run sets), stdout / stderr inherited — rank 0's JSON line is the last line of stdout.  Fails LOUDLY
+    (rc != 0, nothing measured) when fewer than N devices are visible: a run that silently measured one GPU would be
+    recorded as an N-GPU number.  Returns the exit code."""
+    import subprocess
+    if need_gpus:
+        have = visible_gpus()
+        if have < ngpus:
+            print("bench.py: --gpus %d but only %d GPU(s) visible to this process: refusing to run (an N-GPU number needs N "
+                  "devices; use --emulate-ranks N for the functional single-GPU rehearsal)" % (ngpus, have), file=sys.stderr)
+            return 3
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(ngpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                "BENCH_SELF_SPAWNED": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: the only kind the host driver supports
+    procs = []
+    for r in range(ngpus):
+        e = dict(env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in pending:              # one rank failed: the others would wait for it forever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    if rc:
+        print("bench.py: a rank exited with code %d; no result" % rc, file=sys.stderr)
+    return rc
+
+
+def spawn_check():
+    """`--spawn-check` (tests/test_bench_cpu.py): what a spawned rank sees, over gloo — no GPU needed."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    if os.environ.get("BENCH_SPAWN_CHECK_FAIL_RANK") == str(rank):
+        sys.exit(7)                                            # the launcher must report this and stop the others
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "world": world, "sum_of_ranks_plus_1": int(t.item()),
+                          "local_rank": int(os.environ["LOCAL_RANK"]), "master_addr": os.environ["MASTER_ADDR"]}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -631,7 +732,20 @@ def main():
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="run the N-rank driver loops (gather of SiftData, sharded matcher) end to end on ONE GPU through the "
                          "loopback transport; functional only, prints no rate")
+    ap.add_argument("--spawn-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--gather-root", choices=("rotate", "fixed"), default="rotate",
+                    help="N > 1: root of the SiftData gather — 'rotate': step %% N (every rank's xGMI ingress takes its turn: "
+                         "one fixed root needs 7 x 77 MB per 1.17 ms step = 460 GB/s into ONE GPU, DESIGN.md section 6); "
+                         "'fixed': rank 0 (BASELINE config 4 as written).  The line reports the other mode in `gather`")
+    ap.add_argument("--preroll-steps", type=int, default=60,
+                    help="untimed steps before the warm-up: the shader clock needs ~40 ms of this load to settle (DESIGN.md "
+                         "section 5), so that a 20-step timed window measures the same steady state as a 100-step one")
     args = ap.parse_args()
+    # `--gpus N` as a plain command (the driver's shape): spawn the N ranks ourselves
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_ranks and not args.pmc_child:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], need_gpus=not args.spawn_check))
+    if args.spawn_check:
+        sys.exit(spawn_check())
     if args.batches_in_flight <= 0:
         args.batches_in_flight = 4 if args.steps >= 50 else 2
     # HIP multiplexes a process's streams onto 4 hardware queues unless told otherwise, and a stream that shares a
@@ -654,9 +768,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        # a line that says n_gpus = WORLD_SIZE while the command said --gpus N would be mis-recorded: refuse
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to run (launch N ranks for --gpus N, or run the plain "
+                  "command and let bench.py spawn them)" % (args.gpus, os.environ.get("WORLD_SIZE")), file=sys.stderr)
+        sys.exit(4)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d has no device %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -686,6 +807,10 @@ def main():
         if world > 1:
             dist.broadcast(idt, 0)
         comm = capi.Comm(ctx, world, rank, bytes(idt.cpu().numpy().tobytes()))
+        if comm.size != world or comm.rank != rank:
+            print("bench.py: communicator reports rank %d of %d, expected %d of %d" % (comm.rank, comm.size, rank, world),
+                  file=sys.stderr)
+            sys.exit(5)
 
     # ---------------- matcher (BASELINE config 5) — its own timed region (barrier on both sides, matcher_leg); the order of
     # the two legs is free and does not change either number (measured both ways)
@@ -715,7 +840,7 @@ def main():
     # Software-pipelined step loop, the same for every N (class StepPipeline above; `--emulate-ranks` drives N of them
     # from N host threads of this process over the loopback transport)
     pl = StepPipeline(torch, capi, ctxs, ctx_streams, comm, rank, world, device, frames, B, NB, scratches, pts, args.unfused,
-                      ring=RING)
+                      ring=RING, root_mode=args.gather_root if world > 1 else "fixed")
     LAG, NSLOT, REC_CAP = pl.LAG, pl.NSLOT, pl.REC_CAP
     packed, cnts, step_ev = pl.packed, pl.cnts, pl.step_ev
     enqueue, run, host_t, trace_host = pl.enqueue, pl.run, pl.host_t, pl.trace_host
@@ -734,15 +859,40 @@ def main():
     # the shader clock ramps up over ~40 ms of this load.  `--steps 20 --warmup 5` therefore reads ~4 % below a 100-step run.
     gen_frames_torch(torch, NB * B, rank * NB * B, device, out=frames)
     torch.cuda.synchronize()
+    # Untimed pre-roll (r04): the same steps the timed region runs, long enough for the shader clock to settle, so that the
+    # driver's `--steps 20 --warmup 5` window and a 100-step run measure the same steady state.  Outside the contract's W
+    # warm-up steps and K timed steps, which follow unchanged; stated in the line (`preroll_steps`).
+    PRE = max(0, args.preroll_steps)
+    if PRE > 0:
+        run(0, PRE)
     if args.warmup > 0:
-        run(0, args.warmup)
+        run(PRE, args.warmup)
     barrier()
     step_ev.clear()
+    pl.gather_s, pl.gather_calls, pl.wire_bytes = 0.0, 0, 0
     t0 = time.perf_counter()
-    all_counts = run(args.warmup, args.steps)
+    all_counts = run(PRE + args.warmup, args.steps)
+    own_dt = time.perf_counter() - t0          # this rank's own loop (before the closing barrier): per-rank rate
     barrier()
     dt = time.perf_counter() - t0
-    last_k = args.warmup + args.steps - 1
+    last_k = PRE + args.warmup + args.steps - 1
+    gather_info = None
+    if world > 1:
+        own = torch.tensor([own_dt, pl.gather_s / max(1, args.steps), float(pl.wire_bytes) / max(1, args.steps)],
+                           dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(allr, own)
+        allr = [t.cpu().numpy() for t in allr]
+        gather_info = {"root": args.gather_root, "rccl_ranks": int(comm.size),
+                       "per_rank_frames_per_s": [round(B * args.steps / float(a[0]), 1) for a in allr],
+                       "gather_ms_per_step": round(1e3 * max(float(a[1]) for a in allr), 4),
+                       "gather_ms_per_step_note": "host time inside misift_gather_complete per step, max over ranks (the gather of "
+                                                  "batch k-LAG runs on the communicator's stream under the extraction of the "
+                                                  "batches behind it; what is NOT hidden shows up in ms_per_step)",
+                       "wire_MB_per_step": round(float(allr[0][2]) / 1e6, 3),
+                       "wire_note": "valid 576-byte records of the non-root ranks into the root + the per-frame counts "
+                                    "all-gather, per step; at ms_per_step this is %.1f GB/s summed over the links"
+                                    % (float(allr[0][2]) / 1e9 / (1e-3 * 1e3 * dt / args.steps))}
     kp_per_frame = float(np.mean(all_counts[rank if all_counts.shape[0] > 1 else 0]))
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -773,6 +923,23 @@ def main():
     last_cnt = cnts[last_slot].cpu().numpy().copy()
     last_counts, last_offs = last_cnt[:B], last_cnt[B:]
     last_recs = packed[last_slot][: int(last_offs[B]) * 576].cpu().numpy().view(capi.POINT_DTYPE).copy()
+
+    # ---------------- N > 1: the same loop with the OTHER gather root (reported beside the headline, never `value`)
+    if world > 1:
+        other = "fixed" if args.gather_root == "rotate" else "rotate"
+        n2 = max(LAG + 2, min(args.steps, 40))
+        pl.root_mode = other
+        barrier()
+        t1 = time.perf_counter()
+        run(last_k + 1, n2)
+        barrier()
+        dt2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
+        pl.root_mode = args.gather_root
+        last_k += n2
+        gather_info["other_root"] = {"root": other, "steps": n2, "value": round(world * B * n2 / float(dt2.item()), 1),
+                                     "ms_per_step": round(1e3 * float(dt2.item()) / n2, 4)}
+        step_ev.clear()
 
     # ---------------- per-kernel durations (HIP events on the launch stream) for the roofline
     if pts is None:
@@ -1151,7 +1318,10 @@ def main():
                               "bit-identical; every descriptor element within 1e-6; no outlier budget)" % (validated - 1))
                if validated else "skipped (--no-cpu)",
                "roofline": roofline, "kernels": kernels, "step_ms": step_ms, "match": match, "cpu_baseline": cpu,
-               "pcie_inclusive": pcie, "single_frame": latency,
+               "pcie_inclusive": pcie, "single_frame": latency, "gather": gather_info, "rccl_ranks": int(comm.size) if comm else 0,
+               "preroll_steps": PRE,
+               "preroll_note": "untimed steps of the same loop before the W warm-up steps (clock settling, DESIGN.md section 5); "
+                               "the timed region is exactly `steps` steps",
                "kernels_note": "ms_per_step = HIP-event durations on the launch stream(s) over 10 more steps of the same "
                                "pipelined loop (per context) with the library's per-kernel events switched on; dog_scan runs as two launches per step (fine levels on the context stream, the "
                                "coarse ScaleDowns + coarse levels beside it on a second stream) whose durations overlap, so the "

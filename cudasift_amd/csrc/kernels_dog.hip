@@ -469,6 +469,9 @@ struct ScanRowCtx {
 // 18 us without).  Now a wavefront parks its codes in LDS and asks for list space once per CQ_CAP candidates, and at the
 // end of its segment once per WORKGROUP (scan_queue_finish).
 #define CQ_CAP 64
+#ifndef SCAN_DIRECT_APPEND
+#define SCAN_DIRECT_APPEND 0     // A/B builds (tools/variants.sh): 1 = r03's per-lane atomics, same results
+#endif
 __device__ __forceinline__ void wave_lds_fence()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -639,7 +642,7 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
         excl += __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, 0u)) << b;
         total += (unsigned)__builtin_popcountll(bl) << b;
       }
-      if (total > CQ_CAP) {
+      if (SCAN_DIRECT_APPEND || total > CQ_CAP) {
         // more candidates in ONE row of a strip than the queue holds (white noise, tiny thresholds): straight to the list
         scan_queue_flush(g, qn);
         if (mask) {
