@@ -99,6 +99,7 @@ SIGNATURES = {
     "misift_gather_post": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "misift_gather_complete": (_i, [_vp, _i, _i, _vp, _vp, _sz, _vp]),
     "misift_match_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "misift_comm_wire_bytes": (_i, [_vp, _vp, _vp]),
     "misift_find_homography": (_i, [_vp, _vp, _i, _fp, _ip, _i, _f, _f, _f]),
     "misift_extract_batch_packed_async": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "misift_lowpass_scaledown": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f, _vp, _i]),
@@ -535,6 +536,9 @@ class HipEvent:
 
 COMM_ID_BYTES = 128
 RESULT_DTYPE = np.dtype([("score", "<f4"), ("ambiguity", "<f4"), ("match", "<i4")])      # 12 B/row (misift_match_sharded)
+# the 528-byte match column misift_match_sharded ships and leaves in d_set2_all (MISIFT_MATCH_COLUMN_BYTES)
+COLUMN_DTYPE = np.dtype([("data", "<f4", (128,)), ("xpos", "<f4"), ("ypos", "<f4"), ("reserved", "<f4", (2,))])
+assert COLUMN_DTYPE.itemsize == 528
 
 
 def comm_unique_id():
@@ -595,6 +599,12 @@ class Comm:
         check(lib().misift_gather_complete(self.h, slot, root, counts.ctypes.data, d_recv, capacity_records, offs),
               "misift_gather_complete")
         return counts, np.array(list(offs), np.int64)
+
+    def wire_bytes(self):
+        """(received, sent) payload bytes of this rank since the communicator was created."""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        check(lib().misift_comm_wire_bytes(self.h, C.byref(a), C.byref(b)), "misift_comm_wire_bytes")
+        return int(a.value), int(b.value)
 
     def match_sharded(self, d_rows1, row_count, d_shard2, shard_count, d_set2_all, d_results_all=None):
         check(lib().misift_match_sharded(self.ctx.h, self.h, d_rows1, row_count, d_shard2, shard_count, d_set2_all,

@@ -447,7 +447,8 @@ int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
                       float thresh, float edge_limit, float factor, int max_pts);
 int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2);
 int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2,
-                       const SiftPointD *pts2_own, int own_t0, int own_t1, hipEvent_t rest_ready, int phase);
+                       const SiftPointD *pts2_own, int own_t0, int own_t1, hipEvent_t rest_ready, int phase,
+                       int packed2 = 0);     // packed2: set 2 is an array of MISIFT_MATCH_COLUMN_BYTES match columns, not records
 enum { MATCH_PHASE_ALL = 0, MATCH_PHASE_OWN = 1, MATCH_PHASE_REST = 2 };   // both launches + merge / the own-shard launch / the rest + merge
 int launch_test_exp2(misift_ctx *ctx, const float *x, float *out, int n);
 int launch_test_points_fn(misift_ctx *ctx, int fn, const float *x, const float *y, float *out, float *out2, int n);

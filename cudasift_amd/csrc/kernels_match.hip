@@ -43,6 +43,9 @@ struct MatchGeom {
   // wire, then everything around them: multigpu.hip).  Chunk c of this launch is chunk chunk_base + c of nchunks_total.
   int tile_base, hole_begin, hole_len;
   int chunk_base, nchunks_total;
+  // set-2 element layout, in floats: SiftPoint records (stride 144, descriptor at 16, xpos/ypos at 0) or the packed
+  // match columns the sharded matcher ships (MISIFT_MATCH_COLUMN_BYTES = 528: stride 132, descriptor at 0, xy at 128)
+  int stride2, data_off2, xy_off2;
 };
 __device__ __forceinline__ int tile_col0(const MatchGeom &G, int v)       // first column of virtual super-tile v
 {
@@ -83,7 +86,7 @@ __device__ __forceinline__ void top2_merge(float &mx, float &sec, int &ix, float
 // chain is covered by the other (and by the second wavefront resident on the SIMD).
 #define MT_SUPER 64
 __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kernel(const SiftPointD *__restrict__ pts1,
-                                                       const SiftPointD *__restrict__ pts2, MatchGeom G,
+                                                       const float *__restrict__ set2, MatchGeom G,
                                                        float *__restrict__ partial)
 {
   __shared__ float Bs[2][MT_SUPER * MT_BSTRIDE];
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
 #pragma unroll
     for (int j = 0; j < MT_STAGE; j++) {
       const int p2 = min(tile_col0(G, st) + scol + 2 * MT_WG_WAVES * j, G.n2 - 1);
-      stage[j] = reinterpret_cast<const float4 *>(pts2[p2].data)[f4];
+      stage[j] = reinterpret_cast<const float4 *>(set2 + (size_t)p2 * G.stride2 + G.data_off2)[f4];
     }
   };
   auto lstore = [&](int buf) {
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
 // had one thread per row walk a strided [chunk][24] table — 0.34 ms for 12 500 rows x 126 chunks, 13 % of that sweep),
 // then the eight classes are combined in every lane of the group exactly as before and lane 0 writes the row.
 __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict__ pts1,
-                                                          const SiftPointD *__restrict__ pts2, MatchGeom G,
+                                                          const float *__restrict__ set2, MatchGeom G,
                                                           const float *__restrict__ partial, int exact_top2,
                                                           unsigned *__restrict__ ticket, unsigned *__restrict__ host_flag,
                                                           unsigned host_seq)
@@ -404,8 +407,9 @@ __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict
     SiftPointD *o = &pts1[G.row_begin + rl];
     o->score = max_score;
     o->match = index;
-    o->match_xpos = index >= 0 ? pts2[index].xpos : 0.0f;   // never reads sift2[-1] (Appendix B #9)
-    o->match_ypos = index >= 0 ? pts2[index].ypos : 0.0f;
+    const float *m2 = set2 + (size_t)(index >= 0 ? index : 0) * G.stride2 + G.xy_off2;
+    o->match_xpos = index >= 0 ? m2[0] : 0.0f;              // never reads sift2[-1] (Appendix B #9)
+    o->match_ypos = index >= 0 ? m2[1] : 0.0f;
     o->ambiguity = sec_score / (max_score + 1e-6f);
   }
   // Synchronous callers (misift_match): the workgroup that draws the last ticket stores the call's sequence number in
@@ -479,13 +483,16 @@ extern "C" int misift_test_match_plan(int num_cus, int n1, int n2, int *nchunks,
 // the smaller column), so the result is the single sweep's, bit for bit.  own_t0 == own_t1: the plain single launch.
 // `phase` lets the caller post its exchange between the two launches (the chunk plan is a pure function of the arguments).
 int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2,
-                       const SiftPointD *pts2_own, int own_t0, int own_t1, hipEvent_t rest_ready, int phase)
+                       const SiftPointD *pts2_own, int own_t0, int own_t1, hipEvent_t rest_ready, int phase, int packed2)
 {
   if (row_count <= 0 || n2 <= 0) return MISIFT_OK;
   MatchGeom G;
   memset(&G, 0, sizeof(G));                    // (phases that skip a launch still pass G by value to the merge)
   G.row_begin = row_begin; G.row_count = row_count; G.n1_total = row_begin + row_count;
   G.n2 = n2;
+  if (packed2) { G.stride2 = MISIFT_MATCH_COLUMN_BYTES / 4; G.data_off2 = 0; G.xy_off2 = 128; }
+  else { G.stride2 = MISIFT_POINT_BYTES / 4; G.data_off2 = 16; G.xy_off2 = 0; }
+  const float *f2 = reinterpret_cast<const float *>(pts2), *f2_own = reinterpret_cast<const float *>(pts2_own);
   G.ncols = ctx->opt.match_full ? n2 : MT_TILE * (n2 / MT_TILE);
   const int ntiles_all = (G.ncols + MT_SUPER - 1) / MT_SUPER;                 // 64-column super-tiles
   const int nrb = (row_count + MT_ROWS_PER_BLOCK - 1) / MT_ROWS_PER_BLOCK;
@@ -506,7 +513,7 @@ int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row
     G.ntiles = n_own; G.nchunks = ch_own; G.tiles_per_chunk = tpc_own;
     G.tile_base = own_t0; G.hole_begin = 0x7fffffff; G.hole_len = 0; G.chunk_base = 0;
     LaunchScope ls(ctx, "match_mfma");
-    hipLaunchKernelGGL(match_kernel, dim3(nrb * ch_own), dim3(64 * MT_WG_WAVES), 0, ctx->stream, pts1, pts2_own, G, partial);
+    hipLaunchKernelGGL(match_kernel, dim3(nrb * ch_own), dim3(64 * MT_WG_WAVES), 0, ctx->stream, pts1, f2_own, G, partial);
     int rc = ls.finish();
     if (rc) return rc;
   }
@@ -516,7 +523,7 @@ int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row
     G.ntiles = n_rest; G.nchunks = ch_rest; G.tiles_per_chunk = tpc_rest;
     G.tile_base = 0; G.hole_begin = n_own ? own_t0 : 0x7fffffff; G.hole_len = n_own; G.chunk_base = ch_own;
     LaunchScope ls(ctx, "match_mfma");
-    hipLaunchKernelGGL(match_kernel, dim3(nrb * ch_rest), dim3(64 * MT_WG_WAVES), 0, ctx->stream, pts1, pts2, G, partial);
+    hipLaunchKernelGGL(match_kernel, dim3(nrb * ch_rest), dim3(64 * MT_WG_WAVES), 0, ctx->stream, pts1, f2, G, partial);
     int rc = ls.finish();
     if (rc) return rc;
   }
@@ -528,7 +535,7 @@ int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row
       ctx->match_seq++;
       ctx->match_flagged = 1;
     }
-    hipLaunchKernelGGL(match_merge_kernel, dim3((row_count * 8 + 255) / 256), dim3(256), 0, ctx->stream, pts1, pts2,
+    hipLaunchKernelGGL(match_merge_kernel, dim3((row_count * 8 + 255) / 256), dim3(256), 0, ctx->stream, pts1, f2,
                        G, partial, ctx->opt.match_exact_top2, ctx->d_flags, host_flag, ctx->match_seq);
     return ls.finish();
   }
@@ -536,5 +543,5 @@ int launch_match_split(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row
 
 int launch_match(misift_ctx *ctx, SiftPointD *pts1, int row_begin, int row_count, const SiftPointD *pts2, int n2)
 {
-  return launch_match_split(ctx, pts1, row_begin, row_count, pts2, n2, nullptr, 0, 0, nullptr, MATCH_PHASE_ALL);
+  return launch_match_split(ctx, pts1, row_begin, row_count, pts2, n2, nullptr, 0, 0, nullptr, MATCH_PHASE_ALL, 0);
 }

@@ -1674,7 +1674,7 @@ extern "C" int misift_test_match_split(misift_ctx *ctx, void *d_pts1, int n1, co
   ARG_CHECK(d_pts1 && d_pts2);
   HIP_TRY(hipSetDevice(ctx->device));
   int rc = launch_match_split(ctx, (SiftPointD *)d_pts1, 0, n1, (const SiftPointD *)d_pts2, n2,
-                              (const SiftPointD *)d_pts2, own_tile_begin, own_tile_end, nullptr, MATCH_PHASE_ALL);
+                              (const SiftPointD *)d_pts2, own_tile_begin, own_tile_end, nullptr, MATCH_PHASE_ALL, 0);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return resolve_profile(ctx);

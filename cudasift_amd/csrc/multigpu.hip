@@ -144,6 +144,7 @@ struct misift_comm {
   int cap_frames;
   std::vector<GatherSlot> slots;
   hipEvent_t ev_fork, ev_gathered;   // sharded matcher: inputs ready on the context stream / set 2 complete on the communication stream
+  unsigned long long wire_bytes = 0, sent_bytes = 0;   // bytes this rank has RECEIVED / SENT over the links (misift_comm_wire_bytes)
 };
 
 // ---- RCCL transport
@@ -490,6 +491,8 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
   else {
     int rc = c->tp->allgather(c, s.d_counts, c->d_all_counts, sizeof(int) * (size_t)nf, c->stream);
     if (rc) { s.posted = false; return rc; }
+    c->wire_bytes += (unsigned long long)(nr - 1) * nf * sizeof(int);
+    c->sent_bytes += (unsigned long long)(nr - 1) * nf * sizeof(int);
   }
   HIP_TRY(hipMemcpyAsync(c->h_all_counts, c->d_all_counts, sizeof(int) * (size_t)nr * nf, hipMemcpyDeviceToHost,
                          c->stream));
@@ -517,9 +520,11 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
     for (int r = 0; r < nr && !rc; r++) {
       if (r == root || nrec[r] == 0) continue;
       rc = c->tp->recv(c, (char *)d_recv + off[r] * sizeof(SiftPointD), nrec[r] * sizeof(SiftPointD), r, c->stream);
+      c->wire_bytes += (unsigned long long)nrec[r] * sizeof(SiftPointD);
     }
   } else if (nrec[c->rank] && !rc) {
     rc = c->tp->send(c, s.d_packed, nrec[c->rank] * sizeof(SiftPointD), root, c->stream);
+    c->sent_bytes += (unsigned long long)nrec[c->rank] * sizeof(SiftPointD);
   }
   // a failure inside the group must still close it: an open NCCL group swallows every later collective of this thread
   const int rc_end = c->tp->group_end(c, c->stream);
@@ -532,9 +537,32 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
   return MISIFT_OK;
 }
 
+// Bytes this rank has received / sent over the links since the communicator was created (payload of the collectives
+// and point-to-point messages above; what a ring all-gather forwards on behalf of others is not counted).
+extern "C" int misift_comm_wire_bytes(misift_comm *c, unsigned long long *received, unsigned long long *sent)
+{
+  MG_CHECK(c != nullptr);
+  if (received) *received = c->wire_bytes;
+  if (sent) *sent = c->sent_bytes;
+  return MISIFT_OK;
+}
+
 // ------------------------------------------------------------------ config 5: row-block matcher
 struct MatchResult { float score, ambiguity; int match; };     // the 12 B/row result of SURVEY 8e
 static_assert(sizeof(MatchResult) == 12, "result row");
+
+// a 576-byte record -> the 528-byte match column the sharded matcher ships: 33 float4 per column (32 of descriptor, then
+// {xpos, ypos, 0, 0}); thread t writes float4 t % 33 of column t / 33
+__global__ __launch_bounds__(256) void pack_match_columns_kernel(const SiftPointD *__restrict__ recs, int n,
+                                                                 float4 *__restrict__ out)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t colm = t / 33;
+  const int q = (int)(t - colm * 33);
+  if (colm >= (size_t)n) return;
+  const SiftPointD &r = recs[colm];
+  out[t] = q < 32 ? reinterpret_cast<const float4 *>(r.data)[q] : make_float4(r.xpos, r.ypos, 0.0f, 0.0f);
+}
 
 __global__ void pack_match_results_kernel(const SiftPointD *__restrict__ rows, int n, MatchResult *__restrict__ out)
 {
@@ -556,29 +584,37 @@ extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_row
   const int nr = c->nranks;
   const long long n2 = (long long)shard_count * nr;
   MG_CHECK(n2 < (1ll << 31));
-  // 1. replicate set 2: all-gather of the record shards (576 B x shard_count per rank; 57.6 MB at 100k).  With more than
-  //    one rank it runs on the communication stream while the context stream already sweeps the super-tiles that lie
-  //    entirely inside this rank's OWN shard (read from d_shard2 where it is); the rest of the columns follow behind the
+  // 1. replicate set 2: the shard is packed into 528-byte match columns (descriptor + position: all the sweep reads of a
+  //    record) at its own place in d_set2_all, then all-gathered in place (52.8 MB at 100 k; r03 shipped the 576-byte
+  //    records).  With more than one rank the exchange runs on the communication stream while the context stream already
+  //    sweeps the super-tiles that lie entirely inside this rank's OWN shard; the rest of the columns follow behind the
   //    all-gather's event.  Same result bits as one sweep (launch_match_split).
   const long long own_begin = (long long)c->rank * shard_count, own_end = own_begin + shard_count;
   int own_t0 = (int)((own_begin + 63) / 64), own_t1 = (int)(own_end / 64);
   const bool split = nr > 1 && shard_count && row_count && own_t1 > own_t0 && !getenv("MISIFT_MATCH_NO_OVERLAP");
   hipEvent_t gathered = nullptr;
+  char *cols_all = (char *)d_set2_all;
   if (shard_count) {
+    char *mine = cols_all + (size_t)own_begin * MISIFT_MATCH_COLUMN_BYTES;
+    hipLaunchKernelGGL(pack_match_columns_kernel, dim3((unsigned)(((size_t)shard_count * 33 + 255) / 256)), dim3(256), 0,
+                       ctx->stream, (const SiftPointD *)d_shard2, shard_count, reinterpret_cast<float4 *>(mine));
+    HIP_TRY(hipGetLastError());
     if (split) {
       if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(c->ev_fork, ctx->stream));  // the shard is written, d_set2_all's previous readers are done
+      HIP_TRY(hipEventRecord(c->ev_fork, ctx->stream));  // the columns are packed, d_set2_all's previous readers are done
       HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
     }
     hipStream_t ag_stream = split ? c->stream : ctx->stream;
     if (split) {
       // the own-shard sweep is enqueued BEFORE the exchange is posted (the loopback transport blocks the host in it)
-      int rc = launch_match_split(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2,
-                                  (const SiftPointD *)d_shard2 - own_begin, own_t0, own_t1, nullptr, MATCH_PHASE_OWN);
+      int rc = launch_match_split(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)cols_all, (int)n2,
+                                  (const SiftPointD *)cols_all, own_t0, own_t1, nullptr, MATCH_PHASE_OWN, 1);
       if (rc) return rc;
     }
-    int rc = c->tp->allgather(c, d_shard2, d_set2_all, (size_t)shard_count * sizeof(SiftPointD), ag_stream);
+    int rc = c->tp->allgather(c, mine, cols_all, (size_t)shard_count * MISIFT_MATCH_COLUMN_BYTES, ag_stream);
     if (rc) return rc;
+    c->wire_bytes += (unsigned long long)(nr - 1) * shard_count * MISIFT_MATCH_COLUMN_BYTES;
+    c->sent_bytes += (unsigned long long)(nr - 1) * shard_count * MISIFT_MATCH_COLUMN_BYTES;
     if (split) {
       if (!c->ev_gathered) HIP_TRY(hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
       HIP_TRY(hipEventRecord(c->ev_gathered, c->stream));
@@ -587,9 +623,9 @@ extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_row
   }
   // 2. this rank's rows against (the rest of) set 2 (fp32 MFMA sweep, same kernel as misift_match) and the merge
   if (row_count && n2) {
-    int rc = split ? launch_match_split(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2,
-                                        (const SiftPointD *)d_shard2 - own_begin, own_t0, own_t1, gathered, MATCH_PHASE_REST)
-                   : launch_match(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)d_set2_all, (int)n2);
+    int rc = launch_match_split(ctx, (SiftPointD *)d_rows1, 0, row_count, (const SiftPointD *)cols_all, (int)n2,
+                                (const SiftPointD *)cols_all, split ? own_t0 : 0, split ? own_t1 : 0, gathered,
+                                split ? MATCH_PHASE_REST : MATCH_PHASE_ALL, 1);
     if (rc) return rc;
   }
   // 3. results: 12 B per row, all-gathered so every rank holds the whole answer (row blocks in rank order)
@@ -601,6 +637,8 @@ extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_row
     HIP_TRY(hipGetLastError());
     int rc = c->tp->allgather(c, mine, all, (size_t)row_count * sizeof(MatchResult), ctx->stream);
     if (rc) return rc;
+    c->wire_bytes += (unsigned long long)(nr - 1) * row_count * sizeof(MatchResult);
+    c->sent_bytes += (unsigned long long)(nr - 1) * row_count * sizeof(MatchResult);
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));         // matching.cu:1191: MatchSiftData returns with the results in place
   return MISIFT_OK;

@@ -367,14 +367,20 @@ int misift_gather_complete(misift_comm *comm, int slot, int root, int *h_all_cou
  * waits for the exchange itself), 0 while its kernels are still running.  Lets a caller poll instead of parking a
  * thread in misift_gather_complete. */
 int misift_gather_test(misift_comm *comm, int slot, int *ready);
+/* Payload bytes this rank has received / sent over the links since the communicator was created (either may be NULL). */
+int misift_comm_wire_bytes(misift_comm *comm, unsigned long long *received, unsigned long long *sent);
 
 /* BASELINE config 5 — MatchSiftData (matching.cu:1090-1206) with set 1 split into row blocks, one per rank.
  * d_rows1: this rank's row block (row_count records, updated in place like misift_match); d_shard2: this rank's
  * shard of set 2 (shard_count records; row_count and shard_count must be equal on all ranks — pad the last block).
- * Steps: all-gather of the set-2 shards into d_set2_all (nranks*shard_count records, rank order), the fp32-MFMA
- * sweep of the rank's rows over all of it, then the all-gather of the 12-byte results {float score, float
- * ambiguity, int match} of every row into d_results_all (nranks*row_count entries, may be NULL).  Match indices
- * refer to the gathered set 2.  Returns with everything in place (matching.cu:1191). */
+ * Steps: the shard is packed into MATCH COLUMNS — what the sweep reads of a record and nothing else:
+ * MISIFT_MATCH_COLUMN_BYTES = 528 = descriptor[128], xpos, ypos, 2 reserved words (r04: 8 % less on the wire than the
+ * 576-byte records r03 shipped) — and all-gathered into d_set2_all (nranks*shard_count columns, rank order; a buffer
+ * sized for that many RECORDS is more than enough), then the fp32-MFMA sweep of the rank's rows over all of it, then
+ * the all-gather of the 12-byte results {float score, float ambiguity, int match} of every row into d_results_all
+ * (nranks*row_count entries, may be NULL).  Match indices refer to the gathered set 2.  Returns with everything in
+ * place (matching.cu:1191). */
+#define MISIFT_MATCH_COLUMN_BYTES 528
 int misift_match_sharded(misift_ctx *ctx, misift_comm *comm, void *d_rows1, int row_count, const void *d_shard2,
                          int shard_count, void *d_set2_all, void *d_results_all);
 

@@ -84,6 +84,19 @@ def laplace(base, num_octaves, octave, flavour="off"):
     return out
 
 
+def findpoints(dog, thresh, subsampling=1.0, lowest_scale=0.0, max_pts=32768, edge_limit=10.0, octave=1, flavour="off"):
+    """The reference's FindPointsMulti on a stack of 7 DoG planes [7, h, w]: (records, detection counter — not clamped)."""
+    dog = _f32(dog)
+    assert dog.ndim == 3 and dog.shape[0] == 7
+    _, h, w = dog.shape
+    pts = np.zeros(max_pts, POINT_DTYPE)
+    L = lib(flavour)
+    L.refemul_findpoints.restype = C.c_int
+    n = L.refemul_findpoints(_p(dog), w, h, C.c_float(thresh), C.c_float(edge_limit), C.c_float(1.0 / 5),
+                             C.c_float(lowest_scale), C.c_float(subsampling), octave, max_pts, _p(pts))
+    return pts, int(n)
+
+
 def laplace_taps(num_octaves, flavour="off"):
     k = np.zeros(8 * 12 * 16, np.float32)
     lib(flavour).refemul_laplace_taps(num_octaves, _p(k))

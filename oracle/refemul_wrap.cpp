@@ -5,12 +5,14 @@
 //   ExtractSift           cudaSiftH.cu:72-144      LowPass      cudaSiftH.cu:406-435
 //   ScaleDown             cudaSiftH.cu:308-338     LaplaceMulti cudaSiftH.cu:460-487 (+ PrepareLaplaceKernels :439-458)
 //   MatchSiftData         matching.cu:1090-1206    FindHomography matching.cu:1000-1087
+//   FindPointsMulti       cudaSiftH.cu:489-514
 #include "cudaImage.h"
 #include "cudaSift.h"
 #include "cudaSiftD.h"
 #include "cudaSiftH.h"
 
 extern unsigned int d_PointCounter[8 * 2 + 1];   // cudaSiftD.cu:14
+extern int d_MaxNumPoints;                       // cudaSiftD.cu:13
 extern float d_LaplaceKernel[8 * 12 * 16];       // cudaSiftD.cu:17
 
 namespace {
@@ -101,6 +103,36 @@ void refemul_laplace(const float *image, int w, int h, int octave, int numOctave
 }
 
 void refemul_laplace_taps(int numOctaves, float *kernel /* 8*12*16 */) { PrepareLaplaceKernels(numOctaves, 0.0f, kernel); }
+
+// FindPointsMulti (cudaSiftH.cu:489-514 -> FindPointsMultiNew, cudaSiftD.cu:1292-1431) on a caller-supplied stack of 7
+// DoG planes [7][h][w]: the detections of ONE octave appended from slot 0.  Returns the detection counter
+// d_PointCounter[2*octave] (NOT clamped to maxPts); `out` receives min(count, maxPts) records.
+int refemul_findpoints(const float *dog7, int w, int h, float thresh, float edgeLimit, float factor, float lowestScale,
+                       float subsampling, int octave, int maxPts, SiftPoint *out)
+{
+  SiftData data;
+  InitSiftData(data, maxPts, false, true);
+  memset(data.d_data, 0, sizeof(SiftPoint) * (size_t)maxPts);
+  const int p = iAlignUp(w, 128);
+  float *mem = NULL;
+  cudaMalloc((void **)&mem, sizeof(float) * (size_t)p * h * 8);
+  memset(mem, 0, sizeof(float) * (size_t)p * h * 8);
+  CudaImage planes[8];
+  for (int i = 0; i < 7; i++) {
+    planes[i].Allocate(w, h, p, false, mem + (size_t)i * p * h);
+    for (int y = 0; y < h; y++) memcpy(planes[i].d_data + (size_t)y * p, dog7 + ((size_t)i * h + y) * w, sizeof(float) * (size_t)w);
+  }
+  memset(d_PointCounter, 0, sizeof(d_PointCounter));             // cudaSiftH.cu:75-78
+  cudaMemcpyToSymbol(d_MaxNumPoints, &maxPts, sizeof(int));
+  FindPointsMulti(planes, data, thresh, edgeLimit, factor, lowestScale, subsampling, octave);
+  cudaDeviceSynchronize();
+  const unsigned int count = d_PointCounter[2 * octave];
+  const unsigned int n = count < (unsigned)maxPts ? count : (unsigned)maxPts;
+  memcpy(out, data.d_data, sizeof(SiftPoint) * (size_t)n);
+  cudaFree(mem);
+  FreeSiftData(data);
+  return (int)count;
+}
 
 // MatchSiftData on two host arrays; the five result fields land in pts1 (matching.cu:1195-1199).
 double refemul_match(SiftPoint *pts1, int n1, const SiftPoint *pts2, int n2)

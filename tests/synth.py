@@ -71,3 +71,14 @@ def synth_matches(n, inlier_frac=0.6, seed=0, width=1920, height=1080, noise=0.7
     pts["ambiguity"] = np.where(inl, rng.uniform(0.3, 0.99, n), rng.uniform(0.6, 1.0, n)).astype(np.float32)
     pts["match"] = rng.integers(0, max(n, 1), n)
     return pts, H.astype(np.float32), inl
+
+
+def dense_extrema_dog(w=128, h=64, height=10.0):
+    """A stack of 7 DoG planes [7, h, w] with MORE scale-space maxima per 30x8 block than the reference keeps: plane 3
+    holds isolated peaks on a (2, 3)-pixel lattice (1/6 of the pixels, ~40 per block), everything else is zero, so every
+    lattice point is a strict 26-neighbour maximum that passes the edge test (tr^2 = 4 det / ... < 10 det).
+    Returns (dog, lattice ys, lattice xs)."""
+    dog = np.zeros((7, h, w), np.float32)
+    ys, xs = np.meshgrid(np.arange(2, h - 2, 3), np.arange(2, w - 2, 2), indexing="ij")
+    dog[3, ys, xs] = height
+    return dog, ys.ravel(), xs.ravel()

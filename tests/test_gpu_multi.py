@@ -76,7 +76,7 @@ def _rank_body(capi, rank, world, uid, frames_of, mp, out, errs):
         res = c.zeros(12 * n1)
         comm.match_sharded(d1.ptr, rows, d2.ptr, shard, all2.ptr, res.ptr)
         out[rank] = dict(results=results, rows=c.download(d1, (rows,), capi.POINT_DTYPE),
-                         res=c.download(res, (n1,), capi.RESULT_DTYPE), set2=c.download(all2, (n2,), capi.POINT_DTYPE),
+                         res=c.download(res, (n1,), capi.RESULT_DTYPE), set2=c.download(all2, (n2,), capi.COLUMN_DTYPE),
                          p1=p1, p2=p2)
         comm.close()
         c.close()
@@ -106,7 +106,8 @@ def _check(capi, ctx, world, out, frames_of, mp):
     ref = ctx.match(p1, len(p1), p2, len(p2))
     rows = len(p1) // world
     for r in range(world):
-        assert np.array_equal(out[r]["set2"]["data"], p2["data"])
+        assert np.array_equal(out[r]["set2"]["data"], p2["data"])          # the gathered set 2: 528-byte match columns
+        assert np.array_equal(out[r]["set2"]["xpos"], p2["xpos"]) and np.array_equal(out[r]["set2"]["ypos"], p2["ypos"])
         blk = out[r]["rows"]
         for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
             assert np.array_equal(blk[f], ref[f][r * rows:(r + 1) * rows]), (r, f)
@@ -180,12 +181,13 @@ def _loop_rank(capi, rank, world, lw, plan, out, errs):
             return cnt, packed
 
         def complete(k):
-            recv = c.zeros(576 * cap) if rank == root else None
+            rt = (k % world) if plan.get("rotate") else root        # rotating root: batch k is gathered on rank k % world
+            recv = c.zeros(576 * cap) if rank == rt else None
             polls = 0
             while not comm.gather_test(k % nslot):          # the non-blocking companion: poll instead of parking
                 polls += 1
-            counts, offs = comm.gather_complete(k % nslot, B, root, recv.ptr if recv else None, cap)
-            recs = c.download(recv, (int(offs[-1]),), capi.POINT_DTYPE) if rank == root else None
+            counts, offs = comm.gather_complete(k % nslot, B, rt, recv.ptr if recv else None, cap)
+            recs = c.download(recv, (int(offs[-1]),), capi.POINT_DTYPE) if rank == rt else None
             results.append((k, counts, offs, recs))
 
         for k in range(nb):                                  # post(k) ... complete(k-1): two batches in flight
@@ -195,6 +197,7 @@ def _loop_rank(capi, rank, world, lw, plan, out, errs):
                 complete(k - 1)
         complete(nb - 1)
         comm.barrier()
+        wire_after_gathers = comm.wire_bytes()
         # too little room on the root: every rank takes the same decision, nothing is exchanged, nobody hangs
         cnt, packed = extract(0)
         comm.gather_post(0, cnt.ptr, B, packed.ptr)
@@ -215,8 +218,8 @@ def _loop_rank(capi, rank, world, lw, plan, out, errs):
         res = c.zeros(12 * n1)
         comm.match_sharded(d1.ptr, rows, d2.ptr, shard, all2.ptr, res.ptr)
         out[rank] = dict(results=results, rows=c.download(d1, (rows,), capi.POINT_DTYPE),
-                         res=c.download(res, (n1,), capi.RESULT_DTYPE), set2=c.download(all2, (n2,), capi.POINT_DTYPE),
-                         p1=p1, p2=p2)
+                         res=c.download(res, (n1,), capi.RESULT_DTYPE), set2=c.download(all2, (n2,), capi.COLUMN_DTYPE),
+                         p1=p1, p2=p2, wire=wire_after_gathers)
         comm.close()
         c.close()
     except Exception as e:                         # noqa: BLE001 — reported by the main thread
@@ -242,7 +245,11 @@ def _run_loopback(capi, world, plan):
 def _check_loopback(capi, ctx, world, plan, out):
     root, mp = plan["root"], plan["mp"]
     n_overflowed = 0
-    for k, counts, offs, recs in out[root]["results"]:
+    for k in range(plan["nbatches"]):
+        rt = (k % world) if plan.get("rotate") else root
+        k_, counts, offs, recs = out[rt]["results"][k]
+        assert k_ == k and recs is not None
+        assert all(out[r]["results"][k][3] is None for r in range(world) if r != rt)      # only that batch's root holds records
         assert counts.shape[0] == world and offs[0] == 0
         for r in range(world):
             th = plan["thresh"](r, k)
@@ -265,7 +272,9 @@ def _check_loopback(capi, ctx, world, plan, out):
     ref = ctx.match(p1, len(p1), p2, len(p2))
     rows = plan["rows"]
     for r in range(world):
-        assert np.array_equal(out[r]["set2"].tobytes(), p2.tobytes())        # set 2 replicated in rank order
+        # set 2 replicated in rank order as 528-byte match columns (descriptor + position: what the sweep reads)
+        assert np.array_equal(out[r]["set2"]["data"], p2["data"])
+        assert np.array_equal(out[r]["set2"]["xpos"], p2["xpos"]) and np.array_equal(out[r]["set2"]["ypos"], p2["ypos"])
         blk = out[r]["rows"]
         for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
             assert np.array_equal(blk[f], ref[f][r * rows:(r + 1) * rows]), (r, f)
@@ -303,6 +312,22 @@ def test_loopback_world_gather_and_match_sharded(ctx, world, root, empty, overfl
     if overflow is not None:
         assert nov > 0
     record("loopback_world_%d" % world, root=root, empty_rank=empty, overflow_rank=overflow, overflowed_frames=nov, ok=True)
+
+
+def test_loopback_world_rotating_gather_root(ctx):
+    """The gather root moves with the batch (root = k % world; bench.py --gather-root rotate): one fixed root would take
+    7 senders' records of EVERY batch over its own xGMI links.  Same records as a single-GPU batch."""
+    from cudasift_amd import capi
+    world = 4
+    plan = _plan(world, 0, 2, None)
+    plan["rotate"] = True
+    plan["nbatches"] = 5                                   # batches 0..4: roots 0, 1, 2, 3, 0
+    out = _run_loopback(capi, world, plan)
+    _check_loopback(capi, ctx, world, plan, out)
+    # bytes: a rank receives records only for the batches it is the root of
+    recv = [out[r]["wire"][0] for r in range(world)]
+    assert recv[0] > recv[1] and min(recv) > 0, recv       # rank 0 was the root twice
+    record("loopback_world_rotating_root", received_bytes=recv, ok=True)
 
 
 def test_loopback_world_reports_a_missing_rank(ctx):
@@ -344,7 +369,7 @@ def _match_rank(capi, rank, world, lw, rows, shard, out, errs):
         prof = c.profile_read()
         c.profile_enable(False)
         out[rank] = dict(rows=c.download(d1, (rows,), capi.POINT_DTYPE), res=c.download(res, (n1,), capi.RESULT_DTYPE),
-                         p1=p1, p2=p2, sweeps=prof["match_mfma"]["calls"])
+                         p1=p1, p2=p2, sweeps=prof["match_mfma"]["calls"], wire=comm.wire_bytes())
         comm.close()
         c.close()
     except Exception as e:                         # noqa: BLE001
@@ -388,4 +413,7 @@ def test_loopback_match_sharded_overlaps_the_exchange(ctx, world, rows, shard, o
         lo, hi = (r * shard + 63) // 64, ((r + 1) * shard) // 64
         two = overlap and hi > lo
         assert out[r]["sweeps"] == (4 if two else 2), (r, out[r]["sweeps"])      # two calls: 2 launches each when split
+        # bytes on the wire (r04): 528-byte match columns, not 576-byte records, + the 12-byte results; two calls
+        per_call = (world - 1) * (shard * capi.COLUMN_DTYPE.itemsize + rows * 12)
+        assert out[r]["wire"] == (2 * per_call, 2 * per_call), (r, out[r]["wire"], per_call)
     record("loopback_match_overlap_%d_%d_%d" % (world, shard, overlap), ok=True)

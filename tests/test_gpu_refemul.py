@@ -114,3 +114,25 @@ def test_match_cu_self_check_at_its_own_size(ctx):
     rows = np.arange(0, n, 257)
     so, io = orc.match_argmax(a.reshape(n, 128)[rows], b.reshape(n, 128))
     assert np.array_equal(got["score"][rows], so) and np.array_equal(got["match"][rows], io)
+
+
+def test_hip_keeps_what_the_reference_cap_drops(ctx):
+    """The 32-extrema-per-block cap of FindPointsMultiNew (cudaSiftD.cu:1369-1375): the HIP path, like the oracle, keeps
+    every extremum of the dense synthetic DoG stack; the emulated reference (where it is built) keeps sum(min(n, 32))."""
+    from synth import dense_extrema_dog
+    from oracle import pyoracle as orc
+    dog, ys, xs = dense_extrema_dog()
+    g_pts, g_n = ctx.findpoints(dog, 1.0)
+    o_pts, o_n = orc.findpoints(dog, 1.0)
+    assert g_n == o_n == len(ys), (g_n, o_n, len(ys))
+    key = lambda p, n: sorted(zip(p["xpos"][:n].tolist(), p["ypos"][:n].tolist(), p["scale"][:n].tolist(), p["sharpness"][:n].tolist()))
+    assert key(g_pts, g_n) == key(o_pts, o_n)
+    counts = {"lattice": int(len(ys)), "hip": int(g_n), "oracle": int(o_n)}
+    try:
+        from oracle import pyrefemul as ref
+        if ref.available("fast"):
+            counts["reference_emulated"] = ref.findpoints(dog, 1.0, flavour="fast")[1]
+            assert counts["reference_emulated"] == 1044
+    except Exception:                                      # oracle/_ref not built on this box: the CPU suite pins it
+        pass
+    record("reference_32_per_block_cap", **counts)

@@ -133,6 +133,12 @@ def compare_points(a, b, name, record=None, outlier_budget=0.0):
     return stats
 
 
+def tail_budget(n, rate):
+    """Largest count of outliers accepted among n records when they occur at `rate`: mean + 3 sigma (Poisson) + 1."""
+    mu = rate * n
+    return int(mu + 3.0 * np.sqrt(mu) + 1.0)
+
+
 # ------------------------------------------------------------------ against the reference's own kernels
 # (oracle/_ref/libcudasift_refemul_*.so = the reference's cudaSiftH.cu/cudaSiftD.cu/matching.cu on the CPU SIMT
 # emulator, or the vectors it produced: tests/golden/refemul_golden.npz)
@@ -183,8 +189,14 @@ def compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, name, strict, recor
         # descriptors: libm sincos/exp vs the written-out ones move a sample coordinate in its last bit; through the
         # 8-bit texture weights that is <= 1/256 of a local pixel difference in a few elements, and
         # the reference's own angle-bin wrap (angi = 8 <-> 0 at dy = +-0, B#6) can move one vote between cells
-        assert st["desc_over_1e-4"] <= 0.012 * total and st["desc_over_1e-3"] <= max(2, 0.002 * total), (name, st)
-        assert st["desc_min_cos"] >= 0.995, (name, st)
+        # Budget = the MEASURED tail (r03: 544 385 records on the MI355X vs the emulated reference, 0.71 % over 1e-4 and
+        # 24 = 0.0044 % over 1e-3, min cos 0.9997; profiles/r03_hip_vs_refemul.json) as a rate, plus three standard
+        # deviations of a count at that rate — a 1146-keypoint case legitimately shows 13 (1.1 %), 613 k records may
+        # show 0.84 %.  r03's flat 1.2 % / 0.2 % / 0.995 was 1.7x / 50x looser than the measurement: a regression could
+        # have hidden in it.
+        b4, b3 = tail_budget(total, 0.008), tail_budget(total, 1e-4)
+        assert st["desc_over_1e-4"] <= b4 and st["desc_over_1e-3"] <= b3, (name, st, b4, b3)
+        assert st["desc_min_cos"] >= 0.999, (name, st)
     else:
         assert st["orientation_flips"] <= max(2, 0.002 * total), (name, st)
     if nan_guards is not None:
