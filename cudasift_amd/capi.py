@@ -100,6 +100,7 @@ SIGNATURES = {
     "misift_gather_complete": (_i, [_vp, _i, _i, _vp, _vp, _sz, _vp]),
     "misift_match_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "misift_comm_wire_bytes": (_i, [_vp, _vp, _vp]),
+    "misift_comm_create_host": (_i, [_i, _i, _vp, _vp]),
     "misift_find_homography": (_i, [_vp, _vp, _i, _fp, _ip, _i, _f, _f, _f]),
     "misift_extract_batch_packed_async": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "misift_lowpass_scaledown": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _f, _vp, _i]),
@@ -620,6 +621,52 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+class _HostTransport(C.Structure):
+    """misift_host_transport (include/misift.h)."""
+    AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    P2P = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+    END = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    _fields_ = [("user", C.c_void_p), ("allgather", AG), ("send", P2P), ("recv", P2P), ("group_end", END)]
+
+
+class HostComm(Comm):
+    """A HOST communicator (misift_comm_create_host): no device; counts / packed records / receive buffers are host
+    memory (numpy arrays), the exchange primitives are Python callables — tests/test_dist_cpu.py implements them with
+    torch.distributed (gloo), so the gather logic of multigpu.hip itself runs on a machine without GPUs.
+
+    allgather(send_ptr, recv_ptr, nbytes), send(ptr, nbytes, peer), recv(ptr, nbytes, peer), group_end(): raise on error."""
+
+    def __init__(self, nranks, rank, allgather, send, recv, group_end):     # noqa: super().__init__ not called on purpose
+        def guard(fn):
+            def call(_user, *a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception:                    # noqa: BLE001 — reported through the C-ABI's error path
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return call
+        self._cb = _HostTransport(None, _HostTransport.AG(guard(allgather)), _HostTransport.P2P(guard(send)),
+                                  _HostTransport.P2P(guard(recv)), _HostTransport.END(guard(group_end)))
+        h = C.c_void_p()
+        check(lib().misift_comm_create_host(nranks, rank, C.byref(self._cb), C.byref(h)), "misift_comm_create_host")
+        self.h = h
+        self.ctx = None
+        self.rank, self.size = lib().misift_comm_rank(h), lib().misift_comm_size(h)
+
+    def gather_post(self, slot, counts, nframes, packed, ctx=None):
+        """counts: int32 numpy [nframes]; packed: uint8 numpy (both must stay alive until gather_complete)."""
+        check(lib().misift_gather_post(None, self.h, slot, counts.ctypes.data, nframes, packed.ctypes.data), "misift_gather_post")
+
+    def gather_complete(self, slot, nframes, root=0, recv=None, capacity_records=0):
+        counts = np.zeros((self.size, nframes), np.int32)
+        offs = (C.c_size_t * (self.size + 1))()
+        check(lib().misift_gather_complete(self.h, slot, root, counts.ctypes.data, recv.ctypes.data if recv is not None else None,
+                                           capacity_records, offs), "misift_gather_complete")
+        return counts, np.array(list(offs), np.int64)
 
 
 class PinnedArray:

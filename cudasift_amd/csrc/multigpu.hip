@@ -145,7 +145,52 @@ struct misift_comm {
   std::vector<GatherSlot> slots;
   hipEvent_t ev_fork, ev_gathered;   // sharded matcher: inputs ready on the context stream / set 2 complete on the communication stream
   unsigned long long wire_bytes = 0, sent_bytes = 0;   // bytes this rank has RECEIVED / SENT over the links (misift_comm_wire_bytes)
+  // HOST communicator (misift_comm_create_host): no device, no context — every buffer is host memory, the runtime calls
+  // below become memcpy / malloc / nothing, the five primitives are the caller's callbacks.  The gather logic above the
+  // transport is the same code either way, which is the point: the CPU-only suite runs IT over gloo, not a mirror.
+  bool host = false;
+  misift_host_transport hcb = {};
 };
+
+// what the exchange code needs from the runtime besides the transport, for device and host communicators alike
+static int mg_set_device(misift_comm *c)
+{
+  if (!c->host) HIP_TRY(hipSetDevice(c->ctx->device));
+  return MISIFT_OK;
+}
+static int mg_copy(misift_comm *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
+{
+  if (c->host) { if (bytes) memcpy(dst, src, bytes); return MISIFT_OK; }
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, st));
+  return MISIFT_OK;
+}
+static int mg_sync(misift_comm *c, hipStream_t st)
+{
+  if (!c->host) HIP_TRY(hipStreamSynchronize(st));
+  return MISIFT_OK;
+}
+static int mg_alloc_counts(misift_comm *c, size_t ints)
+{
+  if (c->host) {
+    c->d_all_counts = (int *)calloc(ints, sizeof(int));
+    c->h_all_counts = (int *)calloc(ints, sizeof(int));
+    if (!c->d_all_counts || !c->h_all_counts) { misift_set_error("out of host memory"); return MISIFT_ENOMEM; }
+    return MISIFT_OK;
+  }
+  if (!c->d_all_counts) HIP_TRY(hipMalloc((void **)&c->d_all_counts, sizeof(int) * ints));
+  if (!c->h_all_counts) HIP_TRY(hipHostMalloc((void **)&c->h_all_counts, sizeof(int) * ints, hipHostMallocDefault));
+  return MISIFT_OK;
+}
+static int mg_free_counts(misift_comm *c)
+{
+  if (c->host) { free(c->d_all_counts); free(c->h_all_counts); }
+  else {
+    if (c->d_all_counts) HIP_TRY(hipFree(c->d_all_counts));
+    if (c->h_all_counts) HIP_TRY(hipHostFree(c->h_all_counts));
+  }
+  c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0;
+  return MISIFT_OK;
+}
 
 // ---- RCCL transport
 static int rccl_allgather(misift_comm *c, const void *send, void *recv, size_t bytes, hipStream_t st)
@@ -166,6 +211,35 @@ static int rccl_recv(misift_comm *c, void *buf, size_t bytes, int peer, hipStrea
 }
 static int rccl_group_end(misift_comm *, hipStream_t) { NCCL_TRY(g_rccl.GroupEnd()); return MISIFT_OK; }
 static const Transport kRcclTransport = {rccl_allgather, rccl_group_start, rccl_send, rccl_recv, rccl_group_end};
+
+// ---- host transport: the caller's callbacks on host memory (tests: torch.distributed / gloo)
+#define HCB_TRY(expr, what)                                                                  \
+  do {                                                                                       \
+    const int r_ = (expr);                                                                   \
+    if (r_) { misift_set_error("host transport: %s failed with %d", what, r_); return MISIFT_EHIP; } \
+  } while (0)
+static int host_allgather(misift_comm *c, const void *send, void *recv, size_t bytes, hipStream_t)
+{
+  HCB_TRY(c->hcb.allgather(c->hcb.user, send, recv, bytes), "all-gather");
+  return MISIFT_OK;
+}
+static int host_group_start(misift_comm *) { return MISIFT_OK; }
+static int host_send(misift_comm *c, const void *buf, size_t bytes, int peer, hipStream_t)
+{
+  HCB_TRY(c->hcb.send(c->hcb.user, buf, bytes, peer), "send");
+  return MISIFT_OK;
+}
+static int host_recv(misift_comm *c, void *buf, size_t bytes, int peer, hipStream_t)
+{
+  HCB_TRY(c->hcb.recv(c->hcb.user, buf, bytes, peer), "recv");
+  return MISIFT_OK;
+}
+static int host_group_end(misift_comm *c, hipStream_t)
+{
+  HCB_TRY(c->hcb.group_end(c->hcb.user), "group end");
+  return MISIFT_OK;
+}
+static const Transport kHostTransport = {host_allgather, host_group_start, host_send, host_recv, host_group_end};
 
 // ---- loopback transport: a rendezvous object shared by the N communicators of one process
 struct misift_loopback_world {
@@ -353,6 +427,7 @@ static int comm_finish_create(misift_ctx *ctx, ncclComm_t nc, bool owns, misift_
 extern "C" void misift_comm_destroy(misift_comm *c)
 {
   if (!c) return;
+  if (c->host) { mg_free_counts(c); delete c; return; }
   if (c->ctx) hipSetDevice(c->ctx->device);
   if (c->stream) { hipStreamSynchronize(c->stream); }
   if (c->nccl && c->owns_nccl && g_rccl_state > 0) g_rccl.CommDestroy(c->nccl);
@@ -413,39 +488,57 @@ extern "C" int misift_comm_create_loopback(misift_ctx *ctx, misift_loopback_worl
   return rc;
 }
 
+extern "C" int misift_comm_create_host(int nranks, int rank, const misift_host_transport *t, misift_comm **out)
+{
+  MG_CHECK(out && t && t->allgather && t->send && t->recv && t->group_end && nranks >= 1 && rank >= 0 && rank < nranks);
+  misift_comm *c = new misift_comm();
+  c->ctx = nullptr; c->nccl = nullptr; c->owns_nccl = false; c->world = nullptr;
+  c->tp = &kHostTransport;
+  c->rank = rank; c->nranks = nranks; c->stream = nullptr;
+  c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0; c->ev_gathered = nullptr; c->ev_fork = nullptr;
+  c->slots.resize(MISIFT_GATHER_SLOTS);
+  for (GatherSlot &s : c->slots) { memset(&s, 0, sizeof(s)); }
+  c->host = true;
+  c->hcb = *t;
+  *out = c;
+  return MISIFT_OK;
+}
+
 extern "C" int misift_comm_rank(const misift_comm *c) { return c ? c->rank : -1; }
 extern "C" int misift_comm_size(const misift_comm *c) { return c ? c->nranks : 0; }
 
 extern "C" int misift_comm_barrier(misift_comm *c)
 {
   MG_CHECK(c != nullptr);
-  HIP_TRY(hipSetDevice(c->ctx->device));
+  int rc = mg_set_device(c);
+  if (rc) return rc;
   // an all-gather of one int per rank on the communication stream, then a host wait: every rank has arrived
   if (c->cap_frames < 1) {                              // (a failed attempt leaves what it did allocate for the next one)
-    if (!c->d_all_counts) HIP_TRY(hipMalloc((void **)&c->d_all_counts, sizeof(int) * (size_t)c->nranks * 64));
-    if (!c->h_all_counts)
-      HIP_TRY(hipHostMalloc((void **)&c->h_all_counts, sizeof(int) * (size_t)c->nranks * 64, hipHostMallocDefault));
-    HIP_TRY(hipMemsetAsync(c->d_all_counts, 0, sizeof(int) * (size_t)c->nranks * 64, c->stream));
+    rc = mg_alloc_counts(c, (size_t)c->nranks * 64);
+    if (rc) return rc;
+    if (!c->host) HIP_TRY(hipMemsetAsync(c->d_all_counts, 0, sizeof(int) * (size_t)c->nranks * 64, c->stream));
     c->cap_frames = 64;
   }
-  int rc = c->tp->allgather(c, c->d_all_counts + c->rank, c->d_all_counts, sizeof(int), c->stream);
+  rc = c->tp->allgather(c, c->d_all_counts + c->rank, c->d_all_counts, sizeof(int), c->stream);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return MISIFT_OK;
+  return mg_sync(c, c->stream);
 }
 
 // ------------------------------------------------------------------ config 4: gather of SiftData
 extern "C" int misift_gather_post(misift_ctx *ctx, misift_comm *c, int slot, const int *d_counts, int nframes,
                                   const void *d_packed)
 {
-  MG_CHECK(ctx && c && c->ctx->device == ctx->device && d_counts && d_packed && nframes >= 1);
+  MG_CHECK(c && d_counts && d_packed && nframes >= 1);
+  MG_CHECK(c->host || (ctx && c->ctx->device == ctx->device));       // a host communicator has no context: pass NULL
   MG_CHECK(slot >= 0 && slot < (int)c->slots.size());
   GatherSlot &s = c->slots[slot];
   s.d_counts = d_counts; s.d_packed = d_packed; s.nframes = nframes;
-  HIP_TRY(hipSetDevice(ctx->device));
-  // the batch queued last on the context (on its own stream, or on one of its pipelines with batches in flight)
-  // produces these buffers
-  HIP_TRY(hipEventRecord(s.ready, misift_ctx_result_stream(ctx)));
+  if (!c->host) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    // the batch queued last on the context (on its own stream, or on one of its pipelines with batches in flight)
+    // produces these buffers
+    HIP_TRY(hipEventRecord(s.ready, misift_ctx_result_stream(ctx)));
+  }
   s.posted = true;
   return MISIFT_OK;
 }
@@ -458,6 +551,7 @@ extern "C" int misift_gather_test(misift_comm *c, int slot, int *ready)
   MG_CHECK(c && ready && slot >= 0 && slot < (int)c->slots.size());
   GatherSlot &s = c->slots[slot];
   MG_CHECK(s.posted);
+  if (c->host) { *ready = 1; return MISIFT_OK; }
   HIP_TRY(hipSetDevice(c->ctx->device));
   const hipError_t e = hipEventQuery(s.ready);
   if (e == hipSuccess) { *ready = 1; return MISIFT_OK; }
@@ -474,29 +568,29 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
   MG_CHECK(s.posted);
   MG_CHECK(h_all_counts != nullptr);
   MG_CHECK(c->rank != root || c->nranks == 1 || d_recv != nullptr);
-  HIP_TRY(hipSetDevice(c->ctx->device));
+  int rc0 = mg_set_device(c);
+  if (rc0) return rc0;
   const int nf = s.nframes, nr = c->nranks;
   if (nf > c->cap_frames) {
-    if (c->d_all_counts) HIP_TRY(hipFree(c->d_all_counts));
-    if (c->h_all_counts) HIP_TRY(hipHostFree(c->h_all_counts));
-    c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0;
-    HIP_TRY(hipMalloc((void **)&c->d_all_counts, sizeof(int) * (size_t)nr * nf));
-    HIP_TRY(hipHostMalloc((void **)&c->h_all_counts, sizeof(int) * (size_t)nr * nf, hipHostMallocDefault));
+    rc0 = mg_free_counts(c);
+    if (!rc0) rc0 = mg_alloc_counts(c, (size_t)nr * nf);
+    if (rc0) return rc0;
     c->cap_frames = nf;
   }
-  HIP_TRY(hipStreamWaitEvent(c->stream, s.ready, 0));
+  if (!c->host) HIP_TRY(hipStreamWaitEvent(c->stream, s.ready, 0));
   // 1. per-frame counts of every rank (nframes ints per rank; every rank must post the same nframes)
-  if (nr == 1)           // nothing to gather: a plain copy
-    HIP_TRY(hipMemcpyAsync(c->d_all_counts, s.d_counts, sizeof(int) * (size_t)nf, hipMemcpyDeviceToDevice, c->stream));
-  else {
+  if (nr == 1) {         // nothing to gather: a plain copy
+    rc0 = mg_copy(c, c->d_all_counts, s.d_counts, sizeof(int) * (size_t)nf, hipMemcpyDeviceToDevice, c->stream);
+    if (rc0) return rc0;
+  } else {
     int rc = c->tp->allgather(c, s.d_counts, c->d_all_counts, sizeof(int) * (size_t)nf, c->stream);
     if (rc) { s.posted = false; return rc; }
     c->wire_bytes += (unsigned long long)(nr - 1) * nf * sizeof(int);
     c->sent_bytes += (unsigned long long)(nr - 1) * nf * sizeof(int);
   }
-  HIP_TRY(hipMemcpyAsync(c->h_all_counts, c->d_all_counts, sizeof(int) * (size_t)nr * nf, hipMemcpyDeviceToHost,
-                         c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));          // the message sizes must be known on the host (NCCL API)
+  rc0 = mg_copy(c, c->h_all_counts, c->d_all_counts, sizeof(int) * (size_t)nr * nf, hipMemcpyDeviceToHost, c->stream);
+  if (!rc0) rc0 = mg_sync(c, c->stream);             // the message sizes must be known on the host (NCCL API)
+  if (rc0) return rc0;
   memcpy(h_all_counts, c->h_all_counts, sizeof(int) * (size_t)nr * nf);
   std::vector<size_t> nrec((size_t)nr, 0), off((size_t)nr + 1, 0);
   for (int r = 0; r < nr; r++) {
@@ -529,12 +623,14 @@ extern "C" int misift_gather_complete(misift_comm *c, int slot, int root, int *h
   // a failure inside the group must still close it: an open NCCL group swallows every later collective of this thread
   const int rc_end = c->tp->group_end(c, c->stream);
   if (rc || rc_end) { s.posted = false; return rc ? rc : rc_end; }
-  if (c->rank == root && d_recv && nrec[root])
-    HIP_TRY(hipMemcpyAsync((char *)d_recv + off[root] * sizeof(SiftPointD), s.d_packed, nrec[root] * sizeof(SiftPointD),
-                           hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));          // the slot's buffers are free again when this returns
+  if (c->rank == root && d_recv && nrec[root]) {
+    rc = mg_copy(c, (char *)d_recv + off[root] * sizeof(SiftPointD), s.d_packed, nrec[root] * sizeof(SiftPointD),
+                 hipMemcpyDeviceToDevice, c->stream);
+    if (rc) { s.posted = false; return rc; }
+  }
+  rc = mg_sync(c, c->stream);                        // the slot's buffers are free again when this returns
   s.posted = false;
-  return MISIFT_OK;
+  return rc;
 }
 
 // Bytes this rank has received / sent over the links since the communicator was created (payload of the collectives
@@ -577,7 +673,8 @@ __global__ void pack_match_results_kernel(const SiftPointD *__restrict__ rows, i
 extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_rows1, int row_count, const void *d_shard2,
                                     int shard_count, void *d_set2_all, void *d_results_all)
 {
-  MG_CHECK(ctx && c && c->ctx == ctx && row_count >= 0 && shard_count >= 0);
+  MG_CHECK(c && !c->host);                              // the sweep runs on the GPU: device communicators only
+  MG_CHECK(ctx && c->ctx == ctx && row_count >= 0 && shard_count >= 0);
   MG_CHECK(row_count == 0 || d_rows1);
   MG_CHECK(shard_count == 0 || (d_shard2 && d_set2_all));
   HIP_TRY(hipSetDevice(ctx->device));

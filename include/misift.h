@@ -326,6 +326,21 @@ typedef struct misift_comm misift_comm;
 int misift_comm_unique_id(void *id128);
 int misift_comm_create(misift_ctx *ctx, int nranks, int rank, const void *id128, misift_comm **out);
 int misift_comm_adopt(misift_ctx *ctx, void *nccl_comm, misift_comm **out);
+/* HOST communicator: no device and no context — counts, packed records and the receive buffer are HOST memory and the
+ * five primitives of the exchange are the caller's callbacks (return 0 on success; send / recv may only queue, group_end
+ * completes everything queued since the last call).  misift_comm_barrier, misift_gather_post (ctx = NULL),
+ * misift_gather_test and misift_gather_complete run the SAME code above the transport as on RCCL — count staging,
+ * per-rank record counts and offsets, root placement, -1 frames, the collective MISIFT_ENOMEM decision — which is what
+ * the CPU-only suite drives over torch.distributed / gloo (tests/test_dist_cpu.py); misift_match_sharded needs a
+ * device communicator.  Not a performance path. */
+typedef struct misift_host_transport {
+  void *user;
+  int (*allgather)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+  int (*send)(void *user, const void *buf, size_t bytes, int peer);
+  int (*recv)(void *user, void *buf, size_t bytes, int peer);
+  int (*group_end)(void *user);
+} misift_host_transport;
+int misift_comm_create_host(int nranks, int rank, const misift_host_transport *transport, misift_comm **out);
 /* In-process LOOPBACK WORLD ("fake N ranks on one GPU").  The reference has no multi-device code at
  * all (cudaSiftH.cu:19-37 picks one device), so nothing in it corresponds to this; it exists so that every N > 1
  * branch behind misift_gather_* / misift_match_sharded runs on the hardware a developer has: N communicators, one host

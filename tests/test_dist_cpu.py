@@ -1,11 +1,18 @@
-"""Multi-process CPU tests (gloo, world_size 2) of the multi-GPU plumbing in cudasift_amd/dist.py:
-the frame sharding, the variable-length gather of SiftPoint records to rank 0 and the row-block matcher
-split with all-gather of set 2 — the same code path bench.py drives with backend "nccl" (RCCL)."""
+"""Multi-process CPU tests (gloo, world_size 2 / 3) of the multi-GPU exchange.  Since r04 the gather of SiftData is
+libmisift.so's OWN code: a HOST communicator (misift_comm_create_host, include/misift.h) runs misift_gather_post /
+misift_gather_complete — count staging, per-rank record counts and offsets, root placement, the -1 frames, the collective
+ENOMEM decision — on host memory, and the five transport primitives are torch.distributed (gloo) calls made from the
+callbacks below.  (r01-r03 tested a Python mirror of that logic, cudasift_amd/dist.py, which could drift from the C++;
+it is gone.)  The row-block matcher split of BASELINE config 5 is exercised with gloo collectives and the CPU oracle as
+the matcher, through bench.py's own matcher leg."""
+import ctypes as C
 import os
 import socket
 
 import numpy as np
 import pytest
+
+RECORD_BYTES = 576
 
 
 def _free_port():
@@ -16,37 +23,89 @@ def _free_port():
     return p
 
 
+def shard_range(total, rank, world):
+    """Contiguous block partition of `total` units (frames / rows): the first (total % world) ranks get one more."""
+    q, r = divmod(total, world)
+    begin = rank * q + min(rank, r)
+    return begin, begin + q + (1 if rank < r else 0)
+
+
+def gloo_host_comm(capi, dist, torch, rank, world):
+    """capi.HostComm whose primitives are gloo collectives / point-to-point messages on the caller's host buffers."""
+    pending = []
+
+    def view(ptr, nbytes):
+        return torch.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=torch.uint8)
+
+    def allgather(send, recv, nbytes):
+        if nbytes == 0:
+            return
+        outs = [view(recv + r * nbytes, nbytes) for r in range(world)]
+        dist.all_gather(outs, view(send, nbytes).clone())          # (in-place contributions: the source is copied first)
+
+    def send(ptr, nbytes, peer):
+        pending.append(dist.P2POp(dist.isend, view(ptr, nbytes), peer))
+
+    def recv(ptr, nbytes, peer):
+        pending.append(dist.P2POp(dist.irecv, view(ptr, nbytes), peer))
+
+    def group_end():
+        if pending:
+            for w in dist.batch_isend_irecv(list(pending)):
+                w.wait()
+        pending.clear()
+
+    return capi.HostComm(world, rank, allgather, send, recv, group_end)
+
+
 def _worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
-    from cudasift_amd.dist import RECORD_BYTES, gather_sift_records, shard_range, unpack_records
+    from cudasift_amd import capi
     from oracle import pyoracle as orc
     from synth import descriptors_to_points, synth_descriptors
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cpu")
-    # ---- frames shard: every rank owns B frames with different valid counts
-    B, max_pts = 3, 16
-    rng = np.random.default_rng(100 + rank)
-    counts = rng.integers(0, max_pts + 1, size=B).astype(np.int32)
-    counts[rank % B] = 0                                   # an empty frame
-    pts = torch.from_numpy(rng.integers(0, 255, size=(B, max_pts * RECORD_BYTES), dtype=np.uint8))
-    all_counts, bufs = gather_sift_records(dist, torch, pts, counts, rank, world, dev)
-    ok = True
-    if rank == 0:
-        assert bufs is not None and len(bufs) == world
-        for r in range(world):
-            rr = np.random.default_rng(100 + r)
-            c = rr.integers(0, max_pts + 1, size=B).astype(np.int32)
-            c[r % B] = 0
-            ref = rr.integers(0, 255, size=(B, max_pts * RECORD_BYTES), dtype=np.uint8)
-            ok &= bool(np.array_equal(all_counts[r], c))
-            frames = unpack_records(bufs[r], all_counts[r])
-            for f in range(B):
-                ok &= bool(np.array_equal(frames[f].numpy().reshape(-1), ref[f, : c[f] * RECORD_BYTES]))
-    else:
-        assert bufs is None
+    comm = gloo_host_comm(capi, dist, torch, rank, world)
+    ok = comm.rank == rank and comm.size == world
+    comm.barrier()
+    # ---- frames shard: every rank owns B frames with different valid counts; gather on root 1 (not 0)
+    B, max_pts, root = 3, 16, world - 1
+
+    def batch(r):
+        rr = np.random.default_rng(100 + r)
+        c = rr.integers(0, max_pts + 1, size=B).astype(np.int32)
+        c[r % B] = 0                                        # an empty frame
+        body = rr.integers(0, 255, size=int(c.sum()) * RECORD_BYTES, dtype=np.uint8)
+        return c, body
+
+    counts, body = batch(rank)
+    packed = np.zeros(B * max_pts * RECORD_BYTES, np.uint8)
+    packed[: body.size] = body
+    cap = world * B * max_pts
+    recv = np.zeros(cap * RECORD_BYTES, np.uint8) if rank == root else None
+    comm.gather_post(0, counts, B, packed)
+    all_counts, offs = comm.gather_complete(0, B, root, recv, cap)
+    for r in range(world):
+        c, b = batch(r)
+        ok &= bool(np.array_equal(all_counts[r], c))
+        ok &= int(offs[r + 1] - offs[r]) == int(c.sum())
+        if rank == root:
+            ok &= bool(np.array_equal(recv[int(offs[r]) * RECORD_BYTES: int(offs[r + 1]) * RECORD_BYTES], b))
+    # too little room on the root: every rank returns ENOMEM, nothing is exchanged, nobody waits
+    comm.gather_post(1, counts, B, packed)
+    try:
+        comm.gather_complete(1, B, root, recv, 1)
+        ok = False
+    except RuntimeError as e:
+        ok &= "room for 1" in str(e)
+    comm.barrier()
+    rx, tx = comm.wire_bytes()
+    mine = int(counts.sum()) * RECORD_BYTES
+    total = sum(int(batch(r)[0].sum()) for r in range(world)) * RECORD_BYTES
+    ok &= tx >= (mine if rank != root else 0) and (rx >= total - mine if rank == root else True)
+    comm.close()
     # ---- matcher: row blocks of set 1, set 2 sharded then all-gathered (BASELINE config 5)
     n1, n2 = 96, 64
     p1 = descriptors_to_points(synth_descriptors(n1, 1), orc.POINT_DTYPE)
@@ -74,7 +133,6 @@ def _worker(rank, world, port, out_dir):
 
 
 def test_shard_range_partitions():
-    from cudasift_amd.dist import shard_range
     for total in (0, 1, 7, 512, 100000):
         for world in (1, 2, 3, 8):
             r = [shard_range(total, k, world) for k in range(world)]
@@ -92,15 +150,16 @@ def test_gather_and_row_block_match_world2(tmp_path):
 
 
 def _pipe_worker(rank, world, port, out_dir):
+    """Five pipelined batches through misift_gather_post / misift_gather_complete of a host communicator, rotating root
+    (root = k % world, bench.py --gather-root rotate), a rank with nothing to send, an overflowed (-1) frame."""
     import torch
     import torch.distributed as dist
-    from cudasift_amd.dist import RECORD_BYTES, RecordGather, unpack_records
+    from cudasift_amd import capi
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cpu")
+    comm = gloo_host_comm(capi, dist, torch, rank, world)
     B, cap, steps = 4, 12, 5
-    g = RecordGather(dist, torch, rank, world, dev, nslots=2)
 
     def batch(r, k):
         rng = np.random.default_rng(1000 * r + k)
@@ -116,26 +175,29 @@ def _pipe_worker(rank, world, port, out_dir):
         return c, body, packed
 
     ok = True
+    live = {}
+    room = world * B * cap
+    recv = np.zeros(room * RECORD_BYTES, np.uint8)
 
-    def check(k, res):
+    def complete(k):
         nonlocal ok
-        all_counts, bufs = res
+        root = k % world
+        all_counts, offs = comm.gather_complete(k % 2, B, root, recv if rank == root else None, room)
         for r in range(world):
             c, body, _ = batch(r, k)
             ok &= bool(np.array_equal(all_counts[r], c))
-            if rank == 0:
-                ok &= bool(np.array_equal(bufs[r].numpy(), body))
-                frames = unpack_records(bufs[r], np.clip(all_counts[r], 0, None))
-                ok &= len(frames) == B
-        if rank != 0:
-            ok &= bufs is None
+            if rank == root:
+                ok &= bool(np.array_equal(recv[int(offs[r]) * RECORD_BYTES: int(offs[r + 1]) * RECORD_BYTES], body))
+        live.pop(k % 2)
 
     for k in range(steps):                                  # software pipeline: complete(k-1) after post(k)
         c, _, packed = batch(rank, k)
-        g.post(k % 2, torch.from_numpy(c), torch.from_numpy(packed))
+        live[k % 2] = (c, packed)                           # the C side holds pointers into these until complete()
+        comm.gather_post(k % 2, c, B, packed)
         if k > 0:
-            check(k - 1, g.complete((k - 1) % 2))
-    check(steps - 1, g.complete((steps - 1) % 2))
+            complete(k - 1)
+    complete(steps - 1)
+    comm.close()
     open(os.path.join(out_dir, "pok%d" % rank), "w").write("1" if ok else "0")
     dist.destroy_process_group()
 
