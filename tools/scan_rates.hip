@@ -94,6 +94,36 @@ __device__ __forceinline__ Pair4 blur_pair_lds(const Taps2 &t, float4 c, float4 
   return h;
 }
 
+// ---- order D (r04, VERDICT r03 "next" #5): the VERTICAL pass on the matrix pipe.  V_s[x] = sum_j k_s[j] p_j[x] is a
+// shared-operand contraction: v_mfma_f32_4x4x1_16b_f32 with A = tap j of four scales (lane l holds the tap of scale
+// l % 4: the same in all 16 blocks), B = this lane's pixel, chained over the five taps through C — output register r of
+// every lane is scale r's sum for the lane's OWN pixel.  40 MFMAs per wave-row (4 pixel components x 2 scale groups x 5
+// taps) replace 60 packed multiply-adds; whether the chain rounds like the fmaf chain is checked by k_mfma_check.
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct TapsA { float g0[5], g1[5]; };          // per lane: tap j of scale (l % 4) + 1 (group 0) / (l % 4) + 5 (group 1)
+__device__ __forceinline__ v4f vert_mfma(const float (&a)[5], float c, float p1, float p2, float p3, float p4)
+{
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], c, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], p2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], p3, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[4], p4, acc, 0, 0, 0);
+  return acc;
+}
+// horizontal pass of one scale pair from its vertical sums (the second half of blur_pair_chain)
+__device__ __forceinline__ Pair4 horiz_pair(const Taps2 &t, const Pair4 &v)
+{
+  const v2f lx = from_left2(v.x), ly = from_left2(v.y), lz = from_left2(v.z), lw = from_left2(v.w);
+  const v2f rx = from_right2(v.x), ry = from_right2(v.y), rz = from_right2(v.z), rw = from_right2(v.w);
+  Pair4 h;
+  h.x = conv9p(t, v.x, lw + v.y, lz + v.z, ly + v.w, lx + rx);
+  h.y = conv9p(t, v.y, v.x + v.z, lw + v.w, lz + rx, ly + ry);
+  h.z = conv9p(t, v.z, v.y + v.w, v.x + rx, lw + ry, lz + rz);
+  h.w = conv9p(t, v.w, v.z + rx, v.y + ry, v.x + rz, lw + rw);
+  return h;
+}
+
 #define TIC const unsigned long long c0_ = __builtin_readcyclecounter(), r0_ = __builtin_amdgcn_s_memrealtime()
 #define TOC if (blockIdx.x == 0 && threadIdx.x == 0) { ((unsigned long long *)out)[4] = __builtin_readcyclecounter() - c0_; \
                                                       ((unsigned long long *)out)[5] = __builtin_amdgcn_s_memrealtime() - r0_; }
@@ -144,6 +174,90 @@ __global__ void k_row(float *out, int iters)
   TOC;
 }
 
+__global__ void k_row_mfma(float *out, int iters)
+{
+  __shared__ v2f s_taps[16][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 15) s_taps[wave][lane] = mk2(out[0] * (1.0f + lane), out[1] * (2.0f + lane));
+  __syncthreads();
+  const v2f *tk = s_taps[wave];
+  TapsA A;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {                 // (timing: any per-lane constants do)
+    A.g0[j] = out[0] * (1.0f + (lane & 3) + j);
+    A.g1[j] = out[1] * (5.0f + (lane & 3) + j);
+  }
+  float f = (float)threadIdx.x;
+  float4 c = make_float4(f, f + 1, f + 2, f + 3), p1 = make_float4(f * 2, f * 3, f * 4, f * 5), p2 = p1, p3 = c, p4 = p1;
+  p2.x += 1; p3.y += 2; p4.z += 3;
+  float acc = 0;
+  TIC;
+  for (int it = 0; it < iters; it++) {
+    asm volatile("" ::: "memory");
+    float4 d[5];
+    // vertical sums of all six scales: 8 independent 5-deep MFMA chains
+    const v4f ax = vert_mfma(A.g0, c.x, p1.x, p2.x, p3.x, p4.x), ay = vert_mfma(A.g0, c.y, p1.y, p2.y, p3.y, p4.y);
+    const v4f az = vert_mfma(A.g0, c.z, p1.z, p2.z, p3.z, p4.z), aw = vert_mfma(A.g0, c.w, p1.w, p2.w, p3.w, p4.w);
+    const v4f bx = vert_mfma(A.g1, c.x, p1.x, p2.x, p3.x, p4.x), by = vert_mfma(A.g1, c.y, p1.y, p2.y, p3.y, p4.y);
+    const v4f bz = vert_mfma(A.g1, c.z, p1.z, p2.z, p3.z, p4.z), bw = vert_mfma(A.g1, c.w, p1.w, p2.w, p3.w, p4.w);
+    Taps2 t = load_taps2(tk);
+    __builtin_amdgcn_sched_barrier(0);
+    Pair4 v;
+    v.x = mk2(ax[0], ax[1]); v.y = mk2(ay[0], ay[1]); v.z = mk2(az[0], az[1]); v.w = mk2(aw[0], aw[1]);
+    const Pair4 b0 = horiz_pair(t, v);
+    asm volatile("" ::: "memory");
+    t = load_taps2(tk + 5);
+    __builtin_amdgcn_sched_barrier(0);
+    d[0] = make_float4(b0.x.y - b0.x.x, b0.y.y - b0.y.x, b0.z.y - b0.z.x, b0.w.y - b0.w.x);
+    v.x = mk2(ax[2], ax[3]); v.y = mk2(ay[2], ay[3]); v.z = mk2(az[2], az[3]); v.w = mk2(aw[2], aw[3]);
+    const Pair4 b1 = horiz_pair(t, v);
+    asm volatile("" ::: "memory");
+    t = load_taps2(tk + 10);
+    __builtin_amdgcn_sched_barrier(0);
+    d[1] = make_float4(b1.x.x - b0.x.y, b1.y.x - b0.y.y, b1.z.x - b0.z.y, b1.w.x - b0.w.y);
+    d[2] = make_float4(b1.x.y - b1.x.x, b1.y.y - b1.y.x, b1.z.y - b1.z.x, b1.w.y - b1.w.x);
+    v.x = mk2(bx[0], bx[1]); v.y = mk2(by[0], by[1]); v.z = mk2(bz[0], bz[1]); v.w = mk2(bw[0], bw[1]);
+    const Pair4 b2 = horiz_pair(t, v);
+    d[3] = make_float4(b2.x.x - b1.x.y, b2.y.x - b1.y.y, b2.z.x - b1.z.y, b2.w.x - b1.w.y);
+    d[4] = make_float4(b2.x.y - b2.x.x, b2.y.y - b2.y.x, b2.z.y - b2.z.x, b2.w.y - b2.w.x);
+    float amax = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 5; p++) amax = max3f(max3f(amax, fabsf(d[p].x), fabsf(d[p].y)), fabsf(d[p].z), fabsf(d[p].w));
+    acc = fmaxf(acc, amax);
+    if (__builtin_expect(amax == 12345.678f, 0)) { c.x += 1.0f; p1.y += 1.0f; }
+  }
+  if (acc == 12345.678f) out[2] = acc;
+  TOC;
+}
+
+// Does the MFMA chain round like the fmaf chain of conv9 (first product rounded, four fused multiply-adds)?  Every lane
+// evaluates both on pseudo-random operands (taps in (0, 1), pixels in (0, 255), and a few denormal / huge ones);
+// res[0] = evaluations, res[1] = bit mismatches.
+__global__ void k_mfma_check(unsigned *res, int iters)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned seed = 12345u + 7919u * threadIdx.x + 104729u * blockIdx.x, bad = 0, n = 0;
+  auto rnd = [&]() -> float { seed = seed * 1664525u + 1013904223u; return (float)(seed >> 8) * (1.0f / 16777216.0f); };
+  for (int it = 0; it < iters; it++) {
+    float a[5], px[5];
+    for (int j = 0; j < 5; j++) { a[j] = rnd() * (j ? 0.3f : 1.0f); px[j] = rnd() * (j ? 510.0f : 255.0f); }
+    if ((it & 63) == 7) px[2] = 1e-41f;              // a denormal operand
+    if ((it & 63) == 9) a[3] = 3e-39f;               // a denormal tap
+    if ((it & 63) == 11) px[4] = 3e37f;
+    const v4f m = vert_mfma(a, px[0], px[1], px[2], px[3], px[4]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      // register r = the taps held by lane (lane & ~3) + r, this lane's pixels
+      float s = __shfl(a[0], (lane & ~3) + r) * px[0];
+      for (int j = 1; j < 5; j++) s = __builtin_fmaf(__shfl(a[j], (lane & ~3) + r), px[j], s);
+      n++;
+      if (__float_as_uint(s) != __float_as_uint(m[r])) bad++;
+    }
+  }
+  atomicAdd(&res[0], n);
+  atomicAdd(&res[1], bad);
+}
+
 // dependent chains of packed fmas: ILP 1, 2, 4, 8 (8 instructions per iteration each)
 #define PKF(r) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(k), "v"(c));
 #define PKF_OS(r) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(r) : "v"(k), "v"(c));
@@ -177,6 +291,7 @@ int main()
   CHECK(hipMemcpy(out, h, sizeof(h), hipMemcpyHostToDevice));
   Entry e[] = {
     {"row_chain (per row)", k_row<0>, 1}, {"row_ilv (per row)", k_row<1>, 1}, {"row_lds (per row)", k_row<2>, 1},
+    {"row_mfma_vert (per row)", k_row_mfma, 1},
     {"pk_fma dep ILP1", k_pk_dep1, 8}, {"pk_fma dep ILP2", k_pk_dep2, 8}, {"pk_fma dep ILP4", k_pk_dep4, 8}, {"pk_fma dep ILP8", k_pk_dep8, 8},
     {"pk_fma opsel ILP1", k_pk_dep1_opsel, 8}, {"pk_fma opsel ILP4", k_pk_dep4_opsel, 8},
     {"pk ILP1 + indep dpp", k_pk_dep1_dpp, 8}, {"pk -> dpp of result", k_pk_then_dpp, 8},
@@ -185,6 +300,16 @@ int main()
          "W wavefronts per SIMD on every SIMD (W <= 4: one workgroup per CU; 6, 8: two).  [wave0] = s_memtime interval of wavefront 0 / W:\n"
          "the oldest wavefront is favoured by the issue arbiter and runs at its solo speed -- not a throughput.\n", prop.gcnArchName, cus);
   printf("%-24s %9s %9s %9s %9s %9s %9s %8s %9s\n", "item", "W=1", "W=2", "W=3", "W=4", "W=6", "W=8", "MHz(4)", "[wave0]4");
+  {
+    unsigned *res, hres[2] = {0, 0};
+    CHECK(hipMalloc((void **)&res, 8));
+    CHECK(hipMemset(res, 0, 8));
+    hipLaunchKernelGGL(k_mfma_check, dim3(256), dim3(256), 0, 0, res, 4096);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(hres, res, 8, hipMemcpyDeviceToHost));
+    printf("mfma_f32_4x4x1 chain vs the fmaf chain of conv9: %u evaluations, %u bit mismatches\n", hres[0], hres[1]);
+    CHECK(hipFree(res));
+  }
   hipEvent_t t0, t1;
   CHECK(hipEventCreate(&t0));
   CHECK(hipEventCreate(&t1));
