@@ -343,7 +343,9 @@ struct misift_ctx {
   int chain_embed;              // 1 = that chain runs inside the scan launch when one chain covers all levels (MISIFT_CHAIN_EMBED)
   int bin_min_frames;           // >= this many frames: bin_detections runs (MISIFT_BIN_MIN_FRAMES)
   int small_frames;             // <= this many frames: short scan segments, wide refine / per-keypoint grids (MISIFT_SMALL_FRAMES)
+  int lowpass_tile;             // 1 = such batches: the LDS-tiled prefilter + first ScaleDown (MISIFT_LOWPASS_TILE)
   int strip_rows_small;         // rows per prefilter / ScaleDown segment for such batches, even (MISIFT_STRIP_ROWS_SMALL)
+  int scan_rows_small_coarse;   // ... and for the levels behind the embedded ScaleDown chain (MISIFT_SCAN_ROWS_SMALL_COARSE)
   int scan_rows_small;          // rows per scan segment for such batches (MISIFT_SCAN_ROWS_SMALL)
   int cur_binned;               // this call's per-keypoint kernels read d_det_sorted (set by misift_extract_enqueue)
   int want_export, exported;    // host export of the counters by the last kernel: asked for by misift_extract_sync / done
@@ -405,6 +407,10 @@ int launch_lowpass(misift_ctx *ctx, const void *src, int src_u8, const StripGeom
 int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const StripGeom &g, float *dst, int dpitch,
                         long long dst_frame_stride, const float k9[9], float *dst2, int dpitch2,
                         long long dst2_frame_stride, const float k5[5], int *done, unsigned *zero_cnt);
+int launch_lowpass_down_tile(misift_ctx *ctx, const void *src, int src_u8, int width, int height, int spitch,
+                             long long src_frame_stride, int nframes, float *dst, int dpitch, long long dst_frame_stride,
+                             const float k9[9], float *dst2, int dpitch2, long long dst2_frame_stride, const float k5[5],
+                             unsigned *zero_cnt);
 int launch_scaledown_chain(misift_ctx *ctx, float *scratch, long long frame_stride, int nframes, const int (*dims)[3],
                            const long long *offs, int nlev, const float k5[5]);
 int launch_scaledown(misift_ctx *ctx, const float *src, const StripGeom &g, float *dst, int dpitch,

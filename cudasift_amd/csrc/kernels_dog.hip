@@ -1404,8 +1404,11 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
     int seg = (int)((L.h + want - 1) / want);
 #if SCAN_RING
     if (P.nframes <= ctx->small_frames) {
-      // a frame or two: the launch is latency-bound (rows per wavefront x ~1 us), so short segments on every SIMD
-      if (seg < ctx->scan_rows_small) seg = ctx->scan_rows_small;
+      // a frame or two: the launch is latency-bound (rows per wavefront x ~1 us), so short segments on every SIMD —
+      // shorter still on the levels behind the embedded ScaleDown chain, whose rows are the tail of the launch's
+      // critical path (chain -> coarse rows)
+      const int floor_rows = (chain && lev - lev_begin >= 2) ? ctx->scan_rows_small_coarse : ctx->scan_rows_small;
+      if (seg < floor_rows) seg = floor_rows;
       if (seg > RING_ROWS) seg = (seg + RING_ROWS - 1) / RING_ROWS * RING_ROWS;
     } else {
       seg = (seg + RING_ROWS - 1) / RING_ROWS * RING_ROWS;     // whole turns of the nine-row ring

@@ -273,6 +273,157 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
   if (y1 == g.height && (g.height & 1) == 0) emit((g.height - 2) >> 1, a1, a2, a3, a4, a4);
 }
 
+// ------------------------------------- LowPass + first ScaleDown, tiled (small batches, r04)
+// The streamed kernel above is built for throughput: a wavefront walks a 240-pixel strip row by row, 8 rows of prologue
+// before its first output row, ~19 dependent rows for an 8-row segment.  For ONE frame that is a latency chain at one
+// wavefront per SIMD (17 us of a call's 83, r04 single-call budget).  Here a workgroup owns a 64 x 32 tile of the
+// prefiltered image and does both separable passes — and the decimation — from LDS with every lane busy in parallel:
+//   S  (TH+12) x (TW+12)  source region, clamp-to-edge          H  (TH+12) x (TW+4)   horizontal 9-tap
+//   O  (TH+4)  x (TW+4)   vertical 9-tap = prefiltered tile + 2 px halo (an out-of-image entry holds the value of the
+//                         clamped pixel, as the decimation's clamped reads see it); the inner TH x TW goes to `dst`
+//   DH (TH+4)  x (TW/2)   horizontal 5-tap decimation            then the vertical 5-tap -> TH/2 x TW/2 pixels of `dst2`
+// Same expressions on the same operands as lowpass_kernel + scaledown_kernel (conv9_expr; fmaf chains of hdec / vcomb):
+// bit-identical.  Any width, any alignment, fp32 or 8-bit source (scalar loads); ~1.5x the arithmetic of the streamed
+// kernel (halo), which is why batches keep that one.
+// (stores: LPT_NT = 1 streams them out non-temporally while the kernel runs instead of leaving 10 MB of dirty lines for
+//  the end-of-kernel L2 write-back, which is part of a dependent kernel's duration)
+#ifndef LPT_NT
+#define LPT_NT 1
+#endif
+#if LPT_NT
+#define LPT_STORE1(p, v) __builtin_nontemporal_store((v), (p))
+typedef float lpt_v2f __attribute__((ext_vector_type(2)));
+#define LPT_STORE2(p, v) do { const float2 v2_ = (v); lpt_v2f w2_; w2_.x = v2_.x; w2_.y = v2_.y; __builtin_nontemporal_store(w2_, reinterpret_cast<lpt_v2f *>(p)); } while (0)
+#else
+#define LPT_STORE1(p, v) (*(p) = (v))
+#define LPT_STORE2(p, v) (*reinterpret_cast<float2 *>(p) = (v))
+#endif
+#define LPT_TW 64
+#define LPT_TH 32
+#define LPT_SW (LPT_TW + 12)
+#define LPT_SH (LPT_TH + 12)
+#define LPT_HW (LPT_TW + 4)
+#define LPT_OH (LPT_TH + 4)
+template <typename SRC>
+__global__ __launch_bounds__(256) void lowpass_down_tile_kernel(const SRC *__restrict__ src, int width, int height,
+                                                                int spitch, long long src_frame_stride,
+                                                                float *__restrict__ dst, int dpitch,
+                                                                long long dst_frame_stride, Taps5 t,
+                                                                float *__restrict__ dst2, int dpitch2,
+                                                                long long dst2_frame_stride, Taps5 t5, int tiles_x,
+                                                                unsigned *__restrict__ zero_cnt, int nframes)
+{
+  __shared__ float s_S[LPT_SH * LPT_SW];        // later: DH
+  __shared__ float s_H[LPT_SH * LPT_HW];
+  __shared__ float s_O[LPT_OH * LPT_HW];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, frame = blockIdx.y;
+  if (zero_cnt && blockIdx.x == 0 && tid < CNT_STRIDE) {      // the first kernel of the call clears the counters
+    zero_cnt[(size_t)frame * CNT_STRIDE + tid] = 0u;
+    if (frame == 0)
+      for (int b = 0; b < CNT_SPARE_BLOCKS; b++) zero_cnt[(size_t)(nframes + b) * CNT_STRIDE + tid] = 0u;
+  }
+  const SRC *img = src + (long long)frame * src_frame_stride;
+  float *out = dst + (long long)frame * dst_frame_stride;
+  float *out2 = dst2 + (long long)frame * dst2_frame_stride;
+  const int x0 = tx * LPT_TW, y0 = ty * LPT_TH;              // tile origin in the prefiltered image (both even)
+  const float k0 = t.k[0], k1 = t.k[1], k2 = t.k[2], k3 = t.k[3], k4 = t.k[4];
+  const float d0 = t5.k[0], d1 = t5.k[1], d2 = t5.k[2];
+  // ---- S: source pixels (x0 - 6 + i, y0 - 6 + j), clamped
+  for (int idx = tid; idx < LPT_SH * LPT_SW; idx += 256) {
+    const int j = idx / LPT_SW, i = idx - j * LPT_SW;
+    s_S[idx] = (float)img[(size_t)clampi(y0 - 6 + j, 0, height - 1) * spitch + clampi(x0 - 6 + i, 0, width - 1)];
+  }
+  __syncthreads();
+  // The two 9-tap passes are register-blocked (a thread reads a run of LDS quads once and produces 4 / 8 outputs from
+  // them: a third of the LDS instructions of one-output-per-thread loops, which bound the first version of this kernel).
+  // Both run the REGULAR stencil everywhere — exact wherever the output pixel lies inside the image, because S holds the
+  // clamped source — and the entries of O outside the image, which must hold the value of the CLAMPED pixel for the
+  // decimation, are copied from it afterwards (edge tiles only).
+  // ---- H: rows of S; quad g = columns x0 - 2 + 4g .. + 3, from S columns 4g .. 4g + 11 of the row
+  for (int idx = tid; idx < LPT_SH * (LPT_HW / 4); idx += 256) {
+    const int j = idx / (LPT_HW / 4), g = idx - j * (LPT_HW / 4);
+    const float4 *r = reinterpret_cast<const float4 *>(s_S + j * LPT_SW + 4 * g);
+    const float4 a = r[0], b = r[1], c = r[2];                // S columns 4g .. 4g+11; output i = 4g + m is centred on 4g + 4 + m
+    float4 h;
+    h.x = conv9_expr(k0, k1, k2, k3, k4, b.x, b.y + a.w, b.z + a.z, b.w + a.y, c.x + a.x);
+    h.y = conv9_expr(k0, k1, k2, k3, k4, b.y, b.z + b.x, b.w + a.w, c.x + a.z, c.y + a.y);
+    h.z = conv9_expr(k0, k1, k2, k3, k4, b.z, b.w + b.y, c.x + b.x, c.y + a.w, c.z + a.z);
+    h.w = conv9_expr(k0, k1, k2, k3, k4, b.w, c.x + b.z, c.y + b.y, c.z + b.x, c.w + a.w);
+    *reinterpret_cast<float4 *>(s_H + j * LPT_HW + 4 * g) = h;
+  }
+  __syncthreads();
+  // ---- O: rows y0 - 2 + j; a thread takes two rows of one quad column: H rows j .. j + 9 (local)
+  for (int idx = tid; idx < (LPT_OH / 2) * (LPT_HW / 4); idx += 256) {
+    const int jp = idx / (LPT_HW / 4), g = idx - jp * (LPT_HW / 4), j = 2 * jp;
+    const float4 *c = reinterpret_cast<const float4 *>(s_H + j * LPT_HW + 4 * g);      // H row j <-> source row y0 - 6 + j
+    float4 w[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) w[k] = c[k * (LPT_HW / 4)];
+    float4 o0, o1;                                            // O rows j and j + 1: centred on H rows j + 4 and j + 5
+    o0.x = conv9_expr(k0, k1, k2, k3, k4, w[4].x, w[5].x + w[3].x, w[6].x + w[2].x, w[7].x + w[1].x, w[8].x + w[0].x);
+    o0.y = conv9_expr(k0, k1, k2, k3, k4, w[4].y, w[5].y + w[3].y, w[6].y + w[2].y, w[7].y + w[1].y, w[8].y + w[0].y);
+    o0.z = conv9_expr(k0, k1, k2, k3, k4, w[4].z, w[5].z + w[3].z, w[6].z + w[2].z, w[7].z + w[1].z, w[8].z + w[0].z);
+    o0.w = conv9_expr(k0, k1, k2, k3, k4, w[4].w, w[5].w + w[3].w, w[6].w + w[2].w, w[7].w + w[1].w, w[8].w + w[0].w);
+    o1.x = conv9_expr(k0, k1, k2, k3, k4, w[5].x, w[6].x + w[4].x, w[7].x + w[3].x, w[8].x + w[2].x, w[9].x + w[1].x);
+    o1.y = conv9_expr(k0, k1, k2, k3, k4, w[5].y, w[6].y + w[4].y, w[7].y + w[3].y, w[8].y + w[2].y, w[9].y + w[1].y);
+    o1.z = conv9_expr(k0, k1, k2, k3, k4, w[5].z, w[6].z + w[4].z, w[7].z + w[3].z, w[8].z + w[2].z, w[9].z + w[1].z);
+    o1.w = conv9_expr(k0, k1, k2, k3, k4, w[5].w, w[6].w + w[4].w, w[7].w + w[3].w, w[8].w + w[2].w, w[9].w + w[1].w);
+    *reinterpret_cast<float4 *>(s_O + j * LPT_HW + 4 * g) = o0;
+    *reinterpret_cast<float4 *>(s_O + (j + 1) * LPT_HW + 4 * g) = o1;
+    // the tile's own pixels (local rows 2 .. TH + 1, columns 2 .. TW + 1) go to `dst`
+    const int x = x0 - 2 + 4 * g;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+      const int jj = j + rr, y = y0 - 2 + jj;
+      if (jj < 2 || jj >= LPT_TH + 2 || y >= height) continue;
+      const float4 o = rr ? o1 : o0;
+      float *orow = out + (size_t)y * dpitch;
+      if (g >= 1 && g < LPT_HW / 4 - 1 && x + 3 < width) {   // a whole quad inside the tile and the image: x % 4 == 2
+        LPT_STORE2(orow + x, make_float2(o.x, o.y));
+        LPT_STORE2(orow + x + 2, make_float2(o.z, o.w));
+      } else {
+        const float e[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int i = 4 * g + m;
+          if (i >= 2 && i < LPT_TW + 2 && x + m < width) LPT_STORE1(orow + x + m, e[m]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- edge tiles: the entries of O that lie outside the image take the value of the clamped pixel
+  if (x0 < 2 || y0 < 2 || x0 + LPT_TW + 2 > width || y0 + LPT_TH + 2 > height) {
+    for (int idx = tid; idx < LPT_OH * LPT_HW; idx += 256) {
+      const int j = idx / LPT_HW, i = idx - j * LPT_HW;
+      const int x = x0 - 2 + i, y = y0 - 2 + j;
+      const int cx = clampi(x, 0, width - 1), cy = clampi(y, 0, height - 1);
+      if (cx != x || cy != y) s_O[idx] = s_O[(cy - (y0 - 2)) * LPT_HW + (cx - (x0 - 2))];      // source entries are inside: never written here
+    }
+    __syncthreads();
+  }
+  // ---- DH: decimated column X (global tx * TW/2 + X) of every row of O: prefiltered columns 2Xg - 2 .. 2Xg + 2
+  float *s_DH = s_S;
+  for (int idx = tid; idx < LPT_OH * (LPT_TW / 2); idx += 256) {
+    const int j = idx / (LPT_TW / 2), X = idx - j * (LPT_TW / 2);
+    const float *r = s_O + j * LPT_HW + 2 * X;                // local column 2X <-> prefiltered column 2Xg - 2
+    const float s = __builtin_fmaf(d0, r[0] + r[4], d1 * (r[1] + r[3]));
+    s_DH[idx] = __builtin_fmaf(d2, r[2], s);
+  }
+  __syncthreads();
+  const int w2 = width / 2, h2 = height / 2;
+  for (int idx = tid; idx < (LPT_TH / 2) * (LPT_TW / 2); idx += 256) {
+    const int Y = idx / (LPT_TW / 2), X = idx - Y * (LPT_TW / 2);
+    const int Yg = ty * (LPT_TH / 2) + Y, Xg = tx * (LPT_TW / 2) + X;
+    if (Yg >= h2 || Xg >= w2) continue;
+    const float *c = s_DH + (2 * Y) * (LPT_TW / 2) + X;       // local row 2Y <-> prefiltered row 2Yg - 2
+    float v = __builtin_fmaf(d2, c[2 * (LPT_TW / 2)], d0 * (c[0] + c[4 * (LPT_TW / 2)]));
+    v = __builtin_fmaf(d1, c[LPT_TW / 2] + c[3 * (LPT_TW / 2)], v);
+    LPT_STORE1(out2 + (size_t)Yg * dpitch2 + Xg, v);
+  }
+}
+
 // ---------------------------------------------------------------- ScaleDown
 // 5-tap Gaussian (variance 0.5) + 2x decimation: horizontal then vertical.
 // Geometry `g` describes the SOURCE image; strips/segments tile the OUTPUT (w/2, h/2).
@@ -445,6 +596,29 @@ int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const Stri
                             dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
   }
   *done = 1;
+  return ls.finish();
+}
+
+// the tiled form for small batches: any shape (no alignment or width conditions), always done
+int launch_lowpass_down_tile(misift_ctx *ctx, const void *src, int src_u8, int width, int height, int spitch,
+                             long long src_frame_stride, int nframes, float *dst, int dpitch, long long dst_frame_stride,
+                             const float k9[9], float *dst2, int dpitch2, long long dst2_frame_stride, const float k5[5],
+                             unsigned *zero_cnt)
+{
+  Taps5 t, t5;
+  for (int j = 0; j <= 4; j++) t.k[j] = k9[4 - j];
+  for (int j = 0; j < 5; j++) t5.k[j] = k5[j];
+  const int tiles_x = (width + LPT_TW - 1) / LPT_TW, tiles_y = (height + LPT_TH - 1) / LPT_TH;
+  const dim3 grid(tiles_x * tiles_y, nframes);
+  LaunchScope ls(ctx, "lowpass_down");
+  if (src_u8)
+    hipLaunchKernelGGL(lowpass_down_tile_kernel<unsigned char>, grid, dim3(256), 0, ctx->stream,
+                       static_cast<const unsigned char *>(src), width, height, spitch, src_frame_stride, dst, dpitch,
+                       dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, tiles_x, zero_cnt, nframes);
+  else
+    hipLaunchKernelGGL(lowpass_down_tile_kernel<float>, grid, dim3(256), 0, ctx->stream, static_cast<const float *>(src),
+                       width, height, spitch, src_frame_stride, dst, dpitch, dst_frame_stride, t, dst2, dpitch2,
+                       dst2_frame_stride, t5, tiles_x, zero_cnt, nframes);
   return ls.finish();
 }
 

@@ -346,10 +346,15 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_BIN_MIN_FRAMES")) ctx->bin_min_frames = atoi(e);
   ctx->small_frames = 4;
   if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
-  ctx->strip_rows_small = 8;
-  if (const char *e = getenv("MISIFT_STRIP_ROWS_SMALL")) ctx->strip_rows_small = atoi(e) >= 2 ? atoi(e) / 2 * 2 : 8;
-  ctx->scan_rows_small = 9;
-  if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL")) ctx->scan_rows_small = atoi(e) > 0 ? atoi(e) : 9;
+  ctx->lowpass_tile = 1;
+  if (const char *e = getenv("MISIFT_LOWPASS_TILE")) ctx->lowpass_tile = atoi(e) != 0;
+  ctx->strip_rows_small = 6;
+  if (const char *e = getenv("MISIFT_STRIP_ROWS_SMALL")) ctx->strip_rows_small = atoi(e) >= 2 ? atoi(e) / 2 * 2 : 6;
+  // (r04 sweep, profiles/r04_single_call_sweep_step5.txt: fine / coarse rows 9/9 31.0 us, 9/4 25.2, 6/4 23.2, 4/3 21.8, 4/2 21.2, 3/3 22.5)
+  ctx->scan_rows_small_coarse = 2;
+  if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL_COARSE")) ctx->scan_rows_small_coarse = atoi(e) > 0 ? atoi(e) : 2;
+  ctx->scan_rows_small = 4;
+  if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL")) ctx->scan_rows_small = atoi(e) > 0 ? atoi(e) : 4;
   ctx->host_spin = 1;
   if (const char *e = getenv("MISIFT_HOST_SPIN")) ctx->host_spin = atoi(e) != 0;
   HIP_TRY(hipEventCreate(&ctx->ev0));
@@ -970,7 +975,13 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
       pre_src = upImg; pre_u8 = 0; pre_pitch = L.p; pre_frames = nframes; pre_stride = SS;
       lowest_scale *= 2.0f;
     }
-    if (num_octaves >= 2 && ctx->opt.fused) {
+    if (num_octaves >= 2 && ctx->opt.fused && ctx->lowpass_tile && nframes <= ctx->small_frames) {
+      const Level &D = lv[num_octaves - 1];        // a frame or two: the LDS-tiled form (latency, not throughput)
+      rc = launch_lowpass_down_tile(ctx, pre_src, pre_u8, W, H, pre_pitch, pre_stride, pre_frames, L.img, L.p, SS, k9, D.img,
+                                    D.p, SS, k5, ctx->d_counters);
+      if (rc) return rc;
+      first_down_done = 1;
+    } else if (num_octaves >= 2 && ctx->opt.fused) {
       const Level &D = lv[num_octaves - 1];
       StripGeom g = make_geom(ctx, W, H, pre_pitch, pre_frames, pre_stride, W, H, 60);
       rc = launch_lowpass_down(ctx, pre_src, pre_u8, g, L.img, L.p, SS, k9, D.img, D.p, SS, k5, &first_down_done,
