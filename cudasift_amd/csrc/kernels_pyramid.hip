@@ -330,9 +330,20 @@ __global__ __launch_bounds__(256) void lowpass_down_tile_kernel(const SRC *__res
   const float k0 = t.k[0], k1 = t.k[1], k2 = t.k[2], k3 = t.k[3], k4 = t.k[4];
   const float d0 = t5.k[0], d1 = t5.k[1], d2 = t5.k[2];
   // ---- S: source pixels (x0 - 6 + i, y0 - 6 + j), clamped
-  for (int idx = tid; idx < LPT_SH * LPT_SW; idx += 256) {
-    const int j = idx / LPT_SW, i = idx - j * LPT_SW;
-    s_S[idx] = (float)img[(size_t)clampi(y0 - 6 + j, 0, height - 1) * spitch + clampi(x0 - 6 + i, 0, width - 1)];
+  // (all of a thread's loads are issued before its first LDS store: a rolled load -> store loop is one memory round trip
+  //  per trip, and fourteen of them were most of this kernel's 15 us)
+  {
+    constexpr int TRIPS = (LPT_SH * LPT_SW + 255) / 256;
+    float v[TRIPS];
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++) {
+      const int idx = min(tid + 256 * k, LPT_SH * LPT_SW - 1);
+      const int j = idx / LPT_SW, i = idx - j * LPT_SW;
+      v[k] = (float)img[(size_t)clampi(y0 - 6 + j, 0, height - 1) * spitch + clampi(x0 - 6 + i, 0, width - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++)
+      if (tid + 256 * k < LPT_SH * LPT_SW) s_S[tid + 256 * k] = v[k];
   }
   __syncthreads();
   // The two 9-tap passes are register-blocked (a thread reads a run of LDS quads once and produces 4 / 8 outputs from
