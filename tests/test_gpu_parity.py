@@ -245,6 +245,22 @@ def test_extract_batch_equals_single(ctx):
         compare_points(ref[:nref], pts[f][:n[f]], "extract_batch_f%d" % f, record)
 
 
+@pytest.mark.parametrize("nframes,noct,w,h,u8", [(2, 5, 640, 360, False), (4, 3, 322, 250, False), (3, 6, 770, 516, True),
+                                                  (2, 7, 1283, 1030, False), (1, 2, 193, 131, False)])
+def test_small_batches_take_the_single_call_kernels(ctx, nframes, noct, w, h, u8):
+    """Batches of 1-4 frames run the latency-shaped kernels of the single-call path (r04: tiled prefilter, chained
+    ScaleDowns inside the scan launch or — more than three coarse levels — as launches of their own, no binning, the last
+    kernel's counter export): several frames per launch, ragged widths, 8-bit sources, 2 ... 7 octaves vs the oracle."""
+    imgs = np.stack([synth_frame(300 + 7 * f + noct, w, h) for f in range(nframes)])
+    if u8:
+        imgs = np.clip(np.rint(imgs), 0, 255).astype(np.uint8)
+    pts, n = ctx.extract_batch_ex(imgs, num_octaves=noct, thresh=2.5, max_pts=8192)
+    for f in range(nframes):
+        ref, nref, cref = orc().extract(imgs[f].astype(np.float32), num_octaves=noct, thresh=2.5, max_pts=8192)
+        assert nref == n[f] and nref > 50, (f, nref, n)
+        compare_points(ref[:nref], pts[f][:n[f]], "small_batch_%d_%d_f%d" % (nframes, noct, f), record)
+
+
 def test_extract_deterministic_set(ctx, stereo):
     a, na, ca = ctx.extract(stereo[1][:480, :640], thresh=3.0)
     b, nb, cb = ctx.extract(stereo[1][:480, :640], thresh=3.0)
