@@ -148,6 +148,13 @@ __global__ __launch_bounds__(256, 4) void lowpass_kernel(const SRC *__restrict__
 // aligned rows); other shapes run the two separate kernels.
 // Lanes 1..62 hold valid prefiltered quads, lanes 2..61 store (the decimation needs both neighbours),
 // so a strip advances by 60 quads.
+// The prefiltered rows (8.3 MB per 1080p frame, read back by the scan from HBM anyway: the L2 cannot hold them) leave as
+// non-temporal stores: r04 A/B over six alternating pairs on two boxes, default bench: 58.5 k +- 0.1 against 57.8 k +- 0.8
+// frames/s (tools/ab_bench.sh; LPD_NT = 2 adds the decimated rows: 57.4 k, noisier; r01's rejection of non-temporal stores
+// predates batches in flight).
+#ifndef LPD_NT
+#define LPD_NT 1
+#endif
 #define FUSED_OUT_LANES 60
 // MODE 1: width % 4 == 0; MODE 2: any width (ragged last quad, see clamp_quad in common.hpp).
 template <typename SRC, int MODE>
@@ -215,7 +222,13 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
         if (2 * q + 1 < w2o) *reinterpret_cast<float2 *>(d2) = o;
         else if (2 * q < w2o) d2[0] = o.x;
       } else {
+#if LPD_NT >= 2
+        typedef float lpd_v2f __attribute__((ext_vector_type(2)));
+        lpd_v2f o2; o2.x = o.x; o2.y = o.y;
+        __builtin_nontemporal_store(o2, reinterpret_cast<lpd_v2f *>(d2));
+#else
         *reinterpret_cast<float2 *>(d2) = o;
+#endif
       }
     }
   };
@@ -242,7 +255,15 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
     o.y = conv9_expr(k0, k1, k2, k3, k4, W4.y, W3.y + W5.y, W2.y + W6.y, W1.y + W7.y, W0.y + W8.y);
     o.z = conv9_expr(k0, k1, k2, k3, k4, W4.z, W3.z + W5.z, W2.z + W6.z, W1.z + W7.z, W0.z + W8.z);
     o.w = conv9_expr(k0, k1, k2, k3, k4, W4.w, W3.w + W5.w, W2.w + W6.w, W1.w + W7.w, W0.w + W8.w);
+#if LPD_NT
+    if (writer && y >= y0 && y < y1) {
+      typedef float lpd_v4f __attribute__((ext_vector_type(4)));
+      lpd_v4f o4; o4.x = o.x; o4.y = o.y; o4.z = o.z; o4.w = o.w;
+      __builtin_nontemporal_store(o4, reinterpret_cast<lpd_v4f *>(out + (size_t)y * dpitch + 4 * q));
+    }
+#else
     if (writer && y >= y0 && y < y1) *reinterpret_cast<float4 *>(out + (size_t)y * dpitch + 4 * q) = o;
+#endif
     float4 oc = o;                                         // the prefiltered row as ScaleDown's clamped reads see it:
     if (MODE == 2 && qc.edge == 2) {                       // columns past width-1 take the value of column width-1
       const float e = qc.rem == 1 ? o.x : (qc.rem == 2 ? o.y : o.z);
