@@ -1,14 +1,15 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark: 1920x1080 SIFT frames/s (+ 100k x 100k match Mpairs/s).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
-torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the env).
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 either a launcher starts one rank per GPU
+(torch.distributed.run: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the env) or — the plain command — bench.py spawns the N
+ranks itself (spawn_ranks) and refuses to run when fewer than N devices are visible.
 
 A step = one pass of the hot path (ExtractSift: LowPass -> pyramid -> DoG -> extrema -> orientation ->
 descriptors -> count read-back, mainSift.cpp:58-67 parameters) over one batch of FRAMES_PER_GPU synthetic
 1920x1080 frames already resident in HBM.  Every rank holds 8 such batches of DISTINCT frames (512 frames = the
 whole BASELINE config 4 job at N = 1) and rotates through them; with N > 1 the valid SiftPoint records of every
-batch are gathered on rank 0 over RCCL/xGMI (misift_gather_*), pipelined under the following batches.  Per-GPU
+batch are gathered on ONE rank over RCCL/xGMI (misift_gather_*; the root rotates with the step by default, --gather-root), pipelined under the following batches.  Per-GPU
 work is fixed as N grows ("weak").  Rank 0 prints ONE JSON line; `value` is whole-job frames/s.
 
 torch is plumbing only (device memory, the frame generator, rendezvous/barrier): all compute AND the data-path
@@ -1303,7 +1304,7 @@ def main():
                "config": {"workload": "batches of %d synthetic 1920x1080 frames per GPU, %d distinct batches per GPU rotated "
                                       "(%d distinct frames per GPU; BASELINE config 4: 512 frames over 8 GPUs), ExtractSift "
                                       "5 octaves initBlur 1.0 thresh 3.0 maxPts 32768, frames resident in HBM, count read-back%s"
-                                      % (B, NB, NB * B, " + RCCL gather of SiftData to rank 0 (misift_gather_*)" if comm else ""),
+                                      % (B, NB, NB * B, (" + RCCL gather of SiftData (misift_gather_*), root = %s" % ("step %% N" if args.gather_root == "rotate" and world > 1 else "rank 0")) if comm else ""),
                           "frames_per_gpu": B, "distinct_frames_per_gpu": NB * B, "contexts": NCTX,
                           "batches_in_flight": NCTX * RING,
                           "batches_in_flight_note": "misift_ctx_set_batches_in_flight(%d): pipelines behind ONE context; kernel "
