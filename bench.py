@@ -1016,9 +1016,40 @@ def main():
             for i in range(40):
                 t1 = time.perf_counter()
                 capi.check(capi.lib().misift_match(ctx.h, a.data_ptr(), npts, pts.data_ptr(), npts), "misift_match")
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t1)
+                ts.append(time.perf_counter() - t1)          # (the call itself returns with the results in place)
+            torch.cuda.synchronize()
             latency["match_%dx%d_ms" % (npts, npts)] = round(1e3 * float(np.median(ts[10:])), 4)
+
+        # ... and the same calls made the way the reference's demo makes them: from C++, through the drop-in API
+        # (build/single_call = tools/single_call.cpp: mainSift.cpp:58-81 on synthetic frames, 200 calls each) — no Python
+        # or ctypes in the timed call.  `host=1` keeps the reference's host mirror of SiftData (ExtractSift then copies
+        # the records back inside its timed region, like cudaSiftH.cu:139-140).
+        exe = os.path.join(ROOT, "build", "single_call")
+        if os.path.exists(exe):
+            try:
+                from synth import synth_frame
+                dropin = {}
+                with tempfile.TemporaryDirectory() as td:
+                    for (lw, lh) in ((1920, 1080), (1280, 960)):
+                        f0, f1 = os.path.join(td, "f0_%d.f32" % lw), os.path.join(td, "f1_%d.f32" % lw)
+                        synth_frame(0, lw, lh).tofile(f0)
+                        synth_frame(1, lw, lh).tofile(f1)
+                        for host in (0, 1):
+                            r = subprocess.run([exe, f0, f1, str(lw), str(lh), "200", "5", "3.0", str(host)], capture_output=True,
+                                               text=True, timeout=300)
+                            for ln in r.stdout.splitlines():
+                                if ln.startswith("{"):
+                                    e = json.loads(ln)
+                                    kind = "extract" if e["what"].startswith("ExtractSift") else "match"
+                                    key = "%s_%dx%d%s_ms" % (kind, lw, lh, "_with_host_mirror" if host else "")
+                                    dropin[key] = e["p50_ms"]
+                                    dropin[key.replace("_ms", "_points")] = e["points"]
+                latency["cpp_caller_through_libcudasift"] = dropin
+                latency["cpp_caller_note"] = ("p50 of 200 back-to-back calls from C++ through the drop-in API (tools/single_call.cpp; "
+                                              "tests/synth.py frames 0 and 1); the figures above are the same entry points called "
+                                              "from Python through ctypes, whose per-call overhead (~3 us) is not the library's")
+            except Exception as e:          # noqa: BLE001 — a side measurement must not break the line
+                latency["cpp_caller_through_libcudasift"] = "failed: %s" % e
 
     # ---------------- PCIe-inclusive side measurement (never `value`): pinned host frames -> H2D -> extract -> D2H
     pcie = None

@@ -113,6 +113,11 @@ struct CtxExtra {
   misift_ctx *last_lane = nullptr;     // the pipeline that took the most recent batch (nullptr: the context itself)
   hipEvent_t last_done = nullptr;
   hipStream_t own_stream = nullptr;    // a child context owns its stream
+  // host-side tap tables of the last call's (num_octaves, init_blur)
+  int taps_noct = -1;
+  float taps_table[8 * 12 * 16];
+  float k9_blur = -1.0f, k9[9], k5[5];
+  bool k5_done = false;
 };
 static CtxExtra *extra(misift_ctx *ctx);
 
@@ -936,11 +941,23 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   // (the frames' counter blocks are cleared by the prefilter kernel — the first kernel of every path below)
   ctx->exported = 0;
 
-  float table[8 * 12 * 16];
-  misift_laplace_taps(num_octaves, table);          // cudaSiftH.cu:109-111
-  float k9[9], k5[5];
-  lowpass_taps(init_blur > 0.001f ? init_blur : 0.001f, k9);
-  scaledown_taps(0.5f, k5);
+  // the tap tables depend on (num_octaves, init_blur) only: a few hundred expf / powf, i.e. microseconds of host time in
+  // front of the first launch of EVERY call — cached per context (r04 single-call budget)
+  CtxExtra *xt = extra(ctx);
+  if (xt->taps_noct != num_octaves) {
+    misift_laplace_taps(num_octaves, xt->taps_table);          // cudaSiftH.cu:109-111
+    xt->taps_noct = num_octaves;
+  }
+  const float blur = init_blur > 0.001f ? init_blur : 0.001f;
+  if (!(xt->k9_blur == blur)) {
+    lowpass_taps(blur, xt->k9);
+    xt->k9_blur = blur;
+  }
+  if (!xt->k5_done) {
+    scaledown_taps(0.5f, xt->k5);
+    xt->k5_done = true;
+  }
+  const float *table = xt->taps_table, *k9 = xt->k9, *k5 = xt->k5;
 
   // arena layout of cudaSiftH.cu:104-107, :151-159, :179-184 (per frame, frame stride S)
   size_t size_img, size_tmp;
