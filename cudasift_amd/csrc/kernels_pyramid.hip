@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void lowpass_down_tile_kernel(const SRC *__res
                                                                 long long dst_frame_stride, Taps5 t,
                                                                 float *__restrict__ dst2, int dpitch2,
                                                                 long long dst2_frame_stride, Taps5 t5, int tiles_x,
-                                                                unsigned *__restrict__ zero_cnt, int nframes)
+                                                                unsigned *__restrict__ zero_cnt, int nframes, int dst_al8)
 {
   __shared__ float s_S[LPT_SH * LPT_SW];        // later: DH
   __shared__ float s_H[LPT_SH * LPT_HW];
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void lowpass_down_tile_kernel(const SRC *__res
       if (jj < 2 || jj >= LPT_TH + 2 || y >= height) continue;
       const float4 o = rr ? o1 : o0;
       float *orow = out + (size_t)y * dpitch;
-      if (g >= 1 && g < LPT_HW / 4 - 1 && x + 3 < width) {   // a whole quad inside the tile and the image: x % 4 == 2
+      if (dst_al8 && g >= 1 && g < LPT_HW / 4 - 1 && x + 3 < width) {   // a whole quad inside the tile and the image: x % 4 == 2 (8-byte aligned rows)
         LPT_STORE2(orow + x, make_float2(o.x, o.y));
         LPT_STORE2(orow + x + 2, make_float2(o.z, o.w));
       } else {
@@ -642,15 +642,17 @@ int launch_lowpass_down_tile(misift_ctx *ctx, const void *src, int src_u8, int w
   for (int j = 0; j < 5; j++) t5.k[j] = k5[j];
   const int tiles_x = (width + LPT_TW - 1) / LPT_TW, tiles_y = (height + LPT_TH - 1) / LPT_TH;
   const dim3 grid(tiles_x * tiles_y, nframes);
+  // the pair stores need 8-byte aligned rows (every arena of ours is; a caller's odd pointer takes the scalar stores)
+  const int dst_al8 = (((uintptr_t)dst) & 7) == 0 && (dpitch & 1) == 0 && (dst_frame_stride & 1) == 0;
   LaunchScope ls(ctx, "lowpass_down");
   if (src_u8)
     hipLaunchKernelGGL(lowpass_down_tile_kernel<unsigned char>, grid, dim3(256), 0, ctx->stream,
                        static_cast<const unsigned char *>(src), width, height, spitch, src_frame_stride, dst, dpitch,
-                       dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, tiles_x, zero_cnt, nframes);
+                       dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, tiles_x, zero_cnt, nframes, dst_al8);
   else
     hipLaunchKernelGGL(lowpass_down_tile_kernel<float>, grid, dim3(256), 0, ctx->stream, static_cast<const float *>(src),
                        width, height, spitch, src_frame_stride, dst, dpitch, dst_frame_stride, t, dst2, dpitch2,
-                       dst2_frame_stride, t5, tiles_x, zero_cnt, nframes);
+                       dst2_frame_stride, t5, tiles_x, zero_cnt, nframes, dst_al8);
   return ls.finish();
 }
 
