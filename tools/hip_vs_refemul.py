@@ -2,7 +2,7 @@
 """The HIP path against the reference's OWN code, no oracle in between, at scale: N synthetic 1920x1080 frames (+ the stereo
 pair) extracted by libmisift.so on the GPU and by the emulated reference (oracle/_ref/libcudasift_refemul_fast.so: the
 reference's kernels and host code on the CPU SIMT emulator, prebuilt — it travels to the GPU box) -> pooled statistics,
-gpurun_out/r03_hip_vs_refemul.json.  Test infrastructure, like tests/test_gpu_golden.py, which asserts the same on five
+gpurun_out/r04_hip_vs_refemul.json.  Test infrastructure, like tests/test_gpu_golden.py, which asserts the same on five
 committed golden cases."""
 import json
 import os
@@ -67,8 +67,8 @@ for name, img, noct, th, blur, lowest, up in cases:
 pooled["only_hip"] = pooled.pop("only_oracle")          # stats() names its first argument "oracle"
 out["pooled_hip_vs_reference"] = pooled
 out["seconds"] = {"hip_single_frame_calls_incl_upload": round(t_hip, 2), "emulated_reference": round(t_ref, 2)}
-path = os.path.join(ROOT, "gpurun_out", "r03_hip_vs_refemul_variants.json" if os.environ.get("HVR_VARIANTS") else
-                    "r03_hip_vs_refemul.json" if N else "r03_hip_vs_refemul_match.json")
+path = os.path.join(ROOT, "gpurun_out", "r04_hip_vs_refemul_variants.json" if os.environ.get("HVR_VARIANTS") else
+                    "r04_hip_vs_refemul.json" if N else "r04_hip_vs_refemul_match.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(pooled, indent=1))

@@ -17,6 +17,8 @@ timeout 600 python bench.py --emulate-ranks 8 > gpurun_out/r04_emulate8.json 2> 
 MATCH_REPS=8 python tools/match_prof.py | tail -1 | tee gpurun_out/r04_match_plain.txt
 (cd /tmp && rm -rf /tmp/mt && rocprofv3 --kernel-trace --stats -d /tmp/mt -o m --output-format csv -- python $GRAFT_REPO_ROOT/tools/match_prof.py > /dev/null 2>&1); find /tmp/mt -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_match_kernel_stats.csv \;
 head -3 gpurun_out/r04_match_kernel_stats.csv
+SIMT_THREADS=16 HVR_FRAMES=256 timeout 900 python tools/hip_vs_refemul.py > gpurun_out/r04_hip_vs_refemul.log 2>&1; echo "hip_vs_refemul rc=$?"
+SIMT_THREADS=16 HVR_VARIANTS=1 timeout 600 python tools/hip_vs_refemul.py > gpurun_out/r04_hip_vs_refemul_variants.log 2>&1; echo "variants rc=$?"
 bash tools/single_call.sh r04_final 200 > /dev/null 2>&1; cat gpurun_out/r04_final_single_call_wall.jsonl
 python - <<'PY'
 import json
