@@ -855,7 +855,7 @@ def main():
 
     # The synthetic frames are generated last, after every allocation.  A short run starts slow whatever precedes it (idle,
     # the frame generator or the MFMA-bound matcher): after 5 warm-up steps the first timed steps take 1.37 ms and the
-    # twentieth 1.27.  Per-launch durations (tools/r03_ramp.sh) show why: the VALU-bound kernels speed up over the first
+    # twentieth 1.27.  Per-launch durations (a 30-step run under rocprofv3 --kernel-trace, r03) show why: the VALU-bound kernels speed up over the first
     # ~30 steps (dog_scan 0.69 -> 0.57 ms, descr_all 0.33 -> 0.285) while the HBM-bound lowpass_down is flat at 0.225 —
     # the shader clock ramps up over ~40 ms of this load.  `--steps 20 --warmup 5` therefore reads ~4 % below a 100-step run.
     gen_frames_torch(torch, NB * B, rank * NB * B, device, out=frames)
