@@ -320,7 +320,9 @@ typedef float lpt_v2f __attribute__((ext_vector_type(2)));
 #define LPT_STORE2(p, v) (*reinterpret_cast<float2 *>(p) = (v))
 #endif
 #define LPT_TW 64
+#ifndef LPT_TH
 #define LPT_TH 32
+#endif
 #define LPT_SW (LPT_TW + 12)
 #define LPT_SH (LPT_TH + 12)
 #define LPT_HW (LPT_TW + 4)
