@@ -1172,6 +1172,9 @@ static int wait_host_flag(misift_ctx *ctx, unsigned *word, unsigned seq)
   if (ctx->host_spin) {
     for (unsigned spins = 0; !seen; spins++) {
       seen = *flag == seq;
+#if defined(__x86_64__) || defined(__i386__)
+      if (!seen) __builtin_ia32_pause();                   // a polite spin: the sibling hyper-thread keeps its issue slots
+#endif
       if (!seen && (spins & 0x3fff) == 0x3fff) {           // every ~16 k polls: is the stream still alive?
         const hipError_t q = hipStreamQuery(ctx->stream);
         if (q == hipSuccess) { seen = *flag == seq; break; }
