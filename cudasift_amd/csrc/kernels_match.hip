@@ -70,14 +70,24 @@ __device__ __forceinline__ void top2_update(float sc, int p2, float &mx, float &
 
 // exact merge of two top-2 summaries of disjoint column sets (ties -> smaller column index,
 // which is what one ascending scan over the union would produce)
+// (selects, not branches: as an if/else every merge became two exec-mask regions behind its own operand wait, and the
+//  32 merges at the end of match_kernel ran as one serial chain — 4.4 us of a 24 us launch, tools/match_stamps.py)
 __device__ __forceinline__ void top2_merge(float &mx, float &sec, int &ix, float omx, float osec, int oix)
 {
-  if (omx > mx || (omx == mx && oix >= 0 && (ix < 0 || oix < ix))) {
-    const float nsec = fmaxf(mx, osec);
-    mx = omx; ix = oix; sec = nsec;
-  } else {
-    sec = fmaxf(sec, omx);
-  }
+  const bool take = (omx > mx) | ((omx == mx) & (oix >= 0) & ((ix < 0) | (oix < ix)));
+  const float sec_take = fmaxf(mx, osec), sec_keep = fmaxf(sec, omx);
+  sec = take ? sec_take : sec_keep;
+  mx = take ? omx : mx;
+  ix = take ? oix : ix;
+}
+// lane ^ 1 / lane ^ 2 within a quad: one DPP move each (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E), no LDS round trip
+template <int CTRL> __device__ __forceinline__ int quad_xchg(int v)
+{
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL> __device__ __forceinline__ float quad_xchg(float v)
+{
+  return __builtin_bit_cast(float, quad_xchg<CTRL>(__builtin_bit_cast(int, v)));
 }
 
 // One workgroup = 4 wavefronts = 128 rows of set 1; it sweeps a chunk of 64-column super-tiles of set 2.
@@ -85,6 +95,29 @@ __device__ __forceinline__ void top2_merge(float &mx, float &sec, int &ix, float
 // 64 dependent v_mfma_f32_32x32x2_f32 each, interleaved, so the 64-cycle dependent-issue latency of one
 // chain is covered by the other (and by the second wavefront resident on the SIMD).
 #define MT_SUPER 64
+#ifndef MT_A_SWAP
+#define MT_A_SWAP 1
+#endif
+#ifndef MT_STAMPS
+#define MT_STAMPS 0              // developer build (tools/variants.sh -DMT_STAMPS=1): 100 MHz time stamps, tools/match_stamps.py
+#endif
+#if MT_STAMPS
+__device__ unsigned g_mt_stamp[16];
+#define MT_STAMP_MAX(slot) do { if (threadIdx.x == 0) atomicMax(&g_mt_stamp[slot], (unsigned)wall_clock64()); } while (0)
+#define MT_STAMP_MIN(slot) do { if (threadIdx.x == 0) atomicMin(&g_mt_stamp[slot], (unsigned)wall_clock64()); } while (0)
+extern "C" int misift_debug_match_stamps(unsigned *out16)
+{
+  unsigned init[16];
+  for (int i = 0; i < 16; i++) init[i] = (i == 0 || i == 8) ? 0xffffffffu : 0u;
+  HIP_TRY(hipDeviceSynchronize());
+  if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mt_stamp), sizeof(init)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_mt_stamp), init, sizeof(init)));
+  return MISIFT_OK;
+}
+#else
+#define MT_STAMP_MAX(slot) do { } while (0)
+#define MT_STAMP_MIN(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kernel(const SiftPointD *__restrict__ pts1,
                                                        const float *__restrict__ set2, MatchGeom G,
                                                        float *__restrict__ partial)
@@ -98,6 +131,8 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
   const int chunk = item / nrb, rb = item % nrb;
   const int st0 = chunk * G.tiles_per_chunk;                       // super-tile range of this chunk
   const int st1 = min(st0 + G.tiles_per_chunk, G.ntiles);
+  MT_STAMP_MIN(0);                 // first workgroup starts
+  MT_STAMP_MAX(1);                 // last workgroup starts
 
   // ---- A fragment: row (lane&31) of this wave, k = 2t + half, t = 0..63
   const int row_local = rb * MT_ROWS_PER_BLOCK + wave * 32 + col;          // within [0,row_count)
@@ -105,12 +140,29 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
   float a[64];
   {
     const float4 *src = reinterpret_cast<const float4 *>(pts1[row_ld].data);
+#if MT_A_SWAP
+    // The two lanes of a row fetch adjacent float4s (k = 8i..8i+3 | 8i+4..8i+7) and trade the halves they do not need
+    // with v_permlane32_swap (lanes 32-63 of the first operand <-> lanes 0-31 of the second): 16 loads per lane
+    // instead of 32 of which half of every float4 was thrown away — the row fetch is the head of a small launch's
+    // critical path and bound by the texture addresser (32 cache lines per instruction: rows are 576 bytes apart).
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const float4 v = src[2 * i + half];
+      const auto xy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), false, false);
+      const auto zw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w), false, false);
+      a[4 * i + 0] = __builtin_bit_cast(float, (unsigned)xy[0]);       // k = 8i     | 8i + 1
+      a[4 * i + 1] = __builtin_bit_cast(float, (unsigned)zw[0]);       // k = 8i + 2 | 8i + 3
+      a[4 * i + 2] = __builtin_bit_cast(float, (unsigned)xy[1]);       // k = 8i + 4 | 8i + 5
+      a[4 * i + 3] = __builtin_bit_cast(float, (unsigned)zw[1]);       // k = 8i + 6 | 8i + 7
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 32; j++) {
       const float4 v = src[j];
       a[2 * j] = half ? v.y : v.x;
       a[2 * j + 1] = half ? v.w : v.z;
     }
+#endif
   }
   // ---- per-lane running top-2 for 16 rows (accumulator register r <-> row (r&3)+8*(r>>2)+4*half)
   float mx[16], sec[16];
@@ -161,9 +213,14 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
 #endif
   if (st0 < st1) {
     gload(st0);
+#if MT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MT_STAMP_MAX(2);               // rows of set 1 and the first super-tile have arrived
+#endif
     lstore(0);
   }
   __syncthreads();
+  MT_STAMP_MAX(3);                 // first super-tile staged
 #if MT_PIPE_EPILOGUE
   // Software pipeline over the super-tiles (r03): the top-2 update of tile t-1 (128 VALU instructions on its 32 finished
   // accumulator registers) is issued BETWEEN the MFMAs of tile t instead of after them, so a wavefront's matrix pipe
@@ -324,16 +381,14 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
   }
 
 #endif
+  MT_STAMP_MAX(4);                 // sweep done
   // ---- reduce the 4 residues of a class (lanes 4c..4c+3 of the same half): exact merge
 #pragma unroll
-  for (int m = 1; m <= 2; m <<= 1) {
+  for (int r = 0; r < 16; r++)
+    top2_merge(mx[r], sec[r], ix[r], quad_xchg<0xB1>(mx[r]), quad_xchg<0xB1>(sec[r]), quad_xchg<0xB1>(ix[r]));
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float omx = __shfl_xor(mx[r], m, 64), osec = __shfl_xor(sec[r], m, 64);
-      const int oix = __shfl_xor(ix[r], m, 64);
-      top2_merge(mx[r], sec[r], ix[r], omx, osec, oix);
-    }
-  }
+  for (int r = 0; r < 16; r++)
+    top2_merge(mx[r], sec[r], ix[r], quad_xchg<0x4E>(mx[r]), quad_xchg<0x4E>(sec[r]), quad_xchg<0x4E>(ix[r]));
   if ((lane & 3) == 0) {
     const int cls = col >> 2;
 #pragma unroll
@@ -347,6 +402,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
       }
     }
   }
+  MT_STAMP_MAX(5);                 // partial results stored
 }
 
 // Eight threads per row, one per class: each merges its class over the chunks (a contiguous run of 12-byte triples; r02
@@ -361,6 +417,8 @@ __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int rl = t >> 3;
   const bool live = rl < G.row_count;
+  MT_STAMP_MIN(8);
+  MT_STAMP_MAX(9);
   float m = 0.0f, sd = 0.0f;
   int ixm = -1;
   if (live) {
@@ -415,6 +473,7 @@ __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict
   // Synchronous callers (misift_match): the workgroup that draws the last ticket stores the call's sequence number in
   // pinned host memory, which the host polls instead of synchronising the stream (r04 single-call budget: ~5 us of the
   // 39 us a 2000 x 2000 MatchSiftData took).  The ticket word is left at zero for the next call.
+  MT_STAMP_MAX(10);                // rows written
   if (!host_flag) return;
   __shared__ unsigned s_last;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -424,6 +483,7 @@ __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict
   if (s_last && threadIdx.x == 0) {
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(host_flag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    MT_STAMP_MAX(11);              // flag on its way to the host
   }
 }
 
