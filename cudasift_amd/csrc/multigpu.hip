@@ -27,6 +27,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include <rccl/rccl.h>      // types and prototypes only; every call goes through the table below
 #include "common.hpp"
@@ -46,6 +47,21 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)(void);
   const char *(*GetErrorString)(ncclResult_t);
 };
+// the table is filled by dlsym (untyped): pin every slot to the prototype of the header this file was compiled against
+#define RCCL_SLOT_MATCHES(field, fn) \
+  static_assert(std::is_same<decltype(RcclApi::field), decltype(&fn)>::value, "RcclApi::" #field " != " #fn " of rccl.h")
+RCCL_SLOT_MATCHES(GetUniqueId, ncclGetUniqueId);
+RCCL_SLOT_MATCHES(CommInitRank, ncclCommInitRank);
+RCCL_SLOT_MATCHES(CommDestroy, ncclCommDestroy);
+RCCL_SLOT_MATCHES(CommCount, ncclCommCount);
+RCCL_SLOT_MATCHES(CommUserRank, ncclCommUserRank);
+RCCL_SLOT_MATCHES(AllGather, ncclAllGather);
+RCCL_SLOT_MATCHES(Send, ncclSend);
+RCCL_SLOT_MATCHES(Recv, ncclRecv);
+RCCL_SLOT_MATCHES(GroupStart, ncclGroupStart);
+RCCL_SLOT_MATCHES(GroupEnd, ncclGroupEnd);
+RCCL_SLOT_MATCHES(GetErrorString, ncclGetErrorString);
+#undef RCCL_SLOT_MATCHES
 static RcclApi g_rccl;
 static int g_rccl_state = 0;      // 0 = untried, 1 = bound, -1 = unavailable
 
