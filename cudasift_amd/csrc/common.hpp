@@ -348,6 +348,13 @@ struct misift_ctx {
   int scan_rows_small_coarse;   // ... and for the levels behind the embedded ScaleDown chain (MISIFT_SCAN_ROWS_SMALL_COARSE)
   int scan_rows_small;          // rows per scan segment for such batches (MISIFT_SCAN_ROWS_SMALL)
   int cur_binned;               // this call's per-keypoint kernels read d_det_sorted (set by misift_extract_enqueue)
+  // Batches whose frames differ in keypoint count (r04, MISIFT_BALANCE=1): the workgroups of orient_all / descr_all are
+  // dealt out in proportion to the frames' counts through a block -> (frame, sub-block, sub-blocks) table that
+  // frame_shares_kernel writes behind refine_all; off: every frame gets the same number of workgroups
+  int balance_frames;           // 1 = batches of more than small_frames frames use the table
+  int cur_balanced;             // this call's orient_all built the tables (descr_all uses the second one)
+  int4 *d_block_map;            // [map_t_orient | map_t_descr] entries
+  int block_map_cap, map_t_orient, map_t_descr;
   int want_export, exported;    // host export of the counters by the last kernel: asked for by misift_extract_sync / done
   unsigned export_seq;          // sequence number the exporting kernel stores behind the counters
   int host_spin;                // 1 = poll the exported flag instead of hipStreamSynchronize (MISIFT_HOST_SPIN=0 disables)

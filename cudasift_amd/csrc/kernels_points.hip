@@ -720,6 +720,22 @@ __global__ __launch_bounds__(256) void descr_kernel(const float *__restrict__ ba
 // The per-octave detection counts of a frame are final when these kernels run: read them ONCE per wavefront
 // into (scalar) registers instead of chasing 5-10 dependent global loads per keypoint, and keep the keypoint
 // index wave-uniform (readfirstlane) so that the level lookup in the kernel arguments is a scalar load.
+// ---- which frame a workgroup of a per-keypoint launch works on
+// Unbalanced (default): a (sub-blocks, frames) grid, every frame the same number of workgroups — a frame with three
+// times the keypoints of its neighbours finishes three times later and the batch waits for it.  Balanced (BAL): a 1-D
+// grid and a table block -> (frame, sub-block, sub-blocks of that frame) written by frame_shares_kernel, which deals
+// the workgroups out in proportion to the frames' keypoint counts.  Within a frame the keypoints are strided over its
+// sub-blocks exactly as before, so the records do not depend on the split.
+struct FrameShare { int frame, sub, nsub; };
+template <bool BAL> __device__ __forceinline__ FrameShare frame_share(const int4 *__restrict__ block_map)
+{
+  if (BAL) {
+    const int4 e = block_map[blockIdx.x];            // uniform address: one scalar load
+    return FrameShare{e.x, e.y, e.z};                // frame < 0: a spare workgroup of the launch
+  }
+  return FrameShare{(int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x};
+}
+
 struct FrameCounts {
   int ndet[MISIFT_MAX_OCTAVES + 1];           // min(count, max_pts)
   unsigned bdet[MISIFT_MAX_OCTAVES + 1];      // segment base of the octave's detections in the reference layout
@@ -1148,16 +1164,19 @@ struct alignas(16) DescrWaveLds {
   float gauss[16];
   float wtab[64];               // footprint weights wy(row) * wx(column)
 };
-template <bool Q8>
+template <bool Q8, bool BAL>
 __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch, const PyramidInfo &P,
                                                unsigned *__restrict__ counters, const Detection *__restrict__ det,
                                                SiftPointD *__restrict__ pts, int max_pts,
                                                const int *__restrict__ pack_offsets, SiftPointD *__restrict__ pack_dst,
-                                               unsigned *__restrict__ big_list, unsigned big_stride, DescrWaveLds *s_w)
+                                               unsigned *__restrict__ big_list, unsigned big_stride, DescrWaveLds *s_w,
+                                               const int4 *__restrict__ block_map)
 {
   static_assert(PATCH_FLOATS == 4 * SMP_PLANE, "the window and the four vote planes share one buffer");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int frame = blockIdx.y;
+  const FrameShare fs = frame_share<BAL>(block_map);
+  if (BAL && fs.frame < 0) return;
+  const int frame = fs.frame;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   const Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
   SiftPointD *sift = pts ? pts + (size_t)frame * max_pts : nullptr;
@@ -1170,7 +1189,7 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   if (lane < 16) s_w[wave].gauss[lane] = det_exp(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
   footprint_weights_init(s_w[wave].wtab, lane);
   // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
-  if (blockIdx.x == 0 && threadIdx.x == 0) {             // publish the reference's counters (cudaSiftD.cu:14)
+  if (fs.sub == 0 && threadIdx.x == 0) {                 // publish the reference's counters (cudaSiftD.cu:14)
     unsigned b = 0;                                      // (write-through: a workgroup on another XCD may export them)
     for (int k = 1; k <= P.noct; k++) {
       __hip_atomic_store(&cnt[2 * k - 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1180,7 +1199,7 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
       __hip_atomic_store(&cnt[2 * k + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  const int stride = gridDim.x * WAVES_PER_BLOCK;
+  const int stride = fs.nsub * WAVES_PER_BLOCK;
   // Keypoints of a frame are numbered octave after octave (coarsest first); a wavefront takes every stride-th one.
   // (octave, index) advance incrementally — the per-octave counts are re-read only when an octave is exhausted.
   auto ndet = [&](int k) -> int {
@@ -1203,7 +1222,7 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   // three-deep software pipeline over this wavefront's keypoints:
   //   Detection record of keypoint n+2 | window of keypoint n+1 (global -> registers) | keypoint n (LDS)
   int o = 1, i = 0, lim = ndet(1), o1, i1, lim1, o2, i2, lim2;
-  bool more = advance(o, i, lim, __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave));
+  bool more = advance(o, i, lim, __builtin_amdgcn_readfirstlane(fs.sub * WAVES_PER_BLOCK + wave));
   if (!more) return;
   o1 = o; i1 = i; lim1 = lim;
   bool more1 = advance(o1, i1, lim1, stride);
@@ -1381,17 +1400,19 @@ __device__ __forceinline__ bool last_workgroup(unsigned *counters)
   return s_last != 0;
 }
 
-template <bool Q8, int OCC>
+template <bool Q8, int OCC, bool BAL>
 __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                         unsigned *__restrict__ counters,
                                                         const Detection *__restrict__ det,
                                                         SiftPointD *__restrict__ pts, int max_pts, int frac8,
                                                         const int *__restrict__ pack_offsets,
                                                         SiftPointD *__restrict__ pack_dst,
-                                                        unsigned *__restrict__ big_list, unsigned big_stride)
+                                                        unsigned *__restrict__ big_list, unsigned big_stride,
+                                                        const int4 *__restrict__ block_map)
 {
   __shared__ DescrWaveLds s_w[WAVES_PER_BLOCK];
-  descr_all_body<Q8>(scratch, P, counters, det, pts, max_pts, pack_offsets, pack_dst, big_list, big_stride, s_w);
+  descr_all_body<Q8, BAL>(scratch, P, counters, det, pts, max_pts, pack_offsets, pack_dst, big_list, big_stride, s_w,
+                          block_map);
 }
 
 // The few keypoints descr_all_kernel deferred (window larger than 40x40 texels): bilinear fetches from global memory.
@@ -1421,28 +1442,78 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
   export_counters_host(counters, gridDim.y, host_out, host_seq);
 }
 
+// One workgroup.  share(f) = 1 + floor((T - nframes) * n_f / sum n): every frame keeps a workgroup (descr_all's first
+// sub-block of a frame publishes its counters), the shares add up to at most T, the rest of the table says "spare".
+__global__ __launch_bounds__(256) void frame_shares_kernel(const unsigned *__restrict__ counters, int nframes, int noct,
+                                                           int max_pts, int t_a, int4 *__restrict__ map_a, int t_b,
+                                                           int4 *__restrict__ map_b)
+{
+  __shared__ unsigned s_scan[256];
+  __shared__ unsigned long long s_total;
+  const int tid = threadIdx.x;
+  auto frame_points = [&](int f) -> unsigned {
+    unsigned n = 0;
+    for (int o = 1; o <= noct; o++) n += min(counters[(size_t)f * CNT_STRIDE + CNT_DET + o], (unsigned)max_pts);
+    return n;
+  };
+  if (tid == 0) s_total = 0ull;
+  __syncthreads();
+  unsigned long long mine = 0;
+  for (int f = tid; f < nframes; f += 256) mine += frame_points(f);
+  if (mine) atomicAdd(&s_total, mine);
+  __syncthreads();
+  const unsigned long long total = s_total;
+  for (int which = 0; which < 2; which++) {
+    const int T = which ? t_b : t_a;
+    int4 *map = which ? map_b : map_a;
+    if (T < nframes || !map) continue;                         // (the host sizes T >= 8 * nframes)
+    const unsigned long long spare = (unsigned long long)(T - nframes);
+    unsigned carry = 0;
+    for (int base = 0; base < nframes; base += 256) {
+      const int f = base + tid;
+      const unsigned share = f < nframes ? 1u + (total ? (unsigned)(spare * frame_points(f) / total) : 0u) : 0u;
+      s_scan[tid] = share;
+      __syncthreads();
+      for (int d = 1; d < 256; d <<= 1) {                       // inclusive scan of the 256 shares
+        const unsigned v = tid >= d ? s_scan[tid - d] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+      }
+      const unsigned start = carry + s_scan[tid] - share;
+      for (unsigned k = 0; k < share; k++) map[start + k] = make_int4(f, (int)k, (int)share, 0);
+      carry += s_scan[255];
+      __syncthreads();
+    }
+    for (int b = (int)carry + tid; b < T; b += 256) map[b] = make_int4(-1, 0, 0, 0);
+  }
+}
+
 // ---- the r01 forms of the two merged-octave kernels: bilinear fetches straight from global memory (no staged
 // tile), 4 waves/SIMD.  Selected with MISIFT_TILE=0 (A/B measurements).
 // 90 VGPRs: 5 waves/SIMD (the kernel is bound by the dependent LDS / shuffle chain of one keypoint per wavefront, so
 // every extra resident wavefront helps)
-template <bool Q8>
+template <bool Q8, bool BAL>
 __global__ __launch_bounds__(256, 5) void orient_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                          unsigned *__restrict__ counters,
-                                                         Detection *__restrict__ det, int max_pts, int frac8)
+                                                         Detection *__restrict__ det, int max_pts, int frac8,
+                                                         const int4 *__restrict__ block_map)
 {
   __shared__ float s_hist[WAVES_PER_BLOCK][64];
   __shared__ float s_gauss[WAVES_PER_BLOCK][16];
   __shared__ float2 s_smp[WAVES_PER_BLOCK][128];
   __shared__ float s_tgrid[WAVES_PER_BLOCK][176];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int frame = blockIdx.y;
+  const FrameShare fs = frame_share<BAL>(block_map);
+  if (BAL && fs.frame < 0) return;
+  const int frame = fs.frame;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
   const bool q8 = Q8;
   if (lane >= 57) s_smp[wave][64 + lane] = make_float2(-1.0f, 0.0f);
   const FrameCounts fc = load_frame_counts(cnt, P.noct, max_pts, false);
-  const int stride = gridDim.x * WAVES_PER_BLOCK;
-  int idx = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + wave);
+  const int stride = fs.nsub * WAVES_PER_BLOCK;
+  int idx = __builtin_amdgcn_readfirstlane(fs.sub * WAVES_PER_BLOCK + wave);
   int o, i;
   bool more = flat_to_octave(fc, P.noct, idx, o, i);
   // the next keypoint's record is fetched while the current one is processed (its ~1 us load latency was exposed
@@ -1683,14 +1754,56 @@ int launch_renumber_dups(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
   return ls.finish();
 }
 
+// Balanced batches (MISIFT_BALANCE=1): the block tables of this call's orient_all and descr_all launches, written by one
+// small kernel behind refine_all (the per-octave detection counts are final there; second orientations are done by the
+// wavefront of their keypoint, so the same counts weigh both launches).
+static int build_block_maps(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
+{
+  ctx->cur_balanced = 0;
+  if (!ctx->balance_frames || P.nframes <= ctx->small_frames || ctx->in_capture || ctx->tile_orient || !ctx->tile_descr)
+    return MISIFT_OK;
+  const int t_orient = points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu) * P.nframes;
+  const int t_descr = points_grid_x(ctx, P.nframes) * P.nframes;
+  if (ctx->block_map_cap < t_orient + t_descr) {
+    if (ctx->d_block_map) HIP_TRY(hipFree(ctx->d_block_map));
+    ctx->d_block_map = nullptr; ctx->block_map_cap = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->d_block_map, sizeof(int4) * (size_t)(t_orient + t_descr)));
+    ctx->block_map_cap = t_orient + t_descr;
+    ctx->alloc_gen++;
+  }
+  ctx->map_t_orient = t_orient; ctx->map_t_descr = t_descr;
+  LaunchScope ls(ctx, "frame_shares");
+  hipLaunchKernelGGL(frame_shares_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_counters, P.nframes, P.noct, max_pts,
+                     t_orient, ctx->d_block_map, t_descr, ctx->d_block_map + t_orient);
+  int rc = ls.finish();
+  if (rc == MISIFT_OK) ctx->cur_balanced = 1;
+  return rc;
+}
+
 int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts)
 {
   (void)pts;
+  {
+    int rc = build_block_maps(ctx, P, max_pts);
+    if (rc) return rc;
+  }
   LaunchScope ls(ctx, "orient_all");
   Detection *det = ctx->cur_binned ? ctx->d_det_sorted : ctx->d_det;
   const dim3 grid(points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu), P.nframes);
+  const bool q8 = ctx->opt.texfrac_bits == 8;
   if (ctx->tile_orient) LAUNCH_Q8(orient_all_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
-  else LAUNCH_Q8(orient_all_gather_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
+  else if (ctx->cur_balanced) {
+    const dim3 flat(ctx->map_t_orient);
+    if (q8) hipLaunchKernelGGL((orient_all_gather_kernel<true, true>), flat, dim3(256), 0, ctx->stream, scratch, P,
+                               ctx->d_counters, det, max_pts, 0, ctx->d_block_map);
+    else hipLaunchKernelGGL((orient_all_gather_kernel<false, true>), flat, dim3(256), 0, ctx->stream, scratch, P,
+                            ctx->d_counters, det, max_pts, 0, ctx->d_block_map);
+  } else {
+    if (q8) hipLaunchKernelGGL((orient_all_gather_kernel<true, false>), grid, dim3(256), 0, ctx->stream, scratch, P,
+                               ctx->d_counters, det, max_pts, 0, (const int4 *)nullptr);
+    else hipLaunchKernelGGL((orient_all_gather_kernel<false, false>), grid, dim3(256), 0, ctx->stream, scratch, P,
+                            ctx->d_counters, det, max_pts, 0, (const int4 *)nullptr);
+  }
   return ls.finish();
 }
 
@@ -1711,11 +1824,17 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
       ctx->export_seq++;
       ctx->exported = 1;
     }
-#define DESCR_LAUNCH(Q, O) hipLaunchKernelGGL((descr_all_kernel<Q, O>), grid, dim3(256), 0, ctx->stream, scratch, P, ctx->d_counters, \
-                                              det, pts, max_pts, 0, pack_offsets, pack_dst, ctx->d_cand, big_stride)
+    const bool bal = ctx->cur_balanced != 0;
+    const dim3 dgrid = bal ? dim3(ctx->map_t_descr) : grid;
+    const int4 *bmap = bal ? ctx->d_block_map + ctx->map_t_orient : nullptr;
+#define DESCR_LAUNCH(Q, O, B) hipLaunchKernelGGL((descr_all_kernel<Q, O, B>), dgrid, dim3(256), 0, ctx->stream, scratch, P, \
+                                                 ctx->d_counters, det, pts, max_pts, 0, pack_offsets, pack_dst, ctx->d_cand, \
+                                                 big_stride, bmap)
+#define DESCR_LAUNCH_B(Q, O) do { if (bal) DESCR_LAUNCH(Q, O, true); else DESCR_LAUNCH(Q, O, false); } while (0)
     const bool q8 = ctx->opt.texfrac_bits == 8;
-    if (ctx->descr_occ >= 4) { if (q8) DESCR_LAUNCH(true, 4); else DESCR_LAUNCH(false, 4); }
-    else { if (q8) DESCR_LAUNCH(true, 3); else DESCR_LAUNCH(false, 3); }
+    if (ctx->descr_occ >= 4) { if (q8) DESCR_LAUNCH_B(true, 4); else DESCR_LAUNCH_B(false, 4); }
+    else { if (q8) DESCR_LAUNCH_B(true, 3); else DESCR_LAUNCH_B(false, 3); }
+#undef DESCR_LAUNCH_B
 #undef DESCR_LAUNCH
     // (r04 tried folding this launch into descr_all's last workgroup by ticket: a thousand same-address tickets and the
     //  extra registers cost more than the 4 us dispatch — profiles/r04_single_call_sweep_step4.txt)

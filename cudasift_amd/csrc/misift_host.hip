@@ -351,6 +351,8 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_BIN_MIN_FRAMES")) ctx->bin_min_frames = atoi(e);
   ctx->small_frames = 4;
   if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
+  ctx->balance_frames = 0;       // (off until a full GPU suite + bench A/B has run on it: DESIGN.md section 8)
+  if (const char *e = getenv("MISIFT_BALANCE")) ctx->balance_frames = atoi(e) != 0;
   ctx->lowpass_tile = 1;
   if (const char *e = getenv("MISIFT_LOWPASS_TILE")) ctx->lowpass_tile = atoi(e) != 0;
   ctx->strip_rows_small = 6;
@@ -544,6 +546,7 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   if (ctx->d_cand) hipFree(ctx->d_cand);
   if (ctx->d_det) hipFree(ctx->d_det);
   if (ctx->d_det_sorted) hipFree(ctx->d_det_sorted);
+  if (ctx->d_block_map) hipFree(ctx->d_block_map);
   if (ctx->d_own_scratch) hipFree(ctx->d_own_scratch);
   if (ctx->d_match_tmp) hipFree(ctx->d_match_tmp);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -1117,6 +1120,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     //  nothing — the keypoints of one frame share the caches anyway)
     const bool binned = (ctx->bin_detections && nframes >= ctx->bin_min_frames) || ctx->opt.deterministic;
     ctx->cur_binned = binned ? 1 : 0;
+    ctx->cur_balanced = 0;              // set by launch_orient_all when it builds the block tables
     if (binned) {                       // spatial order for the per-keypoint kernels (L1/L2 reuse between neighbours);
       rc = launch_bin_detections(ctx, P, max_pts);      // deterministic mode: a total order
       if (rc) return rc;

@@ -808,6 +808,55 @@ def test_timed_path_16x1080p_packed_async_vs_oracle(ctx):
         assert _canon(recs[offs[f]:offs[f + 1]]) == _canon(recs2[offs[f]:offs[f + 1]]), f
 
 
+def test_balanced_keypoint_launches_on_a_skewed_batch(ctx):
+    """MISIFT_BALANCE=1: the workgroups of orient_all / descr_all are dealt out in proportion to the frames' keypoint
+    counts (frame_shares_kernel writes a block -> (frame, sub-block, sub-blocks) table behind refine_all) instead of the same
+    number per frame.  A batch of eight frames from a busy one down to an empty one must come out record for record as
+    from the plain launch, and equal to the oracle."""
+    import os
+    from cudasift_amd import capi
+    from synth import SYNTH_AMP
+    w, h, mp = 640, 360, 8192
+    amps = [3.0, 1.0, 1.5, 0.8, 0.6, 0.0, 2.0, 0.5]             # oracle: 7224, 207, 1654, 28, 3, 0, 4405, 0 keypoints
+    frames = np.stack([synth_frame(9100 + i, w, h, amp=SYNTH_AMP * a) for i, a in enumerate(amps)])
+    was_fused = ctx.get_options().fused
+    ctx.set_options(fused=1)
+    try:
+        pts_u, n_u = ctx.extract_batch(frames, num_octaves=5, thresh=3.0, max_pts=mp)
+    finally:
+        ctx.set_options(fused=was_fused)
+    saved = os.environ.get("MISIFT_BALANCE")
+    os.environ["MISIFT_BALANCE"] = "1"
+    try:
+        c2 = capi.Context(0)
+    finally:
+        if saved is None:
+            del os.environ["MISIFT_BALANCE"]
+        else:
+            os.environ["MISIFT_BALANCE"] = saved
+    try:
+        c2.set_options(fused=1)
+        c2.profile_enable(True)
+        pts_b, n_b = c2.extract_batch(frames, num_octaves=5, thresh=3.0, max_pts=mp)
+        prof = c2.profile_read()
+        assert prof["frame_shares"]["calls"] == 1                        # the premise: the table was built and used
+        # ... and batches of a frame or two keep the plain launch (single-call path)
+        c2.profile_reset()
+        c2.extract_batch(frames[:2], num_octaves=5, thresh=3.0, max_pts=mp)
+        assert "frame_shares" not in c2.profile_read()
+    finally:
+        c2.close()
+    assert np.array_equal(n_u, n_b), (n_u, n_b)
+    assert n_u[5] == 0 and n_u[0] > 4 * n_u[1] > 0, n_u                   # skewed indeed, one frame empty
+    for f in range(len(amps)):
+        assert _canon(pts_u[f, :n_u[f]]) == _canon(pts_b[f, :n_b[f]]), f
+    ref, nref, _ = orc().extract_batch(frames, num_octaves=5, init_blur=1.0, thresh=3.0, max_pts=mp)
+    assert np.array_equal(n_b, nref), (n_b, nref)
+    for f in range(len(amps)):
+        compare_points(ref[f, :nref[f]], pts_b[f, :n_b[f]], "balanced_f%d" % f, record)
+    record("balanced_skewed_batch", frames=len(amps), keypoints=[int(x) for x in n_b])
+
+
 def test_three_contexts_in_flight_equal_one_context(ctx):
     """`bench.py --contexts K` / INTEGRATION.md section 5: one context per batch in flight.  Three contexts (own stream,
     staging and scratch arena each) get six batches queued round-robin with nothing synchronising in between — their
