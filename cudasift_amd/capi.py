@@ -85,6 +85,7 @@ SIGNATURES = {
     "misift_test_elementary": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i]),
     "misift_test_match_split": (_i, [_vp, _vp, _i, _vp, _i, _i, _i]),
     "misift_test_match_plan": (_i, [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "misift_test_frame_shares": (_i, [_i, _i, C.c_void_p, C.c_void_p]),
     "misift_comm_unique_id": (_i, [_vp]),
     "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "misift_comm_adopt": (_i, [_vp, _vp, C.POINTER(_vp)]),

@@ -1442,8 +1442,25 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
   export_counters_host(counters, gridDim.y, host_out, host_seq);
 }
 
-// One workgroup.  share(f) = 1 + floor((T - nframes) * n_f / sum n): every frame keeps a workgroup (descr_all's first
-// sub-block of a frame publishes its counters), the shares add up to at most T, the rest of the table says "spare".
+// share(f) = 1 + floor((T - nframes) * n_f / sum n): every frame keeps a workgroup (descr_all's first sub-block of a
+// frame publishes its counters), the shares add up to at most T, the rest of the table says "spare".
+__host__ __device__ static inline unsigned keypoint_share(unsigned long long spare, unsigned long long n,
+                                                          unsigned long long total)
+{
+  return 1u + (total ? (unsigned)(spare * n / total) : 0u);
+}
+// host-only test hook (no device needed): the shares frame_shares_kernel gives `nframes` frames with points[f] keypoints
+// out of `nblocks` workgroups
+extern "C" int misift_test_frame_shares(int nblocks, int nframes, const unsigned *points, int *shares)
+{
+  if (!points || !shares || nframes < 1 || nblocks < nframes) return MISIFT_EINVAL;
+  unsigned long long total = 0;
+  for (int f = 0; f < nframes; f++) total += points[f];
+  for (int f = 0; f < nframes; f++)
+    shares[f] = (int)keypoint_share((unsigned long long)(nblocks - nframes), points[f], total);
+  return MISIFT_OK;
+}
+// One workgroup.
 __global__ __launch_bounds__(256) void frame_shares_kernel(const unsigned *__restrict__ counters, int nframes, int noct,
                                                            int max_pts, int t_a, int4 *__restrict__ map_a, int t_b,
                                                            int4 *__restrict__ map_b)
@@ -1471,7 +1488,7 @@ __global__ __launch_bounds__(256) void frame_shares_kernel(const unsigned *__res
     unsigned carry = 0;
     for (int base = 0; base < nframes; base += 256) {
       const int f = base + tid;
-      const unsigned share = f < nframes ? 1u + (total ? (unsigned)(spare * frame_points(f) / total) : 0u) : 0u;
+      const unsigned share = f < nframes ? keypoint_share(spare, frame_points(f), total) : 0u;
       s_scan[tid] = share;
       __syncthreads();
       for (int d = 1; d < 256; d <<= 1) {                       // inclusive scan of the 256 shares

@@ -430,6 +430,11 @@ int misift_test_match_split(misift_ctx *ctx, void *d_pts1, int n1, const void *d
 /* Test-only, host-only (no device needed): the matcher's column-chunk plan for n1 x n2 on a chip of num_cus CUs. */
 int misift_test_match_plan(int num_cus, int n1, int n2, int *nchunks, int *tiles_per_chunk, int *ntiles);
 
+/* Test-only, host-only: how the balanced per-keypoint launches (MISIFT_BALANCE=1) split `nblocks` workgroups among
+ * `nframes` frames holding points[f] keypoints: shares[f] = 1 + floor((nblocks - nframes) * points[f] / sum), the formula
+ * frame_shares_kernel evaluates on the device.  nblocks >= nframes. */
+int misift_test_frame_shares(int nblocks, int nframes, const unsigned *points, int *shares);
+
 /* ------------------------------------------------------------------- timing */
 
 /* TimerGPU (cudautils.h:61-81): event pair on the context stream. */

@@ -151,6 +151,42 @@ def test_header_is_plain_c99(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_frame_shares_of_the_balanced_keypoint_launches():
+    """misift_test_frame_shares (host-only; the formula frame_shares_kernel evaluates on the device, MISIFT_BALANCE=1):
+    every frame keeps at least one workgroup (the first sub-block of a frame publishes its counters), the shares never add
+    up to more than the launch has, they follow the keypoint counts, and equal counts get equal shares."""
+    from cudasift_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(11)
+
+    def shares(nblocks, pts):
+        pts = np.ascontiguousarray(pts, np.uint32)
+        out = np.zeros(len(pts), np.int32)
+        assert L.misift_test_frame_shares(nblocks, len(pts), pts.ctypes.data, out.ctypes.data) == 0
+        return out
+
+    cases = [(2048, [2000] * 64), (2048, [0] * 64), (512, [30000] + [0] * 63), (1280, [16709] + [250] * 63),
+             (8, [5]), (64, [0, 1, 2, 3, 4, 5, 6, 7]), (8 * 300, list(rng.integers(0, 40000, 300))),
+             (4096, [163840] * 512), (1024, [1] + [0] * 127)]
+    cases += [(int(n * rng.integers(8, 40)), list(rng.integers(0, 5 * 32768, n) * (rng.random(n) < 0.7)))
+              for n in rng.integers(5, 600, 100)]
+    for nblocks, pts in cases:
+        pts = np.array(pts, np.uint64)
+        s = shares(nblocks, pts)
+        assert s.min() >= 1 and s.sum() <= nblocks, (nblocks, s.sum())
+        total = int(pts.sum())
+        if total:
+            spare = nblocks - len(pts)
+            assert np.array_equal(s, 1 + (spare * pts) // total)          # the documented formula, exactly
+            assert s.sum() > nblocks - len(pts)                           # at most one workgroup per frame left unused
+            order = np.argsort(pts, kind="stable")
+            assert np.all(np.diff(s[order]) >= 0)                         # more keypoints, never fewer workgroups
+        else:
+            assert np.all(s == 1)
+    assert L.misift_test_frame_shares(3, 4, np.zeros(4, np.uint32).ctypes.data, np.zeros(4, np.int32).ctypes.data) != 0
+    assert L.misift_test_frame_shares(8, 0, None, None) != 0
+
+
 def test_matcher_chunk_plan_properties():
     """misift_test_match_plan (host-only): the column-chunk plan of the matcher covers every super-tile exactly once, has
     no empty chunk, survives degenerate shapes (n2 < 32: no column takes part; the division by zero of an earlier
