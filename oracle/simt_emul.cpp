@@ -325,6 +325,12 @@ float tex_fetch(const Texture *t, float x, float y)
 // ------------------------------------------------------------------------------------------------ runtime API
 // Every allocation gets a zeroed 4 KiB front pad: the reference reads sift2[-1] when a row has no match
 // (matching.cu:393-394) and the emulation must survive what the hardware survives.
+// The payload is filled with 0xFF bytes (a NaN as float, -1 as int): the reference also reads memory it never wrote —
+// FindHomography hands TestHomographies numPtsUp = 16 * ceil(numPts / 16) points of which only numPts were copied
+// (matching.cu:1021-1064) — and with whatever the heap held there the emulated reference was not a function of its
+// inputs (a freed d_coord of an earlier call put real coordinates behind the 8 points of a later one: 6 inliers
+// instead of 5, one CPU run in ten).  NaN coordinates never pass the inlier test, i.e. the padding counts for nothing,
+// which is what the oracle and homography.hip implement (deliberate deviations).
 namespace {
 constexpr size_t PAD = 4096;
 cudaError_t last_error = cudaSuccess;
@@ -332,9 +338,11 @@ cudaError_t last_error = cudaSuccess;
 
 cudaError_t cudaMalloc(void **p, size_t bytes)
 {
-  char *raw = (char *)aligned_alloc(4096, (bytes + 2 * PAD + 4095) / 4096 * 4096);
+  const size_t total = (bytes + 2 * PAD + 4095) / 4096 * 4096;
+  char *raw = (char *)aligned_alloc(4096, total);
   if (!raw) { *p = nullptr; return last_error = cudaErrorMemoryAllocation; }
   memset(raw, 0, PAD);
+  memset(raw + PAD, 0xFF, total - PAD);
   *p = raw + PAD;
   return cudaSuccess;
 }
