@@ -211,3 +211,18 @@ def test_matcher_chunk_plan_properties():
                 if nrb * nt >= 40 * cus and nrb > 0:          # enough work for the quantisation to be a detail
                     rounds = -(-nrb * nch // cus)
                     assert rounds * tpc <= 1.05 * nrb * nt / cus + tpc, (n1, n2, cus, nch, tpc)
+
+
+def test_every_environment_knob_of_the_library_is_documented():
+    """Each getenv("MISIFT_...") in csrc/ is named in README.md, INTEGRATION.md or include/misift.h."""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    knobs = set()
+    for src in (root / "cudasift_amd" / "csrc").iterdir():
+        if src.suffix in (".hip", ".cpp", ".hpp"):
+            text = src.read_text()
+            knobs |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', text))
+            knobs |= set(re.findall(r'match_plan_param\("([A-Z_0-9]+)"', text))
+    docs = "".join((root / f).read_text() for f in ("README.md", "INTEGRATION.md", "include/misift.h"))
+    missing = sorted(k for k in knobs if k not in docs)
+    assert len(knobs) > 20 and not missing, missing
