@@ -15,7 +15,7 @@ HIPOBJS  := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(HIPSRCS))
 
 all: cudasift_amd/libmisift.so cudasift_amd/libcudasift.so cudasift_amd/libcudasift_managed.so oracle dropin build/pmc_calib build/valu_rates build/scan_rates build/single_call
 
-$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/misift.h
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/chain.hpp include/misift.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

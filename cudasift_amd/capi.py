@@ -43,6 +43,8 @@ SIGNATURES = {
     "misift_ctx_set_stream": (_i, [_vp, _vp]),
     "misift_ctx_set_graph_replay": (_i, [_vp, _i]),
     "misift_ctx_sync": (_i, [_vp]),
+    "misift_ctx_set_early_return": (_i, [_vp, _i]),
+    "misift_ctx_chain_fallbacks": (_i, [_vp]),
     "misift_last_error": (C.c_char_p, []),
     "misift_default_options": (None, [C.POINTER(Options)]),
     "misift_set_options": (_i, [_vp, C.POINTER(Options)]),
@@ -225,6 +227,13 @@ class Context:
     def wait_batch(self, stream):
         """Make `stream` (a raw hipStream_t value) wait for the most recently enqueued batch of this context."""
         check(lib().misift_ctx_wait_batch(self.h, stream), "misift_ctx_wait_batch")
+
+    def set_early_return(self, on=True):
+        """Synchronous calls return at the last kernel's completion flag instead of after a stream synchronisation."""
+        check(lib().misift_ctx_set_early_return(self.h, int(on)), "misift_ctx_set_early_return")
+
+    def chain_fallbacks(self):
+        return lib().misift_ctx_chain_fallbacks(self.h)
 
     def sync(self):
         check(lib().misift_ctx_sync(self.h), "misift_ctx_sync")

@@ -22,6 +22,7 @@
 #define CNT_CAND   20         // CNT_CAND + octave : candidate count of that octave
 #define CNT_CANDOVF 28        // candidates dropped because the list was full
 #define CNT_PTOVF  29         // points dropped because maxPts was reached
+#define CNT_CHAINTMO 30       // frame 0's block only: workgroups whose bounded wait for the embedded chain expired (dog_scan_all_kernel)
 #define CNT_DET    32         // CNT_DET + octave : detections of that octave (merged-octave pipeline)
 #define CNT_DUP    40         // CNT_DUP + octave : second-orientation duplicates of that octave
 #define CNT_SPARE_BLOCKS 9    // counter blocks behind the last frame's: flags and ticket words of the call (dog_scan_all_kernel)
@@ -280,7 +281,7 @@ __device__ __forceinline__ float tex2d(const float *img, int w, int h, int pitch
     const int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
     // The two texels of a row are adjacent except at the clamped image edges: fetch them with ONE 8-byte load at
     // column xl (4-byte aligned is enough on gfx950) and pick.
-    const int xl = clampi(ix, 0, w - 2);
+    const int xl = clampi(ix, 0, w > 1 ? w - 2 : 0);        // (a 1-px-wide level: both texels are column 0)
     const Pair2 r0 = *reinterpret_cast<const Pair2 *>(base + (__umul24((unsigned)y0, (unsigned)pitch) + (unsigned)xl) * 4u);
     const Pair2 r1 = *reinterpret_cast<const Pair2 *>(base + (__umul24((unsigned)y1, (unsigned)pitch) + (unsigned)xl) * 4u);
     const bool lo0 = x0 == xl, hi1 = x1 == xl + 1;
@@ -341,6 +342,8 @@ struct misift_ctx {
   // small batches / the single-call path (r04): bound by dependent dispatches, so fewer and wider launches
   int chain_max_frames;         // <= this many frames: coarse ScaleDowns as chained launches (MISIFT_CHAIN_FRAMES)
   int chain_embed;              // 1 = that chain runs inside the scan launch when one chain covers all levels (MISIFT_CHAIN_EMBED)
+  unsigned chain_wait_ticks;    // bound of the in-launch wait for that chain, 100 MHz ticks (MISIFT_CHAIN_WAIT_US; default 100 ms)
+  int chain_fallbacks;          // calls re-run with a stand-alone chain launch because the bound expired (misift_ctx_chain_fallbacks)
   int bin_min_frames;           // >= this many frames: bin_detections runs (MISIFT_BIN_MIN_FRAMES)
   int small_frames;             // <= this many frames: short scan segments, wide refine / per-keypoint grids (MISIFT_SMALL_FRAMES)
   int lowpass_tile;             // 1 = such batches: the LDS-tiled prefilter + first ScaleDown (MISIFT_LOWPASS_TILE)

@@ -820,6 +820,7 @@ struct ScanOct {
 struct ScanAllGeom {
   int nlev, nframes;
   int wait_lev;                               // CHAIN: levels (index into o[]) from here on wait for the embedded chain
+  unsigned wait_ticks;                        // CHAIN: the wait gives up after this many ticks of the 100 MHz wall clock
   long long frame_stride, total_items;
   unsigned cand_stride;                       // candidate words per frame (all octaves)
   ScanOct o[MISIFT_MAX_OCTAVES];              // o[0] = finest level: the long items are dispatched first
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   unsigned lb = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
+  bool chain_failed = false;
 #if SCAN_RING
   if (CHAIN) {
 #if SCAN_STAMPS
@@ -874,7 +876,11 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
       scaledown_chain_block(const_cast<float *>(scratch), C, k5, (int)(lb % tiles), (int)(lb / tiles),
                             reinterpret_cast<float *>(&s_win[0][0]));
       // the chain's stores are write-through (chain.hpp): once they have been acknowledged they are in memory, where
-      // every XCD finds them — no L2 write-back (an agent-scope release fence per workgroup: +45 us per frame, r04)
+      // every XCD finds them — no L2 write-back (an agent-scope release fence per workgroup: +45 us per frame, r04).
+      // "Once they have been acknowledged" is THIS wait: the workgroup-scope fence compiles to s_waitcnt lgkmcnt(0) only,
+      // and without vmcnt(0) the ticket below could overtake the stores (advisor r04: global_store ... sc1 -> s_barrier ->
+      // global_atomic_add with no wait in between).  Each wavefront waits for its own stores; cheap.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
       STAMP_MAX(9);
@@ -888,8 +894,8 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
         const unsigned sub = lb & 15u, members = ((unsigned)nchain - sub + 15u) / 16u;
         if (atomicAdd(&spare[64 + 32 * sub], 1u) == members - 1u) {
           const unsigned nsub = (unsigned)nchain < 16u ? (unsigned)nchain : 16u;
-          if (atomicAdd(&spare[32], 1u) == nsub - 1u) {
-            __hip_atomic_fetch_or(&spare[0], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (atomicAdd(&spare[32], 1u) == nsub - 1u && G.wait_ticks != 0u) {     // (a bound of 0 = the fallback's test: the
+            __hip_atomic_fetch_or(&spare[0], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    //  flag is never raised)
             STAMP_MAX(18);
           }
         }
@@ -901,24 +907,37 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
     // a workgroup that holds an item of a coarse level waits for the flag: ONE lane polls, the others sit at the barrier
     if (G.wait_lev < G.nlev && (long long)lb * WAVES_PER_BLOCK + (WAVES_PER_BLOCK - 1) >= G.o[G.wait_lev].item_begin) {
       STAMP_MAX(15);
-      if (threadIdx.x == 0)
+      __shared__ unsigned s_chain_ok;
+      if (threadIdx.x == 0) {
         // (a read-modify-write: it is performed at the memory side.  An agent-scope atomic LOAD may be served from this
         //  XCD's L2, which is not coherent with the other XCDs' — the first poll caches the line and the loop then spins on
         //  the stale copy until it happens to be evicted: 40 us, measured with SCAN_STAMPS)
         //  — and an add of ZERO is folded into such a load by the compiler: every poll adds one, the flag is the top bit)
+        // BOUNDED: forward progress rests on the chain workgroups (lowest block ids) having been dispatched before the
+        // ones that wait for them.  Should that ever fail (a partition mode, a debugger, a future dispatcher), the wait
+        // gives up after `wait_ticks` of the 100 MHz clock, the workgroup skips its items and raises CNT_CHAINTMO in
+        // frame 0's counter block; the host sees it with the counts and re-runs the call with a stand-alone chain launch.
+        const unsigned long long t0 = wall_clock64();
+        unsigned ok = 1u;
         while ((__hip_atomic_fetch_add(&counters[(size_t)G.nframes * CNT_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
-                0x80000000u) == 0u)
+                0x80000000u) == 0u) {
+          if (wall_clock64() - t0 > (unsigned long long)G.wait_ticks) { ok = 0u; break; }
           __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) atomicAdd(&counters[CNT_CHAINTMO], 1u);
+        s_chain_ok = ok;
+      }
       __syncthreads();
       STAMP_MAX(13);
       // nothing of the coarse levels can be in this XCD's L2 yet (caches are invalidated at kernel start and only
       // wavefronts behind this wait read those levels): a compiler-level acquire is all that is needed
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      chain_failed = s_chain_ok == 0u;             // workgroup-uniform
     }
   }
 #endif
   long long item = (long long)lb * WAVES_PER_BLOCK + wave;
-  const bool valid = item < G.total_items;       // (no early return: scan_queue_finish is a workgroup barrier)
+  const bool valid = item < G.total_items && !chain_failed;      // (no early return: scan_queue_finish is a workgroup barrier)
   __shared__ unsigned s_cq[WAVES_PER_BLOCK][CQ_CAP];
   unsigned qn = 0;
   unsigned *cnt = nullptr, *list = nullptr;
@@ -1440,6 +1459,7 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
     for (int j = 0; j < 5; j++) t5.k[j] = k5[j];
     nchain = C.tiles_x * C.tiles_y * P.nframes;
     G.wait_lev = 0;                                        // (source not among the scanned levels: everything waits)
+    G.wait_ticks = ctx->chain_wait_ticks;
     for (int k = 0; k < G.nlev; k++)
       if (G.o[k].img_off == C.lv[0].off) G.wait_lev = k + 1;
   }

@@ -476,6 +476,8 @@ __global__ __launch_bounds__(256) void match_merge_kernel(SiftPointD *__restrict
   MT_STAMP_MAX(10);                // rows written
   if (!host_flag) return;
   __shared__ unsigned s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // vmcnt(0): this wavefront's row stores are acknowledged BEFORE the ticket is
+                                             // drawn (the workgroup-scope fence alone waits for lgkmcnt only; advisor r04)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;

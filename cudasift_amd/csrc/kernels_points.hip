@@ -1393,6 +1393,10 @@ __device__ __forceinline__ void export_counters_host(const unsigned *counters, u
 __device__ __forceinline__ bool last_workgroup(unsigned *counters)
 {
   __shared__ unsigned s_last;
+  // The ordering below RESTS on this wait: a workgroup-scope release fence compiles to s_waitcnt lgkmcnt(0) only, and the
+  // ticket must not be drawn before every store of this wavefront has been ACKNOWLEDGED (each wavefront waits for its own;
+  // no L2 write-back) — else the host could be told "done" with records still in flight (advisor r04).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (inline asm: invisible to the pass that drops waits)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this workgroup's stores have left the CU
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(counters + CNT_TICKET, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;

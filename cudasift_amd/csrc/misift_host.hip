@@ -347,6 +347,8 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_CHAIN_FRAMES")) ctx->chain_max_frames = atoi(e);
   ctx->chain_embed = 1;
   if (const char *e = getenv("MISIFT_CHAIN_EMBED")) ctx->chain_embed = atoi(e) != 0;
+  ctx->chain_wait_ticks = 10000000u;          // 100 ms of the 100 MHz wall clock: ~4 orders of magnitude above the chain's own time
+  if (const char *e = getenv("MISIFT_CHAIN_WAIT_US")) ctx->chain_wait_ticks = (unsigned)(atof(e) * 100.0);
   ctx->bin_min_frames = 4;
   if (const char *e = getenv("MISIFT_BIN_MIN_FRAMES")) ctx->bin_min_frames = atoi(e);
   ctx->small_frames = 4;
@@ -362,7 +364,10 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL_COARSE")) ctx->scan_rows_small_coarse = atoi(e) > 0 ? atoi(e) : 2;
   ctx->scan_rows_small = 4;
   if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL")) ctx->scan_rows_small = atoi(e) > 0 ? atoi(e) : 4;
-  ctx->host_spin = 1;
+  // 0 = a synchronous call returns after hipStreamSynchronize (everything the call wrote is complete and visible to any
+  // stream, device or host copy: the reference's contract).  1 = it returns as soon as the last kernel's flag reaches
+  // pinned host memory (opt-in: misift_ctx_set_early_return; the cudaSift.h shim does, its read-back is same-stream).
+  ctx->host_spin = 0;
   if (const char *e = getenv("MISIFT_HOST_SPIN")) ctx->host_spin = atoi(e) != 0;
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
@@ -479,6 +484,15 @@ extern "C" int misift_ctx_set_batches_in_flight(misift_ctx *ctx, int k)
   x->lane_done.swap(done);
   return MISIFT_OK;
 }
+
+extern "C" int misift_ctx_set_early_return(misift_ctx *ctx, int on)
+{
+  ARG_CHECK(ctx != nullptr);
+  if (!getenv("MISIFT_HOST_SPIN")) ctx->host_spin = on ? 1 : 0;     // the environment has the last word (A/B runs)
+  return MISIFT_OK;
+}
+
+extern "C" int misift_ctx_chain_fallbacks(misift_ctx *ctx) { return ctx ? ctx->chain_fallbacks : -1; }
 
 extern "C" int misift_ctx_get_batches_in_flight(misift_ctx *ctx)
 {
@@ -909,6 +923,17 @@ int launch_selftest(misift_ctx *ctx)
 // -------------------------------------------------------------- extraction
 struct Level { int w, h, p; float *img; };   // img = frame-0 pointer of that pyramid level
 
+// Images under 16 x 16, or whose coarsest pyramid level is under 8 px: the reference runs them (levels shrink to a few
+// pixels, every access clamped: cudaSiftH.cu:72-167) and so do we — on the dense per-level kernels, whose quad loads clamp
+// at any width >= 1.  The merged-octave kernels (tiled prefilter, cone chain, strips sized for whole wavefronts) are
+// built for images that fill at least a strip and never see such calls.  A level that integer division has shrunk to
+// 0 pixels holds nothing and is skipped (CUDA itself refuses a zero-sized grid there).
+bool misift_tiny_call(int width, int height, int num_octaves)
+{
+  if (num_octaves < 1) return false;
+  return width < 16 || height < 16 || (width >> (num_octaves - 1)) < 8 || (height >> (num_octaves - 1)) < 8;
+}
+
 // Enqueue the whole launch sequence of one batch on the context stream (no synchronisation).
 // d_imgs: fp32 frames, or 8-bit frames when src_u8 (pitch / frame_stride in source elements).
 int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride,
@@ -919,9 +944,10 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   ARG_CHECK(ctx && d_imgs && (pts || (ctx->pack_dst && ctx->opt.fused)));
   extra(ctx)->last_lane = nullptr;      // this batch runs on the context itself: its counters / stream are the results'
   extra(ctx)->last_done = nullptr;
-  ARG_CHECK(nframes >= 1 && width >= 16 && height >= 16 && pitch >= width);
+  ARG_CHECK(nframes >= 1 && width >= 1 && height >= 1 && pitch >= width);
   ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);       // before the shifts below
-  ARG_CHECK((width >> (num_octaves - 1)) >= 8 && (height >> (num_octaves - 1)) >= 8);
+  const bool tiny = misift_tiny_call(width, height, num_octaves);
+  ARG_CHECK(!(tiny && ctx->opt.fused));        // the entry points route tiny calls to the dense kernels (TinyScope)
   ARG_CHECK(max_pts >= 1);
   ARG_CHECK(width * (scale_up ? 2 : 1) < 16384 && height * (scale_up ? 2 : 1) < 16384);
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1070,11 +1096,14 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   // --- pyramid (ScaleDown chain of cudaSiftH.cu:153-160), finest to coarsest
   // Small batches (a single frame above all) are bound by the number of DEPENDENT dispatches, not by their work: up to
   // three levels per launch (scaledown_chain_kernel).  Batches keep one streamed launch per level.
-  const bool chained = !scanned && nframes <= ctx->chain_max_frames;
+  const bool chained = !scanned && !tiny && nframes <= ctx->chain_max_frames;
   // ... and when ONE chain covers every remaining level, it rides in the first workgroups of the scan launch
   ChainGeom embed;
   bool embedded = false;
-  if (chained && ctx->opt.fused && ctx->chain_embed && first_down_done && num_octaves >= 3 && num_octaves - 2 <= 3) {
+  // (only where the host reads the counter blocks afterwards — the synchronous calls: that is where an expired wait is
+  //  noticed and the call re-run, see read_counts)
+  if (chained && ctx->opt.fused && ctx->chain_embed && ctx->want_export && first_down_done && num_octaves >= 3 &&
+      num_octaves - 2 <= 3) {
     const int o = num_octaves - 1, nlev = o - 1;
     int dims[4][3];
     long long offs[4];
@@ -1102,6 +1131,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
       continue;
     }
     const Level &src = lv[o], &dst = lv[o - 1];
+    if (dst.w < 1 || dst.h < 1) break;                 // nothing left to decimate: this and every coarser level is empty
     StripGeom g = make_geom(ctx, src.w, src.h, src.p, nframes, SS, dst.w, dst.h, 62);
     rc = launch_scaledown(ctx, src.img, g, dst.img, dst.p, SS, k5);
     if (rc) return rc;
@@ -1140,6 +1170,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   // --- octaves, coarsest first (cudaSiftH.cu:161 after the recursion)
   for (int o = 1; o <= num_octaves; o++) {
     const Level &L = lv[o];
+    if (L.w < 1 || L.h < 1) continue;                  // an empty level: no pixels, no points (counters stay where they are)
     const float subsampling = (float)(1 << (num_octaves - o));
     const LaplaceTaps taps = octave_taps(table, o);
     {
@@ -1199,6 +1230,7 @@ static int wait_host_flag(misift_ctx *ctx, unsigned *word, unsigned seq)
   return MISIFT_OK;
 }
 
+#define MISIFT_RETRY_CHAIN 1000      // internal to this file: never returned to a caller
 static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *num_pts_out,
                        bool *cand_overflow)
 {
@@ -1211,6 +1243,7 @@ static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pt
                            hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
+  if (ctx->h_counters[CNT_CHAINTMO]) return MISIFT_RETRY_CHAIN;      // dog_scan_all_kernel: the bounded in-launch wait expired
   const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
   for (int f = 0; f < nframes; f++) {
     const unsigned c = ctx->h_counters[(size_t)f * CNT_STRIDE + slot];
@@ -1286,12 +1319,24 @@ static int enqueue_via_graph(misift_ctx *ctx, const CallKey &key, const void *d_
   return enqueue_via_graph(ctx, key, d_imgs, frame_stride, d_scratch, pts);      // replay what was just captured
 }
 
+// The asynchronous entry points run a tiny call on the dense kernels as well (misift_tiny_call).
+struct TinyScope {
+  misift_ctx *ctx;
+  int saved;
+  TinyScope(misift_ctx *c, int w, int h, int noct) : ctx(c), saved(c ? c->opt.fused : 0)
+  {
+    if (ctx && misift_tiny_call(w, h, noct)) ctx->opt.fused = 0;
+  }
+  ~TinyScope() { if (ctx) ctx->opt.fused = saved; }
+};
+
 int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride, int width,
                         int height, int pitch, int num_octaves, float init_blur, float thresh, float lowest_scale,
                         int scale_up, float *d_scratch, SiftPointD *pts, int max_pts, int *num_pts_out)
 {
   ARG_CHECK(ctx != nullptr && num_pts_out != nullptr);
   const int fused_saved = ctx->opt.fused;
+  if (misift_tiny_call(width, height, num_octaves)) ctx->opt.fused = 0;      // restored on every way out below
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = MISIFT_OK;
     int queued = 0;
@@ -1315,6 +1360,20 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
     }
     bool ovf = false;
     if (!rc) rc = read_counts(ctx, nframes, num_octaves, max_pts, num_pts_out, &ovf);
+    if (rc == MISIFT_RETRY_CHAIN && ctx->chain_embed) {
+      // Some workgroup's bounded wait for the ScaleDown chain inside the scan launch expired: its items were skipped, the
+      // records are incomplete.  Never again on this context: the chain becomes a launch of its own (one dependent
+      // dispatch, ~5 us per call), and this call is redone that way.
+      if (!ctx->opt.quiet)
+        fprintf(stderr, "misift: the in-launch wait for the ScaleDown chain expired (workgroups were not dispatched in index "
+                        "order?); this context now launches the chain separately\n");
+      ctx->chain_embed = 0;
+      ctx->chain_fallbacks++;
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      attempt--;
+      continue;
+    }
+    if (rc == MISIFT_RETRY_CHAIN) rc = MISIFT_EHIP;
     if (rc) { ctx->opt.fused = fused_saved; return rc; }
     if (!ovf) break;
     if (ctx->opt.fused && attempt == 0) {
@@ -1414,6 +1473,8 @@ extern "C" int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, 
                                           float thresh, float lowest_scale, float *d_scratch, void *d_pts,
                                           int max_pts, int *d_counts_out)
 {
+  ARG_CHECK(ctx != nullptr);
+  TinyScope tiny(ctx, width, height, num_octaves);
   int rc = misift_extract_enqueue(ctx, d_imgs, 0, nframes, (long long)frame_stride, width, height, pitch,
                                   num_octaves, init_blur, thresh, lowest_scale, 0, d_scratch, (SiftPointD *)d_pts,
                                   max_pts);
@@ -1429,6 +1490,7 @@ extern "C" int misift_extract_batch_packed_async(misift_ctx *ctx, const float *d
                                                  int *d_offsets_out, void *d_packed_out)
 {
   ARG_CHECK(ctx && d_counts_out && d_offsets_out && d_packed_out);
+  TinyScope tiny(ctx, width, height, num_octaves);
   CtxExtra *px = extra(ctx);
   if (!px->lanes.empty()) {
     // batches in flight: this call goes to the next pipeline of the ring, behind a marker on the caller's stream

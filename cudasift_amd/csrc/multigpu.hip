@@ -697,6 +697,17 @@ extern "C" int misift_match_sharded(misift_ctx *ctx, misift_comm *c, void *d_row
   const int nr = c->nranks;
   const long long n2 = (long long)shard_count * nr;
   MG_CHECK(n2 < (1ll << 31));
+  // The shard's 576-byte records are re-packed INTO d_set2_all (528-byte columns): the two buffers must not overlap — an
+  // in-place call (legal while the records themselves were all-gathered, r03) would read records the pack has already
+  // overwritten.  After the call d_set2_all holds match columns, not SiftPoint records (include/misift.h).
+  if (shard_count) {
+    const char *s0 = (const char *)d_shard2, *s1 = s0 + (size_t)shard_count * sizeof(SiftPointD);
+    const char *a0 = (const char *)d_set2_all, *a1 = a0 + (size_t)n2 * MISIFT_MATCH_COLUMN_BYTES;
+    if (s0 < a1 && a0 < s1) {
+      misift_set_error("misift_match_sharded: d_shard2 overlaps d_set2_all (the shard is packed into d_set2_all; pass separate buffers)");
+      return MISIFT_EINVAL;
+    }
+  }
   // 1. replicate set 2: the shard is packed into 528-byte match columns (descriptor + position: all the sweep reads of a
   //    record) at its own place in d_set2_all, then all-gathered in place (52.8 MB at 100 k; r03 shipped the 576-byte
   //    records).  With more than one rank the exchange runs on the communication stream while the context stream already

@@ -33,9 +33,18 @@ static void die(const char *what)
     if ((call) != MISIFT_OK) die(#call); \
   } while (0)
 
+// Every read-back of this API (ExtractSift's record copy, MatchSiftData's field copy) is queued on the context's own
+// stream right behind the kernels, so its calls may return at the last kernel's host flag instead of a full stream
+// synchronisation (misift_ctx_set_early_return; the C-ABI itself defaults to the full synchronisation).
+static void make_ctx(int dev)
+{
+  SAFE(misift_ctx_create(dev, nullptr, &g_ctx));
+  SAFE(misift_ctx_set_early_return(g_ctx, 1));
+}
+
 static misift_ctx *ctx()
 {
-  if (!g_ctx) SAFE(misift_ctx_create(0, nullptr, &g_ctx));
+  if (!g_ctx) make_ctx(0);
   return g_ctx;
 }
 
@@ -173,7 +182,7 @@ void InitCuda(int devNum)
     misift_ctx_destroy(g_ctx);
     g_ctx = nullptr;
   }
-  SAFE(misift_ctx_create(devNum, nullptr, &g_ctx));
+  make_ctx(devNum);
   char name[256];
   int memClockKHz = 0, busWidth = 0, cus = 0, lds = 0;
   size_t mem = 0;

@@ -92,6 +92,12 @@ int misift_ctx_set_graph_replay(misift_ctx *ctx, int on);
 int misift_ctx_create(int device, void *stream, misift_ctx **out);
 void misift_ctx_destroy(misift_ctx *ctx);
 int misift_ctx_set_stream(misift_ctx *ctx, void *stream);
+/* Synchronous calls return at the last kernel's completion flag (1) instead of after a stream synchronisation (0, the
+ * default): see misift_extract.  The host polls a word of pinned memory, i.e. it spins a core while it waits. */
+int misift_ctx_set_early_return(misift_ctx *ctx, int on);
+/* Diagnostics: calls this context re-ran with a stand-alone ScaleDown chain launch because the bounded in-launch wait
+ * of the single-call path expired (never on a healthy device; MISIFT_CHAIN_WAIT_US sets the bound, default 100000). */
+int misift_ctx_chain_fallbacks(misift_ctx *ctx);
 int misift_ctx_sync(misift_ctx *ctx);
 const char *misift_last_error(void);
 
@@ -131,14 +137,18 @@ size_t misift_scratch_floats(int width, int height, int num_octaves, int scale_u
  * d_pts: max_pts records.  *num_pts_out follows the reference's rule
  * numPts = min(counter[2*num_octaves], max_pts) (cudaSiftH.cu:115-116).
  * One host<->device sync (the count read-back), like the reference.
- * Completion (r04): the call returns as soon as the last kernel has handed the counts to the host through pinned
- * memory, i.e. when every record has been written; the records are complete for everything that is enqueued on the
- * context's stream afterwards (misift_match, misift_copy_d2h, the cudaSift.h shim's read-back, ...).  A consumer on
- * ANOTHER stream or device calls misift_ctx_sync() first.  MISIFT_HOST_SPIN=0 restores a full stream synchronisation
- * inside the call.  The same holds for misift_match / misift_match_rows.
- * Input limit (ours, not the reference's): width, height >= 16 and the coarsest pyramid level >= 8 px in both directions
- * (width >> (num_octaves - 1) >= 8, after the doubling of scale_up), else MISIFT_EINVAL.  The reference accepts such
- * images and finds next to nothing in them (tests/test_gpu_refemul.py). */
+ * Completion: the call returns after the context's stream has been synchronised — every record is written and visible
+ * to any stream, device or host copy, like the reference's blocking ExtractSift.  misift_ctx_set_early_return(ctx, 1)
+ * (r05: opt-in; it was the default in r04) lets the synchronous calls return as soon as the call's last kernel has
+ * handed the counts to the host through pinned memory (~10 us earlier): the records are then ordered only for work
+ * enqueued on the CONTEXT'S stream afterwards (misift_match, misift_copy_d2h, the cudaSift.h shim's read-back);
+ * a consumer on another stream or device must call misift_ctx_sync() first.  MISIFT_HOST_SPIN=0 / =1 in the
+ * environment overrides either way.  The same holds for misift_match / misift_match_rows.
+ * Any size from 1 x 1 and any num_octaves <= MISIFT_MAX_OCTAVES is accepted, like the reference (cudaSiftH.cu:72-167):
+ * images under 16 x 16, or whose coarsest pyramid level is under 8 px, run on the dense per-level kernels (every access
+ * clamped); a level that integer division has shrunk to 0 pixels is empty and skipped (tests/test_gpu_refemul.py:
+ * same numPts, counters and keypoints as the emulated reference down to 1 x 1).  Only width, height < 16384
+ * (after the doubling of scale_up) and max_pts >= 1 are required, else MISIFT_EINVAL. */
 int misift_extract(misift_ctx *ctx, const float *d_img, int width, int height, int pitch,
                    int num_octaves, float init_blur, float thresh, float lowest_scale,
                    int scale_up, float *d_scratch, void *d_pts, int max_pts,
@@ -394,7 +404,10 @@ int misift_comm_wire_bytes(misift_comm *comm, unsigned long long *received, unsi
  * sized for that many RECORDS is more than enough), then the fp32-MFMA sweep of the rank's rows over all of it, then
  * the all-gather of the 12-byte results {float score, float ambiguity, int match} of every row into d_results_all
  * (nranks*row_count entries, may be NULL).  Match indices refer to the gathered set 2.  Returns with everything in
- * place (matching.cu:1191). */
+ * place (matching.cu:1191).
+ * Aliasing: d_shard2 must NOT overlap d_set2_all (the shard is re-packed into it; MISIFT_EINVAL otherwise — also with
+ * one rank), and after the call d_set2_all holds 528-byte match columns, not SiftPoint records: look matched records
+ * up in your own copy of set 2. */
 #define MISIFT_MATCH_COLUMN_BYTES 528
 int misift_match_sharded(misift_ctx *ctx, misift_comm *comm, void *d_rows1, int row_count, const void *d_shard2,
                          int shard_count, void *d_set2_all, void *d_results_all);

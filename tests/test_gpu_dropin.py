@@ -50,3 +50,25 @@ def test_reference_main_runs_unchanged(tmp_path, flavour):
     assert m2, out[-2000:]
     assert int(m2.group(2)) > 100                       # RANSAC inliers of the best hypothesis
     assert os.path.exists(tmp_path / "data" / "limg_pts.pgm")
+
+
+def test_reference_main_on_a_100x100_image(tmp_path):
+    """mainSift.cpp asks for 5 octaves (mainSift.cpp:59): on a 100 x 100 image the coarsest level is 6 px.  The
+    reference runs that (cudaSiftH.cu:72-167) and so must the drop-in — r04 ended the caller's process here."""
+    if not os.path.exists(BIN):
+        pytest.skip("%s not built (needs /root/reference at build time)" % BIN)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_pair_u8.npz"))
+    os.makedirs(tmp_path / "data")
+    left, right = z["left"][300:400, 500:600], z["right"][300:400, 500:600]
+    write_pgm(tmp_path / "data" / "left.pgm", left)
+    write_pgm(tmp_path / "data" / "righ.pgm", right)
+    r = subprocess.run([BIN, "0", "1"], cwd=tmp_path, env=dict(os.environ, MISIFT_QUIET="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "Image size = (100,100)" in r.stdout
+    m = re.search(r"Number of original features: (\d+) (\d+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    from oracle import pyoracle as orc
+    _, n1, _ = orc.extract(left.astype(np.float32), 5, 1.0, 4.5)
+    _, n2, _ = orc.extract(right.astype(np.float32), 5, 1.0, 4.5)
+    assert (int(m.group(1)), int(m.group(2))) == (n1, n2)

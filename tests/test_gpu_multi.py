@@ -131,6 +131,28 @@ def test_comm_single_rank_gather_and_match_sharded(ctx):
     record("comm_single_rank", batches=3, ok=True)
 
 
+def test_match_sharded_refuses_aliased_buffers(ctx):
+    """The shard is re-packed into d_set2_all: an in-place call (legal in r03, when records were all-gathered as they
+    were) is refused instead of racing (advisor r04) — with a single-rank communicator too."""
+    from cudasift_amd import capi
+    from synth import descriptors_to_points, synth_descriptors
+    comm = capi.Comm(ctx, 1, 0, capi.comm_unique_id())
+    try:
+        n = 256
+        a = descriptors_to_points(synth_descriptors(n, 1, l2=True), capi.POINT_DTYPE)
+        d1, d2 = ctx.upload(a), ctx.upload(a)
+        with pytest.raises(capi.MisiftError, match="overlaps"):
+            comm.match_sharded(d1.ptr, n, d2.ptr, n, d2.ptr, None)
+        tail = capi.DevBuf(576 * 2 * n)                  # shard in the upper half of the gather buffer: still overlapping
+        capi.check(capi.lib().misift_copy_h2d(ctx.h, tail.ptr + 200 * n, a.ctypes.data, 576 * n))
+        with pytest.raises(capi.MisiftError, match="overlaps"):
+            comm.match_sharded(d1.ptr, n, tail.ptr + 200 * n, n, tail.ptr, None)
+        all2 = capi.DevBuf(576 * n)
+        comm.match_sharded(d1.ptr, n, d2.ptr, n, all2.ptr, None)             # separate buffers: fine
+    finally:
+        comm.close()
+
+
 def test_comm_two_devices_threads(ctx):
     """Two GPUs, one host thread each (what a C++ caller of the boundary does): pipelined gather to rank 0 and the
     row-block matcher.  Skipped on a one-GPU box."""

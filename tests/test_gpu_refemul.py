@@ -46,14 +46,42 @@ def test_hip_equals_emulated_reference_on_small_images(ctx, w, h, noct, th):
     compare_tiny(pts, n, cnt, r_pts, r_n, r_cnt, noct)
 
 
-@pytest.mark.parametrize("w,h,noct", [(9, 9, 1), (48, 36, 4), (12, 200, 2)])
-def test_images_below_the_minimum_size_are_refused(ctx, w, h, noct):
-    """A documented input limit (include/misift.h, DESIGN section 2 deviations): images under 16x16, or whose coarsest
-    pyramid level would be under 8 px, are refused with MISIFT_EINVAL — the reference runs them (and finds next to nothing)."""
-    from cudasift_amd.capi import MisiftError
+@pytest.mark.parametrize("w,h,noct,th", [(9, 9, 1, 0.5), (48, 36, 4, 0.5), (120, 120, 5, 0.5), (12, 200, 2, 0.5), (100, 100, 5, 2.0),
+                                         (20, 20, 5, 0.1), (9, 9, 5, 0.1), (5, 3, 1, 0.1), (3, 7, 2, 0.1), (1, 1, 1, 0.1), (2, 40, 3, 0.1),
+                                         (15, 15, 1, 0.3), (31, 64, 3, 0.5)])
+def test_hip_equals_emulated_reference_below_the_strip_size(ctx, w, h, noct, th):
+    """Images under 16 x 16 and pyramids whose coarsest level is under 8 px (120 x 120 with the demo's 5 octaves,
+    mainSift.cpp:59): the reference runs them, levels shrinking to a few — or zero — pixels (cudaSiftH.cu:72-167), and so
+    does the HIP path, on its dense per-level kernels (misift_tiny_call): same numPts, same counters, same keypoints."""
+    from util import compare_tiny
+    ref = _ref()
     img = np.random.default_rng(1).uniform(0, 255, (h, w)).astype(np.float32)
-    with pytest.raises(MisiftError, match="invalid argument"):
-        ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=0.5)
+    r_pts, r_n, r_cnt = ref.extract(img, noct, 1.0, th, flavour="fast")
+    pts, n, cnt = ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=th)
+    compare_tiny(pts, n, cnt, r_pts, r_n, r_cnt, noct)
+    record("hip_vs_emulated_reference_tiny/%dx%dx%d" % (w, h, noct), num_pts=int(n), num_pts_reference=int(r_n))
+
+
+@pytest.mark.parametrize("w,h,noct", [(120, 120, 5), (48, 36, 4), (9, 9, 3)])
+def test_tiny_images_through_every_entry_point(ctx, w, h, noct):
+    """The same tiny call through the batch, u8, scale_up and packed entry points gives the single call's records."""
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(w)
+    imgs = np.floor(rng.uniform(0, 255, (3, h, w))).astype(np.float32)
+    for i in range(3):
+        o_pts, o_n, o_cnt = orc.extract(imgs[i], num_octaves=noct, thresh=0.5)
+        pts, n, cnt = ctx.extract(imgs[i], num_octaves=noct, thresh=0.5)
+        assert n == o_n and np.array_equal(cnt, o_cnt)
+    bp, bn = ctx.extract_batch(imgs, num_octaves=noct, thresh=0.5)[:2]
+    up, un = ctx.extract_batch_u8(imgs.astype(np.uint8), num_octaves=noct, thresh=0.5)[:2]
+    for i in range(3):
+        o_pts, o_n, _ = orc.extract(imgs[i], num_octaves=noct, thresh=0.5)
+        assert bn[i] == o_n and un[i] == o_n
+        key = lambda p, k: sorted(zip(p["xpos"][:k].tolist(), p["ypos"][:k].tolist(), p["scale"][:k].tolist()))
+        assert key(bp[i], bn[i]) == key(up[i], un[i])
+    o_pts, o_n, o_cnt = orc.extract(imgs[0], num_octaves=noct, thresh=0.5, scale_up=True)
+    pts, n, cnt = ctx.extract(imgs[0], num_octaves=noct, thresh=0.5, scale_up=True)
+    assert n == o_n and np.array_equal(cnt, o_cnt)
 
 
 def test_hip_matcher_equals_emulated_reference(ctx):
