@@ -24,7 +24,8 @@ assert POINT_DTYPE.itemsize == 576
 
 class Options(C.Structure):
     _fields_ = [("texfrac_bits", C.c_int), ("fix_numpts", C.c_int), ("match_full", C.c_int),
-                ("match_exact_top2", C.c_int), ("quiet", C.c_int), ("fused", C.c_int), ("deterministic", C.c_int)]
+                ("match_exact_top2", C.c_int), ("quiet", C.c_int), ("fused", C.c_int), ("deterministic", C.c_int),
+                ("reference_cap", C.c_int)]
 
 
 class MisiftError(RuntimeError):

@@ -325,6 +325,8 @@ struct misift_ctx {
   int cap_det_frames, det_max_pts;
   float *d_own_scratch;         // scratch allocated on behalf of the caller (NULL tempMemory)
   size_t own_scratch_floats;
+  unsigned *d_refcap;           // options.reference_cap: 240-bit extremum masks of the reference's 30 x 8 blocks (launch_refcap)
+  size_t refcap_bytes;
   void *d_match_tmp;            // matcher partial results
   size_t match_tmp_bytes;
   int num_cus;
@@ -379,6 +381,8 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap);
 // the stream the most recent batch of `ctx` ran on (its own, or a pipeline's with batches in flight)
 hipStream_t misift_ctx_result_stream(misift_ctx *ctx);
 int misift_ensure_tmp(misift_ctx *ctx, size_t bytes);
+int launch_refcap(misift_ctx *ctx, int w, int h, int nframes, int octave);
+bool misift_tiny_call(int width, int height, int num_octaves);
 int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride,
                            int width, int height, int pitch, int num_octaves, float init_blur, float thresh,
                            float lowest_scale, int scale_up, float *d_scratch, SiftPointD *pts, int max_pts);

@@ -1152,6 +1152,7 @@ __global__ __launch_bounds__(64) void refine_kernel(const float *__restrict__ sr
   const size_t plane = (size_t)P.height * P.pitch;
   for (unsigned ci = blockIdx.x * blockDim.x + threadIdx.x; ci < ncand; ci += gridDim.x * blockDim.x) {
     const unsigned code = list[ci];
+    if (code == 0xffffffffu) continue;        // struck by the reference's 32-per-block cap (options.reference_cap)
     const int x = code & 0x3fff, y = (code >> 14) & 0x3fff, s = code >> 28;
     float d[3][3][3];       // [plane s..s+2][dy][dx]
     if (FROM_BASE) {
@@ -1344,6 +1345,72 @@ int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long lo
   LaunchScope ls(ctx, "detect");
   hipLaunchKernelGGL(detect_kernel, grid_for(g), dim3(256), 0, ctx->stream, dog, g, dog_frame_stride, thresh,
                      octave, ctx->d_counters, ctx->d_cand, (unsigned)ctx->cand_cap, al);
+  return ls.finish();
+}
+
+// ---- options.reference_cap: the 32-extrema-per-block cap of FindPointsMultiNew (cudaSiftD.cu:1369-1377).  A block of the
+// reference is 30 columns x 8 rows of one scale; it numbers its extrema by an exclusive prefix sum over its threads
+// (columns), each thread listing its own by row, and only the first MEMWID = 32 are handed on.  Here: every true extremum
+// of the dense detect_kernel sets ITS bit in a 240-bit mask of its block (bit = column * 8 + row: the reference's order),
+// then every one whose rank — the number of set bits below its own — is 32 or more is struck from the candidate list.
+#define REFCAP_W 30
+#define REFCAP_H 8
+#define REFCAP_WORDS 8            // 240 bits per block
+__device__ __forceinline__ void refcap_locate(unsigned code, int tiles_x, int tiles_y, size_t *word0, unsigned *bit)
+{
+  const int x = code & 0x3fff, y = (code >> 14) & 0x3fff, s = code >> 28;
+  const int tx = x / REFCAP_W, ty = y / REFCAP_H;
+  *word0 = (((size_t)s * tiles_y + ty) * tiles_x + tx) * REFCAP_WORDS;
+  *bit = (unsigned)((x - tx * REFCAP_W) * REFCAP_H + (y - ty * REFCAP_H));
+}
+__global__ __launch_bounds__(256) void refcap_mark_kernel(const unsigned *__restrict__ counters, const unsigned *__restrict__ cand,
+                                                          unsigned cand_cap, int octave, int tiles_x, int tiles_y,
+                                                          unsigned *__restrict__ mask, size_t mask_words_per_frame)
+{
+  const int frame = blockIdx.y;
+  const unsigned n = min(counters[(size_t)frame * CNT_STRIDE + CNT_CAND + octave], cand_cap);
+  const unsigned *list = cand + (size_t)frame * cand_cap;
+  unsigned *m = mask + (size_t)frame * mask_words_per_frame;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    size_t w0; unsigned bit;
+    refcap_locate(list[i], tiles_x, tiles_y, &w0, &bit);
+    atomicOr(&m[w0 + (bit >> 5)], 1u << (bit & 31u));
+  }
+}
+__global__ __launch_bounds__(256) void refcap_drop_kernel(const unsigned *__restrict__ counters, unsigned *__restrict__ cand,
+                                                          unsigned cand_cap, int octave, int tiles_x, int tiles_y,
+                                                          const unsigned *__restrict__ mask, size_t mask_words_per_frame)
+{
+  const int frame = blockIdx.y;
+  const unsigned n = min(counters[(size_t)frame * CNT_STRIDE + CNT_CAND + octave], cand_cap);
+  unsigned *list = cand + (size_t)frame * cand_cap;
+  const unsigned *m = mask + (size_t)frame * mask_words_per_frame;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    size_t w0; unsigned bit;
+    refcap_locate(list[i], tiles_x, tiles_y, &w0, &bit);
+    unsigned rank = 0;
+    for (unsigned w = 0; w < (bit >> 5); w++) rank += __popc(m[w0 + w]);
+    rank += __popc(m[w0 + (bit >> 5)] & ((1u << (bit & 31u)) - 1u));
+    if (rank >= 32u) list[i] = 0xffffffffu;            // struck: refine_kernel skips it (no pixel has this code)
+  }
+}
+
+int launch_refcap(misift_ctx *ctx, int w, int h, int nframes, int octave)
+{
+  const int tiles_x = (w + REFCAP_W - 1) / REFCAP_W, tiles_y = (h + REFCAP_H - 1) / REFCAP_H;
+  const size_t words = (size_t)NUM_SCALES * tiles_x * tiles_y * REFCAP_WORDS;
+  if (sizeof(unsigned) * words * nframes > ctx->refcap_bytes) {
+    if (ctx->d_refcap) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->d_refcap)); }
+    ctx->d_refcap = nullptr; ctx->refcap_bytes = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->d_refcap, sizeof(unsigned) * words * nframes));
+    ctx->refcap_bytes = sizeof(unsigned) * words * nframes;
+  }
+  HIP_TRY(hipMemsetAsync(ctx->d_refcap, 0, sizeof(unsigned) * words * nframes, ctx->stream));
+  LaunchScope ls(ctx, "refcap");
+  hipLaunchKernelGGL(refcap_mark_kernel, dim3(64, nframes), dim3(256), 0, ctx->stream, ctx->d_counters, ctx->d_cand,
+                     (unsigned)ctx->cand_cap, octave, tiles_x, tiles_y, ctx->d_refcap, words);
+  hipLaunchKernelGGL(refcap_drop_kernel, dim3(64, nframes), dim3(256), 0, ctx->stream, ctx->d_counters, ctx->d_cand,
+                     (unsigned)ctx->cand_cap, octave, tiles_x, tiles_y, ctx->d_refcap, words);
   return ls.finish();
 }
 

@@ -301,6 +301,8 @@ extern "C" void misift_default_options(misift_options *opt)
   if ((e = getenv("MISIFT_QUIET"))) opt->quiet = atoi(e);
   if ((e = getenv("MISIFT_FUSED"))) opt->fused = atoi(e);
   if ((e = getenv("MISIFT_DETERMINISTIC"))) opt->deterministic = atoi(e) != 0;
+  opt->reference_cap = 0;
+  if ((e = getenv("MISIFT_REFERENCE_CAP"))) opt->reference_cap = atoi(e) != 0;
 }
 
 extern "C" void misift_ctx_destroy(misift_ctx *ctx);
@@ -353,7 +355,7 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_BIN_MIN_FRAMES")) ctx->bin_min_frames = atoi(e);
   ctx->small_frames = 4;
   if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
-  ctx->balance_frames = 0;       // (off until a full GPU suite + bench A/B has run on it: DESIGN.md section 8)
+  ctx->balance_frames = 1;       // r05: on by default (full GPU suite + bench A/B both ways: profiles/r05_balance_*); =0 restores per-frame grids
   if (const char *e = getenv("MISIFT_BALANCE")) ctx->balance_frames = atoi(e) != 0;
   ctx->lowpass_tile = 1;
   if (const char *e = getenv("MISIFT_LOWPASS_TILE")) ctx->lowpass_tile = atoi(e) != 0;
@@ -563,6 +565,7 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   if (ctx->d_block_map) hipFree(ctx->d_block_map);
   if (ctx->d_own_scratch) hipFree(ctx->d_own_scratch);
   if (ctx->d_match_tmp) hipFree(ctx->d_match_tmp);
+  if (ctx->d_refcap) hipFree(ctx->d_refcap);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
@@ -928,6 +931,12 @@ struct Level { int w, h, p; float *img; };   // img = frame-0 pointer of that py
 // at any width >= 1.  The merged-octave kernels (tiled prefilter, cone chain, strips sized for whole wavefronts) are
 // built for images that fill at least a strip and never see such calls.  A level that integer division has shrunk to
 // 0 pixels holds nothing and is skipped (CUDA itself refuses a zero-sized grid there).
+// ... and so do calls with options.reference_cap: the cap is defined on the TRUE extrema of a block, which only the dense
+// detect_kernel lists (the fused scan's list holds pre-candidates).
+static bool dense_call(misift_ctx *ctx, int width, int height, int num_octaves)
+{
+  return misift_tiny_call(width, height, num_octaves) || (ctx && ctx->opt.reference_cap);
+}
 bool misift_tiny_call(int width, int height, int num_octaves)
 {
   if (num_octaves < 1) return false;
@@ -1179,6 +1188,10 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
       if (rc) return rc;
       rc = launch_detect(ctx, memoryTmp, g, SS, thresh, o);
       if (rc) return rc;
+      if (ctx->opt.reference_cap) {
+        rc = launch_refcap(ctx, L.w, L.h, nframes, o);
+        if (rc) return rc;
+      }
       rc = launch_refine(ctx, memoryTmp, SS, nullptr, 0, nullptr, L.w, L.h, L.p, nframes, thresh, 10.0f,
                          1.0f / NUM_SCALES, lowest_scale / subsampling, subsampling, o, pts, max_pts);
       if (rc) return rc;
@@ -1325,7 +1338,7 @@ struct TinyScope {
   int saved;
   TinyScope(misift_ctx *c, int w, int h, int noct) : ctx(c), saved(c ? c->opt.fused : 0)
   {
-    if (ctx && misift_tiny_call(w, h, noct)) ctx->opt.fused = 0;
+    if (ctx && dense_call(ctx, w, h, noct)) ctx->opt.fused = 0;
   }
   ~TinyScope() { if (ctx) ctx->opt.fused = saved; }
 };
@@ -1336,7 +1349,7 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
 {
   ARG_CHECK(ctx != nullptr && num_pts_out != nullptr);
   const int fused_saved = ctx->opt.fused;
-  if (misift_tiny_call(width, height, num_octaves)) ctx->opt.fused = 0;      // restored on every way out below
+  if (dense_call(ctx, width, height, num_octaves)) ctx->opt.fused = 0;       // restored on every way out below
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = MISIFT_OK;
     int queued = 0;
@@ -1664,6 +1677,10 @@ extern "C" int misift_findpoints(misift_ctx *ctx, const float *d_dog, int width,
   StripGeom g = make_geom(ctx, width, height, pitch, 1, 0, width, height, 62);
   rc = launch_detect(ctx, d_dog, g, 0, thresh, octave);
   if (rc) return rc;
+  if (ctx->opt.reference_cap) {
+    rc = launch_refcap(ctx, width, height, 1, octave);
+    if (rc) return rc;
+  }
   rc = launch_refine(ctx, d_dog, 0, nullptr, 0, nullptr, width, height, pitch, 1, thresh, edge_limit, 1.0f / NUM_SCALES,
                      lowest_scale, subsampling, octave, (SiftPointD *)d_pts, max_pts);
   if (rc) return rc;

@@ -67,6 +67,14 @@ typedef struct misift_options {
                             dense kernels (fused = 0, or the automatic exact
                             re-run after a candidate-list overflow) sort every
                             segment by (y, x, scale, orientation) afterwards   */
+  int reference_cap;     /* 0 = every scale-space extremum goes on to the refinement
+                            (ours); 1 = the reference's cap: a block of
+                            FindPointsMultiNew — 30 columns x 8 rows of one scale —
+                            keeps its first 32 extrema (by column, then row) and
+                            drops the rest (cudaSiftD.cu:1369-1377; SURVEY
+                            Appendix B #4).  Natural images never reach 32 per
+                            240 pixels; calls with the cap run on the dense
+                            per-level kernels (also MISIFT_REFERENCE_CAP=1)    */
 } misift_options;
 
 /* ------------------------------------------------------------------ runtime */

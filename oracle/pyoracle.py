@@ -202,6 +202,22 @@ def extract(img, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, sca
     return pts, n, np.array(list(cnt), dtype=np.uint32)
 
 
+def descriptor_bounds(img, pts, n, num_octaves=5, init_blur=1.0, ulps=3.0):
+    """orc_descriptor_bounds: for the first n records of one ExtractSift call on `img`, the largest change of every
+    descriptor element that a last-bit difference of the sample coordinates can cause through the 8-bit texture weights
+    (see sift_oracle.c).  Returns (bound[n,128], flips[n], wraps[n])."""
+    img = _f32(img)
+    h, w = img.shape
+    pts = np.ascontiguousarray(pts[:n])
+    bound = np.zeros((n, 128), np.float32)
+    flips, wraps = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    L = lib()
+    L.orc_descriptor_bounds.restype = None
+    L.orc_descriptor_bounds(_p(img), w, h, w, num_octaves, C.c_float(init_blur), _p(pts), n, C.c_float(ulps), _p(bound), _p(flips),
+                            _p(wraps))
+    return bound, flips, wraps
+
+
 def extract_batch(imgs, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, max_pts=32768, fracbits=8,
                   outer_threads=None, inner_threads=1):
     """orc_extract_batch: frames [B,h,w] processed one per OpenMP thread.
@@ -275,6 +291,22 @@ def improve_homography(pts, npts, H, num_loops=5, min_score=0.0, max_ambiguity=0
 def srand(seed):
     """Seed the process-wide libc rand() that FindHomography (oracle and HIP host side) draws from."""
     C.CDLL(None).srand(C.c_uint(seed))
+
+
+class reference_cap:
+    """Context manager: the reference's 32-extrema-per-block cap of FindPointsMultiNew (cudaSiftD.cu:1369-1377) on / off
+    (off = the default: every extremum is kept, a documented deviation)."""
+
+    def __init__(self, on):
+        self.on = int(on)
+
+    def __enter__(self):
+        lib().orc_set_reference_cap(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_reference_cap(0)
+        return False
 
 
 def stats():

@@ -92,6 +92,8 @@ static orc_stats_t g_stats;
 #define ORC_CONTRACT_PLAIN 0
 #define ORC_CONTRACT_NVCC  1
 static int g_contract = ORC_CONTRACT_PLAIN;
+static int g_refcap = 0;       /* 1 = keep the reference's 32-extrema-per-block cap (Appendix B #4); default: keep every extremum */
+void orc_set_reference_cap(int on) { g_refcap = on ? 1 : 0; }
 void orc_set_contract(int mode) { g_contract = mode ? ORC_CONTRACT_NVCC : ORC_CONTRACT_PLAIN; }
 int orc_get_contract(void) { return g_contract; }
 /* a*b + c, a*b - c*d, a*b + c*d + e*f as nvcc-style contraction would evaluate them */
@@ -369,6 +371,8 @@ int orc_findpoints(const float *dog, int w, int h, int pitch, float thresh, floa
     const int s = job / nblk, yb = job % nblk;
     orc_detlist_t *L = &lists[job];
     const float *d0 = dog + size * s, *d1 = dog + size * (s + 1), *d2 = dog + size * (s + 2);
+    /* pass 1: the 26-neighbour test of every pixel of this 8-row band (cudaSiftD.cu:1337-1366) */
+    unsigned char *isext = (unsigned char *)calloc((size_t)8 * w, 1);
     for (int y = 8 * yb; y < 8 * yb + 8 && y < h; y++) {
       int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
       for (int x = 0; x < w; x++) {
@@ -387,7 +391,24 @@ int orc_findpoints(const float *dog, int w, int h, int pitch, float thresh, floa
               maxv = fmaxf(maxv, t);
             }
         if (!((v < fminf(-thresh, minv)) || (v > fmaxf(thresh, maxv)))) continue;
+        isext[(size_t)(y - 8 * yb) * w + x] = 1;
         tilecnt[((size_t)s * tilesy + y / 8) * tilesx + x / 30]++;
+      }
+    }
+    /* the reference's cap (cudaSiftD.cu:1369-1377, off unless orc_set_reference_cap(1)): a block of FindPointsMultiNew —
+     * 30 columns x 8 rows of one scale — hands at most 32 extrema on to the refinement: the first 32 in the order of its
+     * prefix sum over the threads, i.e. by column, then by row */
+    if (g_refcap)
+      for (int tx0 = 0; tx0 < w; tx0 += 30) {
+        int kept = 0;
+        for (int x = tx0; x < tx0 + 30 && x < w; x++)
+          for (int yy = 0; yy < 8; yy++)
+            if (isext[(size_t)yy * w + x] && ++kept > 32) isext[(size_t)yy * w + x] = 0;
+      }
+    /* pass 2: edge test, refinement, append — in scan order (row, column) */
+    for (int y = 8 * yb; y < 8 * yb + 8 && y < h; y++) {
+      for (int x = 0; x < w; x++) {
+        if (!isext[(size_t)(y - 8 * yb) * w + x]) continue;
         /* refinement, cudaSiftD.cu:1383-1417: unclamped neighbour reads (x,y interior here) */
         const float *data1 = d1 + (size_t)y * pitch + x;
         float val = data1[0];
@@ -437,6 +458,7 @@ int orc_findpoints(const float *dog, int w, int h, int pitch, float thresh, floa
         q->edgeness = edge;
       }
     }
+    free(isext);
   }
   int n = 0;
   for (int job = 0; job < nblk * NUM_SCALES; job++) {
@@ -809,6 +831,157 @@ void orc_descriptors(const float *img, int w, int h, int pitch, SiftPoint *pts, 
       { g_stats.nan_guards += guards; g_stats.oob_votes += oob; }
     }
   }
+}
+
+/* ------------------------------------------------ descriptor tail: a per-record BOUND (test infrastructure)
+ * Against the reference's own code (oracle/_ref, the CPU SIMT emulator) ~0.7 % of the descriptors differ by more than
+ * 1e-4 in some element.  The mechanism: the two sides compute a sample coordinate with different
+ * roundings (libm vs written-out sincos, contracted vs plain multiply-adds) — a last-bit difference — and the texture
+ * unit rounds the interpolation weight to 8 fractional bits, so a fetch whose weight sits within that last bit of a
+ * rounding tie moves by 1/256 of the local texel difference.  This function turns the explanation into a bound per
+ * record and element: for every one of the 1024 fetches of a descriptor it checks whether a coordinate perturbation of
+ * `ulps` units in the last place can change the rounded weight, takes (1/256) x the texel difference along that axis
+ * as the fetch's possible change, and propagates it through gradient magnitude, angle split, the spatial vote weights
+ * and the two normalisations.  A regression of the same size as the tail but NOT of this origin exceeds the bound.
+ *   img/w/h/pitch : the octave image the descriptor was sampled from;  p : the record at THAT octave's scale
+ *   bound[128]    : out, largest |change| of each element;  returns the number of fetches that can flip, and in
+ *   *wraps the number of samples whose angle sits on the angi = 8 <-> 0 seam (cudaSiftD.cu:353, Appendix B #6). */
+static int ialign_up(int a, int b);
+static inline float ulp32(float x)
+{
+  x = fabsf(x);
+  if (x < 1.0f) x = 1.0f;
+  int e;
+  frexpf(x, &e);
+  return ldexpf(1.0f, e - 24);
+}
+
+static float fetch_flip(const float *img, int w, int h, int pitch, float x, float y, float ulps, int *nflip)
+{
+  float xb = x - 0.5f, yb = y - 0.5f;
+  float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  float a256 = a * 256.0f, b256 = b * 256.0f;
+  float da = fabsf(a256 - floorf(a256) - 0.5f), db = fabsf(b256 - floorf(b256) - 0.5f);
+  float ra = rintf(a256) * (1.0f / 256.0f), rb = rintf(b256) * (1.0f / 256.0f);
+  fx = fminf(fmaxf(fx, -2.0f), (float)w);
+  fy = fminf(fmaxf(fy, -2.0f), (float)h);
+  int ix = (int)fx, iy = (int)fy;
+  int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
+  int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+  float t00 = img[(size_t)y0 * pitch + x0], t10 = img[(size_t)y0 * pitch + x1];
+  float t01 = img[(size_t)y1 * pitch + x0], t11 = img[(size_t)y1 * pitch + x1];
+  float d = 0.0f;
+  /* a floor() that falls the other way at an integer coordinate changes nothing: weight 0 of one texel = weight 1 of the next */
+  if (da <= 256.0f * ulps * ulp32(x)) { d += (1.0f / 256.0f) * fabsf((1.0f - rb) * (t10 - t00) + rb * (t11 - t01)); (*nflip)++; }
+  if (db <= 256.0f * ulps * ulp32(y)) { d += (1.0f / 256.0f) * fabsf((1.0f - ra) * (t01 - t00) + ra * (t11 - t10)); (*nflip)++; }
+  return d;
+}
+
+int orc_descriptor_bound(const float *img, int w, int h, int pitch, const SiftPoint *p, float ulps, float *bound, int *wraps)
+{
+  float gauss[16];
+  for (int t = 0; t < 16; t++) gauss[t] = det_exp(-(t - 7.5f) * (t - 7.5f) / 128.0f);
+  double raw[128], del[128];
+  for (int i = 0; i < 128; i++) { raw[i] = 0.0; del[i] = 0.0; }
+  float theta = 2.0f * 3.1415f / 360.0f * p->orientation;
+  float sina, cosa;
+  det_sincos(theta, &sina, &cosa);
+  float scale = 12.0f / 16.0f * p->scale;
+  float ssina = scale * sina, scosa = scale * cosa;
+  int nflip = 0, nwrap = 0;
+  for (int y = 0; y < 16; y++)
+    for (int tx = 0; tx < 16; tx++) {
+      float xpos = p->xpos + (tx - 7.5f) * scosa - (y - 7.5f) * ssina + 0.5f;
+      float ypos = p->ypos + (tx - 7.5f) * ssina + (y - 7.5f) * scosa + 0.5f;
+      float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, 8) - tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, 8);
+      float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, 8) - tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, 8);
+      int nf = 0;
+      float ddx = fetch_flip(img, w, h, pitch, xpos + cosa, ypos + sina, ulps, &nf) +
+                  fetch_flip(img, w, h, pitch, xpos - cosa, ypos - sina, ulps, &nf);
+      float ddy = fetch_flip(img, w, h, pitch, xpos - sina, ypos + cosa, ulps, &nf) +
+                  fetch_flip(img, w, h, pitch, xpos + sina, ypos - cosa, ulps, &nf);
+      nflip += nf;
+      float g = sqrtf(dx * dx + dy * dy), gw = gauss[y] * gauss[tx];
+      float grad = gw * g;
+      float angf = 4.0f / 3.1415f * fast_atan2(dy, dx) + 4.0f;
+      /* The seam (Appendix B #6): 4/3.1415 * pi = 4.000118, so a sample whose gradient angle lies within 9.3e-5 rad below
+       * +pi gets angf >= 8, angi = 8, and its vote lands on index hist + 8 — the NEXT cell's bin 0 — instead of this cell's
+       * bin 0; one step further (dy < 0) it is bin 0 of this cell again.  Both sides reproduce the quirk, but which side of
+       * the 9.3e-5-rad band's edges a sample falls on hangs on dy to a few ulp of the texel values (~6e-5), weight flip or not. */
+      const float noise = 6e-5f;
+      int seam = dx < 0.0f && g > 0.0f &&
+                 (angf >= 8.0f - (4.0f / 3.1415f) * (ddx + ddy + 2.0f * noise) / g - 1e-6f || fabsf(dy) <= ddy + noise);
+      if (seam && grad > 0.0f) nwrap++;
+      int hori = (tx + 2) / 4 - 1, veri = (y + 2) / 4 - 1;
+      float horf = (tx - 1.5f) / 4.0f - hori, verf = (y - 1.5f) / 4.0f - veri;
+      int angi = (int)angf;
+      if (angi > 7) angi = 7;
+      float af = angf - angi;
+      /* what this sample can move: its magnitude by gw * (ddx + ddy), its angle by (4/pi) (ddx + ddy) / g bins (at most
+       * everything it has); on the seam the whole vote may sit in the other end bin (or in the next cell's bin 0) */
+      float dmag = gw * (ddx + ddy);
+      float dang = (g > 0.0f) ? (4.0f / 3.1415f) * (ddx + ddy) / g : 0.0f;
+      if (dang > 1.0f) dang = 1.0f;
+      float move = dmag + dang * grad + (seam ? grad : 0.0f);
+      for (int cy = 0; cy < 2; cy++)
+        for (int cx = 0; cx < 2; cx++) {
+          int vh = hori + cx, vv = veri + cy;
+          if (vh < 0 || vh > 3 || vv < 0 || vv > 3) continue;
+          float ws = (cx ? horf : 1.0f - horf) * (cy ? verf : 1.0f - verf);
+          int hist = 8 * (4 * vv + vh);
+          raw[hist + angi] += ws * (1.0f - af) * grad;
+          raw[hist + ((angi + 1) & 7)] += ws * af * grad;
+          if (move > 0.0f) {
+            /* the two bins the vote is split over and their outer neighbours (the split point may cross a bin edge) */
+            for (int k = -1; k <= 2; k++) del[hist + ((angi + k) & 7)] += ws * move;
+            if (seam && hist + 8 < 128) del[hist + 8] += ws * grad;
+          }
+        }
+    }
+  double n1 = 0.0, dn = 0.0;
+  for (int i = 0; i < 128; i++) { n1 += raw[i] * raw[i]; dn += del[i] * del[i]; }
+  n1 = sqrt(n1); dn = sqrt(dn);
+  if (!(n1 > 0.0)) { for (int i = 0; i < 128; i++) bound[i] = 1.0f; if (wraps) *wraps = nwrap; return nflip; }
+  double sum2 = 0.0;
+  for (int i = 0; i < 128; i++) { double v = raw[i] / n1; if (v > 0.2) v = 0.2; sum2 += v * v; }
+  double rs2 = 1.0 / sqrt(sum2);
+  for (int i = 0; i < 128; i++) {
+    /* d(v/|v|) <= (d_i + v_i |d| / |v|) / |v|; the clamp is 1-Lipschitz; the second normalisation scales by rs2 and adds
+     * the same relative term once more */
+    double v = raw[i] / n1;
+    double b1 = (del[i] + v * dn) / n1;
+    bound[i] = (float)(rs2 * (b1 + (v < 0.2 ? v : 0.2) * rs2 * dn / n1));
+  }
+  if (wraps) *wraps = nwrap;
+  return nflip;
+}
+
+/* The same for the records of one ExtractSift call: rebuilds the pyramid of `img` (prefilter + ScaleDowns, as
+ * orc_extract does), finds every record's level from its `subsampling`, and writes bound[n][128], flips[n], wraps[n]. */
+void orc_descriptor_bounds(const float *img, int width, int height, int pitch, int numOctaves, float initBlur,
+                           const SiftPoint *pts, int n, float ulps, float *bound, int *flips, int *wraps)
+{
+  float *lev[16];
+  int lw[16], lh[16], lp[16];
+  float blur = initBlur > 0.001f ? initBlur : 0.001f;
+  lw[0] = width; lh[0] = height; lp[0] = ialign_up(width, 128);
+  lev[0] = (float *)malloc(sizeof(float) * (size_t)lh[0] * lp[0]);
+  orc_lowpass(img, width, height, pitch, lev[0], lp[0], blur);
+  for (int k = 1; k < numOctaves; k++) {
+    lw[k] = lw[k - 1] / 2; lh[k] = lh[k - 1] / 2; lp[k] = ialign_up(lw[k], 128);
+    lev[k] = (float *)malloc(sizeof(float) * (size_t)(lh[k] > 0 ? lh[k] : 1) * lp[k]);
+    if (lw[k] > 0 && lh[k] > 0) orc_scaledown(lev[k - 1], lw[k - 1], lh[k - 1], lp[k - 1], lev[k], lp[k]);
+  }
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < n; i++) {
+    int k = 0;
+    while ((float)(1 << k) < pts[i].subsampling && k < numOctaves - 1) k++;
+    SiftPoint q = pts[i];
+    q.xpos /= q.subsampling; q.ypos /= q.subsampling; q.scale /= q.subsampling;
+    flips[i] = orc_descriptor_bound(lev[k], lw[k], lh[k], lp[k], &q, ulps, bound + (size_t)128 * i, wraps ? &wraps[i] : NULL);
+  }
+  for (int k = 0; k < numOctaves; k++) free(lev[k]);
 }
 
 /* ----------------------------------------------------------- ExtractSift */

@@ -77,7 +77,49 @@ def test_kernel_trace_parsing(tmp_path, monkeypatch):
     assert note is None
     assert res["dog_scan"]["launches_per_step"] == 2 and abs(res["dog_scan"]["ms_per_step"] - 0.6) < 1e-9
     assert res["descr_all"]["launches_per_step"] == 1 and abs(res["descr_all"]["ms_per_step"] - 0.3) < 1e-9
-    assert set(res) == {"dog_scan", "descr_all"}
+    assert set(res) == {"dog_scan", "descr_all", "_all"}
+    # back-to-back launches never overlap here: the union is the sum
+    assert abs(res["dog_scan"]["union_ms_per_step"] - 0.6) < 1e-9
+
+
+def test_kernel_trace_union_of_overlapping_launches(tmp_path, monkeypatch):
+    """roofline.frac is quoted against the wall time during which a dog_scan launch was RUNNING: the two launches of a step
+    (fine levels | coarse levels on a second stream) overlap, and the union counts the overlap once.
+    Canned trace: per step launch A = [t, t+400 us), launch B = [t+150, t+450 us) -> sum 0.7 ms, union 0.45 ms; a descr_all
+    launch overlapping the next step's scan must not leak into dog_scan's union."""
+    import bench
+    assert bench.interval_union_ns([]) == 0
+    assert bench.interval_union_ns([(0, 10), (5, 20), (30, 40), (32, 35), (40, 41)]) == 31
+    steps, skip = 5, 1
+    rows = ["Kind,Agent_Id,Queue_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,End_Timestamp"]
+    scan = "void dog_scan_all_kernel<1, false>(float const*, ScanAllGeom)"
+    for s_ in range(steps):
+        t = 10_000_000 + s_ * 1_000_000
+        rows.append('"KERNEL_DISPATCH",1,1,1,"%s",1,%d,%d' % (scan, t, t + 400_000))
+        rows.append('"KERNEL_DISPATCH",1,2,1,"%s",1,%d,%d' % (scan, t + 150_000, t + 450_000))
+        rows.append('"KERNEL_DISPATCH",1,1,1,"void descr_all_kernel<true, 4, true>(float const*)",1,%d,%d' % (t + 500_000, t + 1_100_000))
+
+    class P:
+        returncode = 0
+        stdout = b""
+
+    def fake_run(cmd, **kw):
+        d = cmd[cmd.index("-d") + 1]
+        os.makedirs(os.path.join(d, "host"), exist_ok=True)
+        open(os.path.join(d, "host", "t_kernel_trace.csv"), "w").write("\n".join(rows) + "\n")
+        return P()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: True)
+    res, note = bench.collect_trace(64, steps=steps, skip=skip)
+    assert note is None
+    assert res["dog_scan"]["launches_per_step"] == 2
+    assert abs(res["dog_scan"]["ms_per_step"] - 0.7) < 1e-9            # the sum double-counts the overlap ...
+    assert abs(res["dog_scan"]["union_ms_per_step"] - 0.45) < 1e-9     # ... the union does not
+    assert abs(res["descr_all"]["union_ms_per_step"] - 0.6) < 1e-9
+    # all kernels together: scan [0, 450) + descr [500, 1100) of a 1000-us period, descr overlapping the next step's scan
+    # (steps 1..4: 450 + 3 x 950 + 600 us of busy time)
+    assert abs(res["_all"]["busy_union_ms_per_step"] - 3.9 / 4) < 1e-9
 
 
 # ---- `python bench.py --gpus N` as a plain command spawns its own ranks (r04; VERDICT r03 "next" #2)
@@ -105,6 +147,19 @@ def test_a_failing_rank_fails_the_whole_run():
     r = _run_bench(["--gpus", "2", "--spawn-check"], {"BENCH_SPAWN_CHECK_FAIL_RANK": "1"})
     assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
     assert "a rank exited with code 7" in r.stderr and "spawn_check" not in r.stdout
+
+
+def test_a_silent_rank_is_ended_by_the_watchdog():
+    """A rank that hangs (in rendezvous, ncclCommInitRank, a collective ...) must not cost the launcher its whole time-out:
+    its watchdog prints the rank and the stage it is stuck in and exits with rc 6, the launcher stops the others."""
+    import time
+    t0 = time.time()
+    r = _run_bench(["--gpus", "2", "--spawn-check"], {"BENCH_SPAWN_CHECK_HANG_RANK": "1", "BENCH_WATCHDOG_S": "3"}, timeout=120)
+    assert r.returncode == 6, (r.returncode, r.stderr[-2000:])
+    # whichever rank's watchdog fires first (the hung one, or rank 0 waiting for it in the barrier) names every rank's stage
+    assert "watchdog: rank" in r.stderr and "rank 1: in stage 'pretend_collective'" in r.stderr, r.stderr[-1500:]
+    assert time.time() - t0 < 60
+    assert "spawn_check" not in r.stdout
 
 
 def test_gpus_n_refuses_to_run_on_fewer_devices():

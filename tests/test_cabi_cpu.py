@@ -56,7 +56,7 @@ def test_host_only_entry_points():
     assert np.array_equal(capi.laplace_taps(5), orc.laplace_taps(5))     # same host formula, same libm
     o = capi.Options()
     capi.lib().misift_default_options(C.byref(o))
-    assert (o.texfrac_bits, o.fix_numpts, o.match_full, o.match_exact_top2) == (8, 0, 0, 0)
+    assert (o.texfrac_bits, o.fix_numpts, o.match_full, o.match_exact_top2, o.reference_cap) == (8, 0, 0, 0, 0)
 
 
 def test_point_record_layout():

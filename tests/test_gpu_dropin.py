@@ -45,7 +45,9 @@ def test_reference_main_runs_unchanged(tmp_path, flavour):
     from oracle import pyoracle as orc
     _, n1, _ = orc.extract(z["left"].astype(np.float32), 5, 1.0, 4.5)
     _, n2, _ = orc.extract(z["right"].astype(np.float32), 5, 1.0, 4.5)
-    assert (int(m.group(1)), int(m.group(2))) == (n1, n2)
+    assert (int(m.group(1)), int(m.group(2))) == (n1, n2) and n1 > 64 and n2 > 64
+    m2 = re.search(r"Number of matching features: (\d+) (\d+)", r.stdout)
+    assert m2 and int(m2.group(2)) >= 8, r.stdout[-1500:]            # the 7-px shift is found
     m2 = re.search(r"Number of matching features: (\d+) (\d+) ([\d.]+)% 1 4.5", out)
     assert m2, out[-2000:]
     assert int(m2.group(2)) > 100                       # RANSAC inliers of the best hypothesis
@@ -59,7 +61,11 @@ def test_reference_main_on_a_100x100_image(tmp_path):
         pytest.skip("%s not built (needs /root/reference at build time)" % BIN)
     z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_pair_u8.npz"))
     os.makedirs(tmp_path / "data")
-    left, right = z["left"][300:400, 500:600], z["right"][300:400, 500:600]
+    # two views 7 px apart of the most textured 100 x 100 patch of left.pgm (119 / 107 features at the demo's thresh 4.5).
+    # NOT any crop: with fewer than 32 features in the second image MatchSiftData compares nothing (matching.cu:1103:
+    # 32 * (numPts2 / 32) columns), every match stays -1 and the reference's OWN PrintMatchData then draws from
+    # sift2[-1] (mainSift.cpp:163-184) — the demo segfaults on such a pair with or without this library.
+    left, right = z["left"][500:600, 700:800], z["left"][500:600, 707:807]
     write_pgm(tmp_path / "data" / "left.pgm", left)
     write_pgm(tmp_path / "data" / "righ.pgm", right)
     r = subprocess.run([BIN, "0", "1"], cwd=tmp_path, env=dict(os.environ, MISIFT_QUIET="1"), capture_output=True, text=True,
@@ -71,4 +77,6 @@ def test_reference_main_on_a_100x100_image(tmp_path):
     from oracle import pyoracle as orc
     _, n1, _ = orc.extract(left.astype(np.float32), 5, 1.0, 4.5)
     _, n2, _ = orc.extract(right.astype(np.float32), 5, 1.0, 4.5)
-    assert (int(m.group(1)), int(m.group(2))) == (n1, n2)
+    assert (int(m.group(1)), int(m.group(2))) == (n1, n2) and n1 > 64 and n2 > 64
+    m2 = re.search(r"Number of matching features: (\d+) (\d+)", r.stdout)
+    assert m2 and int(m2.group(2)) >= 8, r.stdout[-1500:]            # the 7-px shift is found

@@ -71,7 +71,8 @@ def test_extract_equals_reference_kernels(ctx, stereo, golden, name, noct, th, u
         ctx.set_options(fused=saved.fused)
     assert n == int(golden[name + "_n"])
     compare_with_reference(pts, cnt, golden[name + "_records"], golden[name + "_counters"], noct,
-                           "hip_vs_reference_golden/%s_fused%d" % (name, fused), "ulp", record, flip_budget=flips, desc_stride=4 if name in ("wide", "righ", "crop_up") else 1)
+                           "hip_vs_reference_golden/%s_fused%d" % (name, fused), "ulp", record, flip_budget=flips, desc_stride=4 if name in ("wide", "righ", "crop_up") else 1,
+                           img=img, scale_up=up)
 
 
 def test_match_equals_reference_kernel(ctx, golden):

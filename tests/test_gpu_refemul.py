@@ -31,7 +31,7 @@ def test_hip_equals_emulated_reference_on_fresh_frames(ctx, seed, w, h, noct, th
     pts, n, cnt = ctx.extract(img, num_octaves=noct, init_blur=1.0, thresh=th)
     assert n == r_n
     compare_with_reference(pts, cnt, r_pts, r_cnt, noct, "hip_vs_emulated_reference/seed%d_%dx%d" % (seed, w, h), "ulp", record,
-                           flip_budget=2)
+                           flip_budget=2, img=img)
 
 
 @pytest.mark.parametrize("w,h,noct,th", [(64, 48, 3, 1.0), (40, 30, 2, 0.5), (31, 17, 1, 0.3), (16, 16, 1, 0.1), (33, 65, 3, 0.5),
@@ -163,4 +163,36 @@ def test_hip_keeps_what_the_reference_cap_drops(ctx):
             assert counts["reference_emulated"] == 1044
     except Exception:                                      # oracle/_ref not built on this box: the CPU suite pins it
         pass
+    # ... and options.reference_cap = 1 is the reference's behaviour: the first 32 extrema of every 30 x 8 block and scale
+    # (by column, then row) — the same 1 044 records as the oracle with its cap on (and as the emulated reference,
+    # tests/test_refemul_cpu.py::test_32_candidates_per_block_cap_against_reference)
+    saved = ctx.get_options()
+    ctx.set_options(reference_cap=1)
+    try:
+        c_pts, c_n = ctx.findpoints(dog, 1.0)
+    finally:
+        ctx.set_options(reference_cap=saved.reference_cap)
+    with orc.reference_cap(1):
+        oc_pts, oc_n = orc.findpoints(dog, 1.0)
+    assert c_n == oc_n == 1044, (c_n, oc_n)
+    assert key(c_pts, c_n) == key(oc_pts, oc_n)
+    counts["hip_reference_cap"] = int(c_n)
     record("reference_32_per_block_cap", **counts)
+
+
+def test_reference_cap_option_through_extract(ctx):
+    """options.reference_cap routes ExtractSift through the dense kernels + the cap; on a natural frame no block comes near
+    32 extrema, so the records are the default path's."""
+    from oracle import pyoracle as orc
+    from util import compare_points
+    img = synth_frame(120, 640, 480)
+    want, wn, wcnt = orc.extract(img, 4, 1.0, 2.0)
+    saved = ctx.get_options()
+    ctx.set_options(reference_cap=1)
+    try:
+        got, n, cnt = ctx.extract(img, num_octaves=4, init_blur=1.0, thresh=2.0)
+        bp, bn = ctx.extract_batch(np.stack([img, img[::-1].copy()]), num_octaves=4, thresh=2.0)[:2]
+    finally:
+        ctx.set_options(reference_cap=saved.reference_cap)
+    assert n == wn and np.array_equal(cnt, wcnt) and bn[0] == wn
+    compare_points(want[:wn], got[:n], "reference_cap_extract", record)

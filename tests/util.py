@@ -142,9 +142,40 @@ def tail_budget(n, rate):
 # ------------------------------------------------------------------ against the reference's own kernels
 # (oracle/_ref/libcudasift_refemul_*.so = the reference's cudaSiftH.cu/cudaSiftD.cu/matching.cu on the CPU SIMT
 # emulator, or the vectors it produced: tests/golden/refemul_golden.npz)
-def compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, name, strict, record=None, nan_guards=None, flip_budget=0, desc_stride=1):
+BOUND_ULPS = 4.0       # coordinate difference allowed for between the two sides, in units in the last place (see below)
+BOUND_SLACK = 2e-5     # summation order + the elementary functions' own 1-2 ulp on top of the weight flips
+
+
+def descriptor_tail_bound(img, recs_a, recs_b, noct, init_blur, scale_up=False):
+    """Per-record, per-element check of the descriptor tail (the tail used to be accepted as a RATE
+    only).  For every associated pair whose descriptors differ by more than 1e-4 somewhere: the difference of EVERY element
+    must stay below oracle.descriptor_bounds() — what a last-bit difference of the sample coordinates (BOUND_ULPS ulp) can
+    do through the 8-bit texture weights: (1/256) x the local texel difference of each fetch that sits on a rounding tie,
+    carried through gradient magnitude, angle split, vote weights and both normalisations; plus the angi = 8 <-> 0 seam
+    (Appendix B #6).  A difference of the same size but of any other origin is over the bound and fails.
+    Returns (records checked, worst difference / bound)."""
+    from oracle import pyoracle as orc
+    dd = np.abs(recs_a["data"].astype(np.float64) - recs_b["data"])
+    big = np.where(dd.max(axis=1) > 1e-4)[0]
+    if len(big) == 0 or scale_up:            # (scale_up: the pyramid starts from the up-sampled image; not rebuilt here)
+        return 0, 0.0
+    bound, flips, wraps = orc.descriptor_bounds(img, recs_a[big], len(big), noct, init_blur, BOUND_ULPS)
+    excess = dd[big] - (bound + BOUND_SLACK)
+    worst = float((dd[big] / (bound + BOUND_SLACK)).max())
+    bad = np.where(excess.max(axis=1) > 0)[0]
+    assert len(bad) == 0, ("descriptor difference over the texture-weight bound", [
+        {"xpos": float(recs_a["xpos"][big[j]]), "ypos": float(recs_a["ypos"][big[j]]), "element": int(excess[j].argmax()),
+         "diff": float(dd[big[j]][excess[j].argmax()]), "bound": float(bound[j][excess[j].argmax()]), "tie_fetches": int(flips[j]),
+         "seam_samples": int(wraps[j])} for j in bad[:5]])
+    return int(len(big)), worst
+
+
+def compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, name, strict, record=None, nan_guards=None, flip_budget=0, desc_stride=1,
+                           img=None, init_blur=1.0, scale_up=False):
     """o_* = oracle, r_* = emulated reference.  Asserts the pin; returns the statistics.
-    strict: "bits" (same contraction on both sides), "ulp" (oracle without contraction), "" (reference without)."""
+    strict: "bits" (same contraction on both sides), "ulp" (oracle without contraction), "" (reference without).
+    img: the image both sides extracted from — every record over 1e-4 is then checked against its own bound
+    (descriptor_tail_bound) on top of the rate budget."""
     assert np.array_equal(o_cnt, r_cnt), (name, o_cnt, r_cnt)                       # all 17 counters of d_PointCounter
     total = int(o_cnt[2 * noct + 1])
     O, R = o_pts[:total], r_pts[:total]
@@ -172,6 +203,8 @@ def compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, name, strict, recor
     st["desc_over_1e-3"] = int((dd > 1e-3).sum())
     st["desc_max"] = float(dd.max())
     st["desc_min_cos"] = float(cos.min())
+    if img is not None and strict and desc_stride == 1:
+        st["desc_bound_checked"], st["desc_worst_diff_over_bound"] = descriptor_tail_bound(img, A[ok], B[ok], noct, init_blur, scale_up)
     if record:
         record(name, **st)
     tol = 5e-7 if strict else 3e-4
