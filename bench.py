@@ -143,17 +143,23 @@ def pmc_child():
     ctx.set_options(quiet=1)
     nsteps = int(os.environ.get("BENCH_CHILD_STEPS", "4"))
     pipelined = os.environ.get("BENCH_CHILD_PIPELINED", "0") == "1"      # trace pass: queued back to back like the timed loop
+    ring = int(os.environ.get("BENCH_CHILD_RING", "1"))                  # tools/overlap_report.py: K batches in flight, like `value`
+    if ring > 1:
+        ctx.set_batches_in_flight(ring)
     nb = 4 if pipelined else 1       # distinct batches to rotate over: the 256 MB Infinity Cache must not serve the input
     frames = gen_frames_torch(torch, nb * B, 0, device)
-    scratch = torch.empty((B * capi.scratch_floats(W, H, NUM_OCTAVES, False),), dtype=torch.float32, device=device)
-    packed = torch.empty((B * MAX_PTS * 576,), dtype=torch.uint8, device=device)
-    cnts = torch.zeros((2 * B + 1,), dtype=torch.int32, device=device)
+    S = capi.scratch_floats(W, H, NUM_OCTAVES, False)
+    scratch = [torch.empty((B * S,), dtype=torch.float32, device=device) for _ in range(ring)]
+    packed = [torch.empty((B * MAX_PTS * 576,), dtype=torch.uint8, device=device) for _ in range(ring)]
+    cnts = [torch.zeros((2 * B + 1,), dtype=torch.int32, device=device) for _ in range(ring)]
     for it in range(nsteps):
+        r = it % ring
         capi.check(capi.lib().misift_extract_batch_packed_async(
-            ctx.h, frames[(it % nb) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch.data_ptr(), None,
-            MAX_PTS, cnts.data_ptr(), cnts[B:].data_ptr(), packed.data_ptr()), "misift_extract_batch_packed_async")
+            ctx.h, frames[(it % nb) * B].data_ptr(), B, H * W, W, H, W, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scratch[r].data_ptr(), None,
+            MAX_PTS, cnts[r].data_ptr(), cnts[r][B:].data_ptr(), packed[r].data_ptr()), "misift_extract_batch_packed_async")
         if not pipelined:
             torch.cuda.synchronize()
+    ctx.sync()
     torch.cuda.synchronize()
     ctx.close()
 
@@ -255,6 +261,13 @@ def collect_sq(frames_per_launch, timeout_s=240):
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
                 if k in KERNEL_NAMES and r["Counter_Name"] in key:
                     res[KERNEL_NAMES[k]][key[r["Counter_Name"]]] += float(r["Counter_Value"]) / 4.0      # 4 steps
+        # dispatch durations of the SAME pass (kernels run one at a time under --pmc): GRBM_GUI_ACTIVE / duration = shader clock
+        for tf in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+            with open(tf) as f:
+                for r in csv.DictReader(f):
+                    k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+                    if k in KERNEL_NAMES and KERNEL_NAMES[k] in res:
+                        res[KERNEL_NAMES[k]]["ms"] = res[KERNEL_NAMES[k]].get("ms", 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 / 4.0
         return dict(res), None
     except Exception as e:                                   # noqa: BLE001 — the bench line must still come out
         return None, "SQ counter pass failed: %r" % (e,)
@@ -844,9 +857,11 @@ def parse_args():
                          "then stretched by its neighbours, so the per-kernel roofline is quoted on the default, 1")
     ap.add_argument("--batches-in-flight", type=int, default=0,
                     help="pipelines INSIDE the context (misift_ctx_set_batches_in_flight): consecutive batches overlap on the GPU "
-                         "behind ONE context.  0 = auto: 4 for runs of >= 50 timed steps, 2 for shorter ones (the timed region "
-                         "starts and ends with an empty pipeline: 20 steps measure 48.7 / 53.1 / 50.4 k frames/s at K = 1 / 2 / 4, "
-                         "100 steps 51.7 / 54.4 / 55.5 k).  The per-kernel roofline durations always come from a K = 1 child run")
+                         "behind ONE context.  0 = auto = 2 (r05, three alternating runs each on one box, 100 timed steps: K = 2 "
+                         "58.6 / 57.3 / 58.4 k frames/s, K = 4 56.8 / 58.0 / 55.6 k, K = 3 53.1 / 55.6 / 52.9 k, K = 1 51.2 k; with "
+                         "4-5 kernels of different batches resident every small dependent kernel of a batch waits for a slot "
+                         "behind the others' big ones — tools/overlap_report.py, profiles/r05_overlap_K4.txt).  The per-kernel "
+                         "roofline durations always come from a K = 1 child run")
     ap.add_argument("--match-n", type=int, default=100000)
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg AND the oracle self-validation")
@@ -1545,13 +1560,14 @@ class Bench:
         if self.sq:
             insts = sum(e["insts"] for e in self.sq.values())
             active = 4.0 * sum(e["active_quad_cycles"] for e in self.sq.values())
-            clk = None
-            if self.pmc and self.trace:
-                # shader clock under these kernels: cycles the dispatch was active / its duration, over the big kernels
-                num = sum(self.sq[k]["gui_cycles"] for k in ("dog_scan", "descr_all", "lowpass_down") if k in self.sq and k in self.trace)
-                den = sum(self.trace[k]["ms_per_step"] for k in ("dog_scan", "descr_all", "lowpass_down") if k in self.sq and k in self.trace)
-                if den > 0:
-                    clk = num / (den * 1e-3)
+            # shader clock under these kernels: cycles the dispatch was active / its duration in the same counter pass, over the
+            # big kernels (GRBM_GUI_ACTIVE may be reported per XCD and summed: a figure 8x too large is divided down)
+            clk = clk_raw = None
+            big = [k for k in ("dog_scan", "descr_all", "lowpass_down") if k in self.sq and self.sq[k].get("ms", 0) > 0]
+            if big:
+                clk_raw = sum(self.sq[k]["gui_cycles"] for k in big) / (sum(self.sq[k]["ms"] for k in big) * 1e-3)
+                clk = clk_raw / 8.0 if clk_raw > 4.0e9 else clk_raw
+            issue["clock_raw_GHz"] = round(clk_raw / 1e9, 3) if clk_raw else None
             clk_used = clk if clk and 1.0e9 < clk < 2.6e9 else 2.4e9
             simd_cycles = 1024.0 * clk_used * self.ms_per_step * 1e-3
             issue.update({"insts_per_step": int(insts), "active_simd_cycles_per_step": int(active),
@@ -1757,7 +1773,7 @@ def main():
     if args.spawn_check:
         sys.exit(spawn_check())
     if args.batches_in_flight <= 0:
-        args.batches_in_flight = 4 if args.steps >= 50 else 2
+        args.batches_in_flight = 2
     # HIP multiplexes a process's streams onto 4 hardware queues unless told otherwise, and a stream that shares a
     # queue with the extraction stream runs BEHIND the batches queued there: the gather's communication stream then
     # completes batch k-2 only after batch k, the host cannot run ahead and the pipeline loses its depth (1 rank through

@@ -325,6 +325,10 @@ struct misift_ctx {
   int cap_det_frames, det_max_pts;
   float *d_own_scratch;         // scratch allocated on behalf of the caller (NULL tempMemory)
   size_t own_scratch_floats;
+  // developer knobs: bytes of dynamic LDS added to a launch, i.e. a cap on the workgroups of that kernel a CU holds at once
+  // (160 KB per CU: > 53.4 KB -> 2, > 40 KB -> 3), leaving wave slots and registers to the kernels of the OTHER batches in
+  // flight (MISIFT_LDS_PAD_LPD / _SCAN / _ORIENT / _DESCR; 0 = none)
+  int lds_pad_lpd, lds_pad_scan, lds_pad_orient, lds_pad_descr;
   unsigned *d_refcap;           // options.reference_cap: 240-bit extremum masks of the reference's 30 x 8 blocks (launch_refcap)
   size_t refcap_bytes;
   void *d_match_tmp;            // matcher partial results

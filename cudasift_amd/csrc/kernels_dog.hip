@@ -1532,7 +1532,7 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
   }
   const dim3 grid((unsigned)((items + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK) + (unsigned)nchain);
   LaunchScope ls(ctx, "dog_scan");
-#define SCAN_LAUNCH(F, CH) hipLaunchKernelGGL((dog_scan_all_kernel<F, CH>), grid, dim3(256), 0, ctx->stream, scratch, G, at, \
+#define SCAN_LAUNCH(F, CH) hipLaunchKernelGGL((dog_scan_all_kernel<F, CH>), grid, dim3(256), (size_t)ctx->lds_pad_scan, ctx->stream, scratch, G, at, \
                                               thresh, ctx->d_counters, ctx->d_cand, C, t5, nchain)
   if (chain) {
     if (fast && !ragged) SCAN_LAUNCH(1, true);

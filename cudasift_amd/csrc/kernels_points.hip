@@ -1511,7 +1511,7 @@ __global__ __launch_bounds__(256) void frame_shares_kernel(const unsigned *__res
 }
 
 // ---- the r01 forms of the two merged-octave kernels: bilinear fetches straight from global memory (no staged
-// tile), 4 waves/SIMD.  Selected with MISIFT_TILE=0 (A/B measurements).
+// tile), 4 waves/SIMD.  Selected with MISIFT_TILE=0 (A/B measurements, docs/LOG.md section 9).
 // 90 VGPRs: 5 waves/SIMD (the kernel is bound by the dependent LDS / shuffle chain of one keypoint per wavefront, so
 // every extra resident wavefront helps)
 template <bool Q8, bool BAL>
@@ -1815,14 +1815,14 @@ int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
   if (ctx->tile_orient) LAUNCH_Q8(orient_all_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, max_pts, 0);
   else if (ctx->cur_balanced) {
     const dim3 flat(ctx->map_t_orient);
-    if (q8) hipLaunchKernelGGL((orient_all_gather_kernel<true, true>), flat, dim3(256), 0, ctx->stream, scratch, P,
+    if (q8) hipLaunchKernelGGL((orient_all_gather_kernel<true, true>), flat, dim3(256), (size_t)ctx->lds_pad_orient, ctx->stream, scratch, P,
                                ctx->d_counters, det, max_pts, 0, ctx->d_block_map);
-    else hipLaunchKernelGGL((orient_all_gather_kernel<false, true>), flat, dim3(256), 0, ctx->stream, scratch, P,
+    else hipLaunchKernelGGL((orient_all_gather_kernel<false, true>), flat, dim3(256), (size_t)ctx->lds_pad_orient, ctx->stream, scratch, P,
                             ctx->d_counters, det, max_pts, 0, ctx->d_block_map);
   } else {
-    if (q8) hipLaunchKernelGGL((orient_all_gather_kernel<true, false>), grid, dim3(256), 0, ctx->stream, scratch, P,
+    if (q8) hipLaunchKernelGGL((orient_all_gather_kernel<true, false>), grid, dim3(256), (size_t)ctx->lds_pad_orient, ctx->stream, scratch, P,
                                ctx->d_counters, det, max_pts, 0, (const int4 *)nullptr);
-    else hipLaunchKernelGGL((orient_all_gather_kernel<false, false>), grid, dim3(256), 0, ctx->stream, scratch, P,
+    else hipLaunchKernelGGL((orient_all_gather_kernel<false, false>), grid, dim3(256), (size_t)ctx->lds_pad_orient, ctx->stream, scratch, P,
                             ctx->d_counters, det, max_pts, 0, (const int4 *)nullptr);
   }
   return ls.finish();
@@ -1848,7 +1848,7 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
     const bool bal = ctx->cur_balanced != 0;
     const dim3 dgrid = bal ? dim3(ctx->map_t_descr) : grid;
     const int4 *bmap = bal ? ctx->d_block_map + ctx->map_t_orient : nullptr;
-#define DESCR_LAUNCH(Q, O, B) hipLaunchKernelGGL((descr_all_kernel<Q, O, B>), dgrid, dim3(256), 0, ctx->stream, scratch, P, \
+#define DESCR_LAUNCH(Q, O, B) hipLaunchKernelGGL((descr_all_kernel<Q, O, B>), dgrid, dim3(256), (size_t)ctx->lds_pad_descr, ctx->stream, scratch, P, \
                                                  ctx->d_counters, det, pts, max_pts, 0, pack_offsets, pack_dst, ctx->d_cand, \
                                                  big_stride, bmap)
 #define DESCR_LAUNCH_B(Q, O) do { if (bal) DESCR_LAUNCH(Q, O, true); else DESCR_LAUNCH(Q, O, false); } while (0)

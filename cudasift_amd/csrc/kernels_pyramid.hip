@@ -618,15 +618,15 @@ int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const Stri
   const bool rag = (g.width & 3) != 0;
   if (src_u8) {
     const unsigned char *s8 = static_cast<const unsigned char *>(src);
-    if (rag) hipLaunchKernelGGL((lowpass_down_kernel<unsigned char, 2>), grid_for(g), dim3(256), 0, ctx->stream, s8, g, dst,
+    if (rag) hipLaunchKernelGGL((lowpass_down_kernel<unsigned char, 2>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, s8, g, dst,
                                 dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
-    else hipLaunchKernelGGL((lowpass_down_kernel<unsigned char, 1>), grid_for(g), dim3(256), 0, ctx->stream, s8, g, dst,
+    else hipLaunchKernelGGL((lowpass_down_kernel<unsigned char, 1>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, s8, g, dst,
                             dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
   } else {
     const float *sf = static_cast<const float *>(src);
-    if (rag) hipLaunchKernelGGL((lowpass_down_kernel<float, 2>), grid_for(g), dim3(256), 0, ctx->stream, sf, g, dst, dpitch,
+    if (rag) hipLaunchKernelGGL((lowpass_down_kernel<float, 2>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, sf, g, dst, dpitch,
                                 dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
-    else hipLaunchKernelGGL((lowpass_down_kernel<float, 1>), grid_for(g), dim3(256), 0, ctx->stream, sf, g, dst, dpitch,
+    else hipLaunchKernelGGL((lowpass_down_kernel<float, 1>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, sf, g, dst, dpitch,
                             dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
   }
   *done = 1;

@@ -202,10 +202,11 @@ def extract(img, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, sca
     return pts, n, np.array(list(cnt), dtype=np.uint32)
 
 
-def descriptor_bounds(img, pts, n, num_octaves=5, init_blur=1.0, ulps=3.0):
+def descriptor_bounds(img, pts, n, num_octaves=5, init_blur=1.0, ulps=3.0, dtheta_deg=None):
     """orc_descriptor_bounds: for the first n records of one ExtractSift call on `img`, the largest change of every
     descriptor element that a last-bit difference of the sample coordinates can cause through the 8-bit texture weights
-    (see sift_oracle.c).  Returns (bound[n,128], flips[n], wraps[n])."""
+    (see sift_oracle.c).  dtheta_deg[n]: difference of the two sides' orientations (it turns the whole sample grid).
+    Returns (bound[n,128], flips[n], wraps[n])."""
     img = _f32(img)
     h, w = img.shape
     pts = np.ascontiguousarray(pts[:n])
@@ -213,8 +214,9 @@ def descriptor_bounds(img, pts, n, num_octaves=5, init_blur=1.0, ulps=3.0):
     flips, wraps = np.zeros(n, np.int32), np.zeros(n, np.int32)
     L = lib()
     L.orc_descriptor_bounds.restype = None
-    L.orc_descriptor_bounds(_p(img), w, h, w, num_octaves, C.c_float(init_blur), _p(pts), n, C.c_float(ulps), _p(bound), _p(flips),
-                            _p(wraps))
+    dth = None if dtheta_deg is None else np.ascontiguousarray(dtheta_deg, np.float32)
+    L.orc_descriptor_bounds(_p(img), w, h, w, num_octaves, C.c_float(init_blur), _p(pts), n, C.c_float(ulps),
+                            None if dth is None else _p(dth), _p(bound), _p(flips), _p(wraps))
     return bound, flips, wraps
 
 

@@ -845,7 +845,10 @@ void orc_descriptors(const float *img, int w, int h, int pitch, SiftPoint *pts, 
  * and the two normalisations.  A regression of the same size as the tail but NOT of this origin exceeds the bound.
  *   img/w/h/pitch : the octave image the descriptor was sampled from;  p : the record at THAT octave's scale
  *   bound[128]    : out, largest |change| of each element;  returns the number of fetches that can flip, and in
- *   *wraps the number of samples whose angle sits on the angi = 8 <-> 0 seam (cudaSiftD.cu:353, Appendix B #6). */
+ *   *wraps the number of samples whose angle sits on the angi = 8 <-> 0 seam (cudaSiftD.cu:353, Appendix B #6).
+ *   extra         : further displacement of the sample grid between the two sides, in pixels of this level — the two
+ *                   records' orientations may differ by a few ulp (libm vs written-out atan2 in the histogram peak), which
+ *                   turns the whole grid: |d theta| x the grid's radius */
 static int ialign_up(int a, int b);
 static inline float ulp32(float x)
 {
@@ -856,7 +859,7 @@ static inline float ulp32(float x)
   return ldexpf(1.0f, e - 24);
 }
 
-static float fetch_flip(const float *img, int w, int h, int pitch, float x, float y, float ulps, int *nflip)
+static float fetch_flip(const float *img, int w, int h, int pitch, float x, float y, float ulps, float extra, int *nflip)
 {
   float xb = x - 0.5f, yb = y - 0.5f;
   float fx = floorf(xb), fy = floorf(yb);
@@ -873,12 +876,12 @@ static float fetch_flip(const float *img, int w, int h, int pitch, float x, floa
   float t01 = img[(size_t)y1 * pitch + x0], t11 = img[(size_t)y1 * pitch + x1];
   float d = 0.0f;
   /* a floor() that falls the other way at an integer coordinate changes nothing: weight 0 of one texel = weight 1 of the next */
-  if (da <= 256.0f * ulps * ulp32(x)) { d += (1.0f / 256.0f) * fabsf((1.0f - rb) * (t10 - t00) + rb * (t11 - t01)); (*nflip)++; }
-  if (db <= 256.0f * ulps * ulp32(y)) { d += (1.0f / 256.0f) * fabsf((1.0f - ra) * (t01 - t00) + ra * (t11 - t10)); (*nflip)++; }
+  if (da <= 256.0f * (ulps * ulp32(x) + extra)) { d += (1.0f / 256.0f) * fabsf((1.0f - rb) * (t10 - t00) + rb * (t11 - t01)); (*nflip)++; }
+  if (db <= 256.0f * (ulps * ulp32(y) + extra)) { d += (1.0f / 256.0f) * fabsf((1.0f - ra) * (t01 - t00) + ra * (t11 - t10)); (*nflip)++; }
   return d;
 }
 
-int orc_descriptor_bound(const float *img, int w, int h, int pitch, const SiftPoint *p, float ulps, float *bound, int *wraps)
+int orc_descriptor_bound(const float *img, int w, int h, int pitch, const SiftPoint *p, float ulps, float extra, float *bound, int *wraps)
 {
   float gauss[16];
   for (int t = 0; t < 16; t++) gauss[t] = det_exp(-(t - 7.5f) * (t - 7.5f) / 128.0f);
@@ -897,10 +900,10 @@ int orc_descriptor_bound(const float *img, int w, int h, int pitch, const SiftPo
       float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, 8) - tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, 8);
       float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, 8) - tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, 8);
       int nf = 0;
-      float ddx = fetch_flip(img, w, h, pitch, xpos + cosa, ypos + sina, ulps, &nf) +
-                  fetch_flip(img, w, h, pitch, xpos - cosa, ypos - sina, ulps, &nf);
-      float ddy = fetch_flip(img, w, h, pitch, xpos - sina, ypos + cosa, ulps, &nf) +
-                  fetch_flip(img, w, h, pitch, xpos + sina, ypos - cosa, ulps, &nf);
+      float ddx = fetch_flip(img, w, h, pitch, xpos + cosa, ypos + sina, ulps, extra, &nf) +
+                  fetch_flip(img, w, h, pitch, xpos - cosa, ypos - sina, ulps, extra, &nf);
+      float ddy = fetch_flip(img, w, h, pitch, xpos - sina, ypos + cosa, ulps, extra, &nf) +
+                  fetch_flip(img, w, h, pitch, xpos + sina, ypos - cosa, ulps, extra, &nf);
       nflip += nf;
       float g = sqrtf(dx * dx + dy * dy), gw = gauss[y] * gauss[tx];
       float grad = gw * g;
@@ -960,7 +963,7 @@ int orc_descriptor_bound(const float *img, int w, int h, int pitch, const SiftPo
 /* The same for the records of one ExtractSift call: rebuilds the pyramid of `img` (prefilter + ScaleDowns, as
  * orc_extract does), finds every record's level from its `subsampling`, and writes bound[n][128], flips[n], wraps[n]. */
 void orc_descriptor_bounds(const float *img, int width, int height, int pitch, int numOctaves, float initBlur,
-                           const SiftPoint *pts, int n, float ulps, float *bound, int *flips, int *wraps)
+                           const SiftPoint *pts, int n, float ulps, const float *dtheta_deg, float *bound, int *flips, int *wraps)
 {
   float *lev[16];
   int lw[16], lh[16], lp[16];
@@ -979,7 +982,10 @@ void orc_descriptor_bounds(const float *img, int width, int height, int pitch, i
     while ((float)(1 << k) < pts[i].subsampling && k < numOctaves - 1) k++;
     SiftPoint q = pts[i];
     q.xpos /= q.subsampling; q.ypos /= q.subsampling; q.scale /= q.subsampling;
-    flips[i] = orc_descriptor_bound(lev[k], lw[k], lh[k], lp[k], &q, ulps, bound + (size_t)128 * i, wraps ? &wraps[i] : NULL);
+    /* the grid reaches 7.5 sqrt(2) sample pitches (0.75 x scale px each) + the +-1 px of the central differences from the keypoint */
+    const float radius = 7.5f * 1.41421356f * 0.75f * q.scale + 1.5f;
+    const float extra = dtheta_deg ? fabsf(dtheta_deg[i]) * (3.14159265f / 180.0f) * radius : 0.0f;
+    flips[i] = orc_descriptor_bound(lev[k], lw[k], lh[k], lp[k], &q, ulps, extra, bound + (size_t)128 * i, wraps ? &wraps[i] : NULL);
   }
   for (int k = 0; k < numOctaves; k++) free(lev[k]);
 }

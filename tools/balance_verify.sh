@@ -1,5 +1,5 @@
 #!/bin/bash
-# What has to be green before MISIFT_BALANCE becomes the default: the whole GPU suite with
+# What had to be green before MISIFT_BALANCE became the default (r05: profiles/r05_balance_default_ab.txt): the whole GPU suite with
 # every context of the session balanced, the A/B of tools/balance_ab.py, and the default bench line both ways.
 #   gpurun --timeout 1500 -- 'bash tools/balance_verify.sh'   -> gpurun_out/balance_*.{log,txt,json}
 export TMPDIR=/tmp; mkdir -p gpurun_out

@@ -2,7 +2,7 @@
 """The HIP path against the reference's OWN code, no oracle in between, at scale: N synthetic 1920x1080 frames (+ the stereo
 pair) extracted by libmisift.so on the GPU and by the emulated reference (oracle/_ref/libcudasift_refemul_fast.so: the
 reference's kernels and host code on the CPU SIMT emulator, prebuilt — it travels to the GPU box) -> pooled statistics,
-gpurun_out/r04_hip_vs_refemul.json.  Test infrastructure, like tests/test_gpu_golden.py, which asserts the same on five
+gpurun_out/r05_hip_vs_refemul.json.  Test infrastructure, like tests/test_gpu_golden.py, which asserts the same on five
 committed golden cases."""
 import json
 import os
@@ -51,9 +51,10 @@ for name, img, noct, th, blur, lowest, up in cases:
     rp, rn, rc = ref.extract(img, noct, blur, th, lowest_scale=lowest, scale_up=up, flavour="fast")
     t2 = time.time()
     t_hip += t1 - t0; t_ref += t2 - t1
-    st = stats(hp, hc, rp, rc, noct)
+    st = stats(hp, hc, rp, rc, noct, img=img, init_blur=blur, scale_up=up)
     out["images"].append({"image": name, "numPts_hip": hn, "numPts_reference": rn, "only_hip": st["only_oracle"], **{k: st[k] for k in (
-        "records", "counters_equal", "only_reference", "orientation_flips", "desc_over_0.0001", "desc_over_0.001")}})
+        "records", "counters_equal", "only_reference", "orientation_flips", "desc_over_0.0001", "desc_over_0.001")},
+        "desc_over_bound": st.get("desc_over_bound")})
     for kk, v in st.items():
         if isinstance(v, bool):
             pooled[kk] = pooled.get(kk, True) and v
@@ -67,8 +68,8 @@ for name, img, noct, th, blur, lowest, up in cases:
 pooled["only_hip"] = pooled.pop("only_oracle")          # stats() names its first argument "oracle"
 out["pooled_hip_vs_reference"] = pooled
 out["seconds"] = {"hip_single_frame_calls_incl_upload": round(t_hip, 2), "emulated_reference": round(t_ref, 2)}
-path = os.path.join(ROOT, "gpurun_out", "r04_hip_vs_refemul_variants.json" if os.environ.get("HVR_VARIANTS") else
-                    "r04_hip_vs_refemul.json" if N else "r04_hip_vs_refemul_match.json")
+path = os.path.join(ROOT, "gpurun_out", "r05_hip_vs_refemul_variants.json" if os.environ.get("HVR_VARIANTS") else
+                    "r05_hip_vs_refemul.json" if N else "r05_hip_vs_refemul_match.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(pooled, indent=1))

@@ -18,7 +18,9 @@ from synth import synth_frame                           # noqa: E402
 import util                                             # noqa: E402
 
 
-def stats(o_pts, o_cnt, r_pts, r_cnt, noct):
+def stats(o_pts, o_cnt, r_pts, r_cnt, noct, img=None, init_blur=1.0, scale_up=False):
+    """img: the image both sides extracted from -> every descriptor pair over 1e-4 is also checked element by element against
+    its texture-weight bound (oracle.descriptor_bounds, tests/util.py BOUND_*): desc_over_bound counts the failures."""
     total = int(o_cnt[2 * noct + 1])
     st = {"counters_equal": bool(np.array_equal(o_cnt, r_cnt)), "records": total}
     O, R = o_pts[:total], r_pts[:int(r_cnt[2 * noct + 1])]
@@ -39,6 +41,16 @@ def stats(o_pts, o_cnt, r_pts, r_cnt, noct):
         st["desc_over_%g" % t] = int((dd > t).sum())
     st["desc_max"] = float(dd.max()) if len(dd) else 0.0
     st["desc_min_cos"] = float((A["data"][ok].astype(np.float64) * B["data"][ok]).sum(axis=1).min()) if ok.any() else 1.0
+    if img is not None and not scale_up:
+        big = np.where(dd > 1e-4)[0]
+        st["desc_bound_checked"], st["desc_over_bound"], st["desc_diff_over_bound_max"] = int(len(big)), 0, 0.0
+        if len(big):
+            Ab, Bb = A[ok][big], B[ok][big]
+            bound, _, _ = orc.descriptor_bounds(img, Ab, len(big), noct, init_blur, util.BOUND_ULPS,
+                                                dtheta_deg=util.circ_diff_deg(Ab["orientation"], Bb["orientation"]))
+            r = (np.abs(Ab["data"].astype(np.float64) - Bb["data"]) / (bound + util.BOUND_SLACK)).max(axis=1)
+            st["desc_over_bound"] = int((r > 1.0).sum())
+            st["desc_diff_over_bound_max"] = float(r.max())
     return st
 
 
