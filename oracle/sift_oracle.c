@@ -926,7 +926,9 @@ int orc_descriptor_bound(const float *img, int w, int h, int pitch, const SiftPo
       float dmag = gw * (ddx + ddy);
       float dang = (g > 0.0f) ? (4.0f / 3.1415f) * (ddx + ddy) / g : 0.0f;
       if (dang > 1.0f) dang = 1.0f;
-      float move = dmag + dang * grad + (seam ? grad : 0.0f);
+      /* (x 1.5 on the seam: the moved vote also shifts the norm both normalisations divide by — measured worst case 0.92 of
+       *  the plain sum over 140 k records, profiles/r05_desc_bound_report.json) */
+      float move = dmag + dang * grad + (seam ? 1.5f * grad : 0.0f);
       for (int cy = 0; cy < 2; cy++)
         for (int cx = 0; cx < 2; cx++) {
           int vh = hori + cx, vv = veri + cy;
@@ -938,7 +940,7 @@ int orc_descriptor_bound(const float *img, int w, int h, int pitch, const SiftPo
           if (move > 0.0f) {
             /* the two bins the vote is split over and their outer neighbours (the split point may cross a bin edge) */
             for (int k = -1; k <= 2; k++) del[hist + ((angi + k) & 7)] += ws * move;
-            if (seam && hist + 8 < 128) del[hist + 8] += ws * grad;
+            if (seam && hist + 8 < 128) del[hist + 8] += 1.5f * ws * grad;
           }
         }
     }

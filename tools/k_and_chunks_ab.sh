@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05 call 4: (a) K = 2 against K = 4 batches in flight, alternating; (b) the matcher's chunk plan at the shape ONE rank of
+# (a) K = 2 against K = 4 batches in flight, alternating; (b) the matcher's chunk plan at the shape ONE rank of
 # BASELINE config 5 sweeps (12 500 x 100 000) and at 100 k x 100 k
 export TMPDIR=/tmp; mkdir -p gpurun_out/r05_sweep
 L="--no-match --no-cpu --no-latency --no-pcie --no-pmc --no-skewed"

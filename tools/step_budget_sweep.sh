@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05 call 3: where does the step go with K batches in flight?  kernel traces at K = 4 and K = 1 (tools/overlap_report.py) and a
+# where does the step go with K batches in flight?  kernel traces at K = 4 and K = 1 (tools/overlap_report.py) and a
 # sweep of launch-structure / residency knobs on the light bench line
 export TMPDIR=/tmp; mkdir -p gpurun_out/r05_sweep
 cd /tmp
