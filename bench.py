@@ -1558,6 +1558,8 @@ class Bench:
                          "tools/valu_rates: 2.85 plain / 4.45 packed / 4.7 DPP, integer, select) / the same denominator",
                  "source": self.sq_note}
         if self.sq:
+            issue["source"] = ("collected live in this run: rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "
+                               "over 4 steps of the timed entry point")
             insts = sum(e["insts"] for e in self.sq.values())
             active = 4.0 * sum(e["active_quad_cycles"] for e in self.sq.values())
             # shader clock under these kernels: cycles the dispatch was active / its duration in the same counter pass, over the

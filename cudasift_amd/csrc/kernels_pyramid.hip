@@ -158,15 +158,13 @@ __global__ __launch_bounds__(256, 4) void lowpass_kernel(const SRC *__restrict__
 #define FUSED_OUT_LANES 60
 // MODE 1: width % 4 == 0; MODE 2: any width (ragged last quad, see clamp_quad in common.hpp).
 template <typename SRC, int MODE>
-__global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restrict__ src, StripGeom g,
-                                                              float *__restrict__ dst, int dpitch,
-                                                              long long dst_frame_stride, Taps5 t,
-                                                              float *__restrict__ dst2, int dpitch2,
-                                                              long long dst2_frame_stride, Taps5 t5,
-                                                              unsigned *__restrict__ zero_cnt)
+__device__ __forceinline__ void lowpass_down_item(const SRC *__restrict__ src, const StripGeom &g,
+                                                  float *__restrict__ dst, int dpitch,
+                                                  long long dst_frame_stride, const Taps5 &t,
+                                                  float *__restrict__ dst2, int dpitch2,
+                                                  long long dst2_frame_stride, const Taps5 &t5,
+                                                  unsigned *__restrict__ zero_cnt, const ItemCoord &it)
 {
-  const ItemCoord it = decode_item(g);
-  if (!it.valid) return;
   const int lane = threadIdx.x & 63;
   zero_frame_counters(zero_cnt, it, lane, g.nframes);
   const int q = it.strip * FUSED_OUT_LANES + lane - 2;
@@ -292,6 +290,47 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
   }
   // last segment of an even-height image: row `height` clamps to row height-1
   if (y1 == g.height && (g.height & 1) == 0) emit((g.height - 2) >> 1, a1, a2, a3, a4, a4);
+}
+
+template <typename SRC, int MODE>
+__global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restrict__ src, StripGeom g,
+                                                              float *__restrict__ dst, int dpitch,
+                                                              long long dst_frame_stride, Taps5 t,
+                                                              float *__restrict__ dst2, int dpitch2,
+                                                              long long dst2_frame_stride, Taps5 t5,
+                                                              unsigned *__restrict__ zero_cnt)
+{
+  const ItemCoord it = decode_item(g);
+  if (!it.valid) return;
+  lowpass_down_item<SRC, MODE>(src, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt, it);
+}
+
+// The same with FEWER workgroups than blocks of items, every workgroup walking over several (MISIFT_LPD_PERSIST =
+// workgroups per CU): a cap on how many wave slots of the chip this HBM-bound kernel holds while the VALU-bound kernels
+// of the other batch in flight want them (r05 experiment; a kernel of its own so that the default one stays as it was).
+template <typename SRC, int MODE>
+__global__ __launch_bounds__(256, 4) void lowpass_down_persist_kernel(const SRC *__restrict__ src, StripGeom g,
+                                                                      float *__restrict__ dst, int dpitch,
+                                                                      long long dst_frame_stride, Taps5 t,
+                                                                      float *__restrict__ dst2, int dpitch2,
+                                                                      long long dst2_frame_stride, Taps5 t5,
+                                                                      unsigned *__restrict__ zero_cnt)
+{
+  const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
+  const unsigned nblocks = (unsigned)((nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#pragma unroll 1
+  for (unsigned b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const long long item = (long long)b * WAVES_PER_BLOCK + wave;
+    if (item >= nitems) break;
+    ItemCoord it;
+    it.valid = true;
+    it.strip = (int)(item % g.nstrips);           // strip-fastest, like decode_item with noremap & 2
+    const long long r = item / g.nstrips;
+    it.seg = (int)(r % g.nsegs);
+    it.frame = (int)(r / g.nsegs);
+    lowpass_down_item<SRC, MODE>(src, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt, it);
+  }
 }
 
 // ------------------------------------- LowPass + first ScaleDown, tiled (small batches, r04)
@@ -613,22 +652,28 @@ int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const Stri
   for (int j = 0; j <= 4; j++) t.k[j] = k9[4 - j];
   for (int j = 0; j < 5; j++) t5.k[j] = k5[j];
   LaunchScope ls(ctx, "lowpass_down");
+  dim3 lpd_grid = grid_for(g);
+  if (ctx->lpd_persist > 0 && g.nframes > ctx->small_frames) {
+    const unsigned cap = (unsigned)ctx->lpd_persist * (unsigned)ctx->num_cus;
+    if (lpd_grid.x > cap) lpd_grid.x = cap;
+  }
   // widths that are not a multiple of 4 (r03): the same kernel with the ragged-quad loads; the aligned rows checked
   // above make the row pitch a multiple of 4, so the partial quad's dwordx4 stays inside the row
   const bool rag = (g.width & 3) != 0;
+  const bool persist = ctx->lpd_persist > 0 && g.nframes > ctx->small_frames && lpd_grid.x < grid_for(g).x;
+#define LPD_LAUNCH(T, M, P) do { \
+    if (persist) hipLaunchKernelGGL((lowpass_down_persist_kernel<T, M>), lpd_grid, dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, \
+                                    P, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt); \
+    else hipLaunchKernelGGL((lowpass_down_kernel<T, M>), lpd_grid, dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, \
+                            P, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt); } while (0)
   if (src_u8) {
     const unsigned char *s8 = static_cast<const unsigned char *>(src);
-    if (rag) hipLaunchKernelGGL((lowpass_down_kernel<unsigned char, 2>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, s8, g, dst,
-                                dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
-    else hipLaunchKernelGGL((lowpass_down_kernel<unsigned char, 1>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, s8, g, dst,
-                            dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
+    if (rag) LPD_LAUNCH(unsigned char, 2, s8); else LPD_LAUNCH(unsigned char, 1, s8);
   } else {
     const float *sf = static_cast<const float *>(src);
-    if (rag) hipLaunchKernelGGL((lowpass_down_kernel<float, 2>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, sf, g, dst, dpitch,
-                                dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
-    else hipLaunchKernelGGL((lowpass_down_kernel<float, 1>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, sf, g, dst, dpitch,
-                            dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt);
+    if (rag) LPD_LAUNCH(float, 2, sf); else LPD_LAUNCH(float, 1, sf);
   }
+#undef LPD_LAUNCH
   *done = 1;
   return ls.finish();
 }
