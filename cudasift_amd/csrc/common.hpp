@@ -329,7 +329,6 @@ struct misift_ctx {
   // (160 KB per CU: > 53.4 KB -> 2, > 40 KB -> 3), leaving wave slots and registers to the kernels of the OTHER batches in
   // flight (MISIFT_LDS_PAD_LPD / _SCAN / _ORIENT / _DESCR; 0 = none)
   int lds_pad_lpd, lds_pad_scan, lds_pad_orient, lds_pad_descr;
-  int lpd_persist;              // > 0: lowpass_down launched with this many workgroups per CU, each walking over several items (MISIFT_LPD_PERSIST)
   unsigned *d_refcap;           // options.reference_cap: 240-bit extremum masks of the reference's 30 x 8 blocks (launch_refcap)
   size_t refcap_bytes;
   void *d_match_tmp;            // matcher partial results

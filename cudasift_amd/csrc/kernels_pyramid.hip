@@ -305,34 +305,6 @@ __global__ __launch_bounds__(256, 4) void lowpass_down_kernel(const SRC *__restr
   lowpass_down_item<SRC, MODE>(src, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt, it);
 }
 
-// The same with FEWER workgroups than blocks of items, every workgroup walking over several (MISIFT_LPD_PERSIST =
-// workgroups per CU): a cap on how many wave slots of the chip this HBM-bound kernel holds while the VALU-bound kernels
-// of the other batch in flight want them (r05 experiment; a kernel of its own so that the default one stays as it was).
-template <typename SRC, int MODE>
-__global__ __launch_bounds__(256, 4) void lowpass_down_persist_kernel(const SRC *__restrict__ src, StripGeom g,
-                                                                      float *__restrict__ dst, int dpitch,
-                                                                      long long dst_frame_stride, Taps5 t,
-                                                                      float *__restrict__ dst2, int dpitch2,
-                                                                      long long dst2_frame_stride, Taps5 t5,
-                                                                      unsigned *__restrict__ zero_cnt)
-{
-  const long long nitems = (long long)g.nframes * g.nstrips * g.nsegs;
-  const unsigned nblocks = (unsigned)((nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#pragma unroll 1
-  for (unsigned b = blockIdx.x; b < nblocks; b += gridDim.x) {
-    const long long item = (long long)b * WAVES_PER_BLOCK + wave;
-    if (item >= nitems) break;
-    ItemCoord it;
-    it.valid = true;
-    it.strip = (int)(item % g.nstrips);           // strip-fastest, like decode_item with noremap & 2
-    const long long r = item / g.nstrips;
-    it.seg = (int)(r % g.nsegs);
-    it.frame = (int)(r / g.nsegs);
-    lowpass_down_item<SRC, MODE>(src, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt, it);
-  }
-}
-
 // ------------------------------------- LowPass + first ScaleDown, tiled (small batches, r04)
 // The streamed kernel above is built for throughput: a wavefront walks a 240-pixel strip row by row, 8 rows of prologue
 // before its first output row, ~19 dependent rows for an 8-row segment.  For ONE frame that is a latency chain at one
@@ -652,20 +624,13 @@ int launch_lowpass_down(misift_ctx *ctx, const void *src, int src_u8, const Stri
   for (int j = 0; j <= 4; j++) t.k[j] = k9[4 - j];
   for (int j = 0; j < 5; j++) t5.k[j] = k5[j];
   LaunchScope ls(ctx, "lowpass_down");
-  dim3 lpd_grid = grid_for(g);
-  if (ctx->lpd_persist > 0 && g.nframes > ctx->small_frames) {
-    const unsigned cap = (unsigned)ctx->lpd_persist * (unsigned)ctx->num_cus;
-    if (lpd_grid.x > cap) lpd_grid.x = cap;
-  }
+  // (r05 tried this kernel with a capped grid — 1-3 workgroups per CU, each walking over several items, so that the
+  //  HBM-bound prefilter leaves wave slots to the other batch's VALU-bound kernels: no gain, profiles/r05_lpd_persist_ab.txt)
   // widths that are not a multiple of 4 (r03): the same kernel with the ragged-quad loads; the aligned rows checked
   // above make the row pitch a multiple of 4, so the partial quad's dwordx4 stays inside the row
   const bool rag = (g.width & 3) != 0;
-  const bool persist = ctx->lpd_persist > 0 && g.nframes > ctx->small_frames && lpd_grid.x < grid_for(g).x;
-#define LPD_LAUNCH(T, M, P) do { \
-    if (persist) hipLaunchKernelGGL((lowpass_down_persist_kernel<T, M>), lpd_grid, dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, \
-                                    P, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt); \
-    else hipLaunchKernelGGL((lowpass_down_kernel<T, M>), lpd_grid, dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, \
-                            P, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt); } while (0)
+#define LPD_LAUNCH(T, M, P) hipLaunchKernelGGL((lowpass_down_kernel<T, M>), grid_for(g), dim3(256), (size_t)ctx->lds_pad_lpd, ctx->stream, \
+                                               P, g, dst, dpitch, dst_frame_stride, t, dst2, dpitch2, dst2_frame_stride, t5, zero_cnt)
   if (src_u8) {
     const unsigned char *s8 = static_cast<const unsigned char *>(src);
     if (rag) LPD_LAUNCH(unsigned char, 2, s8); else LPD_LAUNCH(unsigned char, 1, s8);

@@ -357,7 +357,6 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
   ctx->balance_frames = 1;       // r05: on by default (full GPU suite + bench A/B both ways: profiles/r05_balance_*); =0 restores per-frame grids
   if (const char *e = getenv("MISIFT_BALANCE")) ctx->balance_frames = atoi(e) != 0;
-  if (const char *e = getenv("MISIFT_LPD_PERSIST")) ctx->lpd_persist = atoi(e);
   if (const char *e = getenv("MISIFT_LDS_PAD_LPD")) ctx->lds_pad_lpd = atoi(e);
   if (const char *e = getenv("MISIFT_LDS_PAD_SCAN")) ctx->lds_pad_scan = atoi(e);
   if (const char *e = getenv("MISIFT_LDS_PAD_ORIENT")) ctx->lds_pad_orient = atoi(e);
