@@ -187,7 +187,9 @@ int misift_extract_batch_async(misift_ctx *ctx, const float *d_imgs, int nframes
  * (-1: that frame's candidate list overflowed), d_offsets_out[0..nframes] =
  * exclusive prefix sum of the non-negative counts (records).  In the default
  * (fused) mode the descriptor kernel writes the packed array itself — no extra
- * packing pass — and d_pts may be NULL (if given it is filled as well).  Nothing
+ * packing pass — and d_pts may be NULL (if given it is filled as well); calls
+ * that run on the dense kernels (fused = 0, reference_cap, images under 16 x 16
+ * or with a coarsest level under 8 px) need d_pts (MISIFT_EINVAL otherwise).  Nothing
  * synchronises; this is what the multi-GPU gather of SiftData (BASELINE
  * config 4) and the host pipeline send. */
 int misift_extract_batch_packed_async(misift_ctx *ctx, const float *d_imgs, int nframes,
