@@ -46,6 +46,7 @@ SIGNATURES = {
     "misift_ctx_sync": (_i, [_vp]),
     "misift_ctx_set_early_return": (_i, [_vp, _i]),
     "misift_ctx_chain_fallbacks": (_i, [_vp]),
+    "misift_ctx_last_call_balanced": (_i, [_vp]),
     "misift_last_error": (C.c_char_p, []),
     "misift_default_options": (None, [C.POINTER(Options)]),
     "misift_set_options": (_i, [_vp, C.POINTER(Options)]),
@@ -232,6 +233,9 @@ class Context:
     def set_early_return(self, on=True):
         """Synchronous calls return at the last kernel's completion flag instead of after a stream synchronisation."""
         check(lib().misift_ctx_set_early_return(self.h, int(on)), "misift_ctx_set_early_return")
+
+    def last_call_balanced(self):
+        return lib().misift_ctx_last_call_balanced(self.h)
 
     def chain_fallbacks(self):
         return lib().misift_ctx_chain_fallbacks(self.h)

@@ -771,6 +771,80 @@ __device__ __forceinline__ bool flat_to_octave(const FrameCounts &c, int noct, i
   return found;
 }
 
+// share(f) = 1 + floor((T - nframes) * n_f / sum n): every frame keeps a workgroup (descr_all's first sub-block of a
+// frame publishes its counters), the shares add up to at most T, the rest of the table says "spare".
+__host__ __device__ static inline unsigned keypoint_share(unsigned long long spare, unsigned long long n,
+                                                          unsigned long long total)
+{
+  return 1u + (total ? (unsigned)(spare * n / total) : 0u);
+}
+// host-only test hook (no device needed): the shares frame_shares_kernel gives `nframes` frames with points[f] keypoints
+// out of `nblocks` workgroups
+extern "C" int misift_test_frame_shares(int nblocks, int nframes, const unsigned *points, int *shares)
+{
+  if (!points || !shares || nframes < 1 || nblocks < nframes) return MISIFT_EINVAL;
+  unsigned long long total = 0;
+  for (int f = 0; f < nframes; f++) total += points[f];
+  for (int f = 0; f < nframes; f++)
+    shares[f] = (int)keypoint_share((unsigned long long)(nblocks - nframes), points[f], total);
+  return MISIFT_OK;
+}
+// The block tables of a balanced batch's orient_all / descr_all launches (see build_block_maps): ONE workgroup of 256
+// threads — a kernel of its own (frame_shares_kernel), or the extra workgroup of the bin_detections launch (r05: one
+// dependent dispatch less per batch; it needs nothing the binning produces, only refine_all's per-octave counts).
+struct FrameSharesArgs { int t_a, t_b; int4 *map_a, *map_b; };
+__device__ __forceinline__ void frame_shares_body(const unsigned *__restrict__ counters, int nframes, int noct, int max_pts,
+                                                  int t_a, int4 *__restrict__ map_a, int t_b, int4 *__restrict__ map_b,
+                                                  unsigned *s_scan, unsigned long long &s_total)
+{
+  const int tid = threadIdx.x;
+  auto frame_points = [&](int f) -> unsigned {
+    unsigned n = 0;
+    for (int o = 1; o <= noct; o++) n += min(counters[(size_t)f * CNT_STRIDE + CNT_DET + o], (unsigned)max_pts);
+    return n;
+  };
+  if (tid == 0) s_total = 0ull;
+  __syncthreads();
+  unsigned long long mine = 0;
+  for (int f = tid; f < nframes; f += 256) mine += frame_points(f);
+  if (mine) atomicAdd(&s_total, mine);
+  __syncthreads();
+  const unsigned long long total = s_total;
+  for (int which = 0; which < 2; which++) {
+    const int T = which ? t_b : t_a;
+    int4 *map = which ? map_b : map_a;
+    if (T < nframes || !map) continue;                         // (the host sizes T >= 8 * nframes)
+    const unsigned long long spare = (unsigned long long)(T - nframes);
+    unsigned carry = 0;
+    for (int base = 0; base < nframes; base += 256) {
+      const int f = base + tid;
+      const unsigned share = f < nframes ? keypoint_share(spare, frame_points(f), total) : 0u;
+      s_scan[tid] = share;
+      __syncthreads();
+      for (int d = 1; d < 256; d <<= 1) {                       // inclusive scan of the 256 shares
+        const unsigned v = tid >= d ? s_scan[tid - d] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+      }
+      const unsigned start = carry + s_scan[tid] - share;
+      for (unsigned k = 0; k < share; k++) map[start + k] = make_int4(f, (int)k, (int)share, 0);
+      carry += s_scan[255];
+      __syncthreads();
+    }
+    for (int b = (int)carry + tid; b < T; b += 256) map[b] = make_int4(-1, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void frame_shares_kernel(const unsigned *__restrict__ counters, int nframes, int noct,
+                                                           int max_pts, int t_a, int4 *__restrict__ map_a, int t_b,
+                                                           int4 *__restrict__ map_b)
+{
+  __shared__ unsigned s_scan[256];
+  __shared__ unsigned long long s_total;
+  frame_shares_body(counters, nframes, noct, max_pts, t_a, map_a, t_b, map_b, s_scan, s_total);
+}
+
 // ------------------------------------------------- spatial binning of the staged detections
 // refine_all appends detections in atomic order, i.e. spatially random: consecutive wavefronts of orient_all /
 // descr_all then share no cache lines and every keypoint's window comes from HBM (r01 PMC: 6 KB fetched per
@@ -790,10 +864,18 @@ __device__ __forceinline__ bool det_less(const Detection &a, const Detection &b)
 
 __global__ __launch_bounds__(256) void bin_detections_kernel(PyramidInfo P, const unsigned *__restrict__ counters,
                                                              const Detection *__restrict__ in,
-                                                             Detection *__restrict__ out, int max_pts, int total_order)
+                                                             Detection *__restrict__ out, int max_pts, int total_order,
+                                                             FrameSharesArgs sh)
 {
   __shared__ unsigned s_hist[BIN_MAX_TILES];
   __shared__ unsigned s_part[256];
+  if ((int)blockIdx.x == P.noct) {            // the extra column of workgroups of a balanced batch: one of them builds the
+    if (blockIdx.y == 0) {                    // block tables, the others have nothing to do
+      __shared__ unsigned long long s_total;
+      frame_shares_body(counters, P.nframes, P.noct, max_pts, sh.t_a, sh.map_a, sh.t_b, sh.map_b, s_part, s_total);
+    }
+    return;
+  }
   const int o = blockIdx.x + 1, frame = blockIdx.y, tid = threadIdx.x;
   const unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   const int n = (int)min(cnt[CNT_DET + o], (unsigned)max_pts);
@@ -1446,70 +1528,6 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
   export_counters_host(counters, gridDim.y, host_out, host_seq);
 }
 
-// share(f) = 1 + floor((T - nframes) * n_f / sum n): every frame keeps a workgroup (descr_all's first sub-block of a
-// frame publishes its counters), the shares add up to at most T, the rest of the table says "spare".
-__host__ __device__ static inline unsigned keypoint_share(unsigned long long spare, unsigned long long n,
-                                                          unsigned long long total)
-{
-  return 1u + (total ? (unsigned)(spare * n / total) : 0u);
-}
-// host-only test hook (no device needed): the shares frame_shares_kernel gives `nframes` frames with points[f] keypoints
-// out of `nblocks` workgroups
-extern "C" int misift_test_frame_shares(int nblocks, int nframes, const unsigned *points, int *shares)
-{
-  if (!points || !shares || nframes < 1 || nblocks < nframes) return MISIFT_EINVAL;
-  unsigned long long total = 0;
-  for (int f = 0; f < nframes; f++) total += points[f];
-  for (int f = 0; f < nframes; f++)
-    shares[f] = (int)keypoint_share((unsigned long long)(nblocks - nframes), points[f], total);
-  return MISIFT_OK;
-}
-// One workgroup.
-__global__ __launch_bounds__(256) void frame_shares_kernel(const unsigned *__restrict__ counters, int nframes, int noct,
-                                                           int max_pts, int t_a, int4 *__restrict__ map_a, int t_b,
-                                                           int4 *__restrict__ map_b)
-{
-  __shared__ unsigned s_scan[256];
-  __shared__ unsigned long long s_total;
-  const int tid = threadIdx.x;
-  auto frame_points = [&](int f) -> unsigned {
-    unsigned n = 0;
-    for (int o = 1; o <= noct; o++) n += min(counters[(size_t)f * CNT_STRIDE + CNT_DET + o], (unsigned)max_pts);
-    return n;
-  };
-  if (tid == 0) s_total = 0ull;
-  __syncthreads();
-  unsigned long long mine = 0;
-  for (int f = tid; f < nframes; f += 256) mine += frame_points(f);
-  if (mine) atomicAdd(&s_total, mine);
-  __syncthreads();
-  const unsigned long long total = s_total;
-  for (int which = 0; which < 2; which++) {
-    const int T = which ? t_b : t_a;
-    int4 *map = which ? map_b : map_a;
-    if (T < nframes || !map) continue;                         // (the host sizes T >= 8 * nframes)
-    const unsigned long long spare = (unsigned long long)(T - nframes);
-    unsigned carry = 0;
-    for (int base = 0; base < nframes; base += 256) {
-      const int f = base + tid;
-      const unsigned share = f < nframes ? keypoint_share(spare, frame_points(f), total) : 0u;
-      s_scan[tid] = share;
-      __syncthreads();
-      for (int d = 1; d < 256; d <<= 1) {                       // inclusive scan of the 256 shares
-        const unsigned v = tid >= d ? s_scan[tid - d] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-      }
-      const unsigned start = carry + s_scan[tid] - share;
-      for (unsigned k = 0; k < share; k++) map[start + k] = make_int4(f, (int)k, (int)share, 0);
-      carry += s_scan[255];
-      __syncthreads();
-    }
-    for (int b = (int)carry + tid; b < T; b += 256) map[b] = make_int4(-1, 0, 0, 0);
-  }
-}
-
 // ---- the r01 forms of the two merged-octave kernels: bilinear fetches straight from global memory (no staged
 // tile), 4 waves/SIMD.  Selected with MISIFT_TILE=0 (A/B measurements, docs/LOG.md section 9).
 // 90 VGPRs: 5 waves/SIMD (the kernel is bound by the dependent LDS / shuffle chain of one keypoint per wavefront, so
@@ -1759,12 +1777,25 @@ int launch_descr(misift_ctx *ctx, const float *base, long long base_frame_stride
   return ls.finish();
 }
 
+static int prepare_block_maps(misift_ctx *ctx, const PyramidInfo &P, bool *wanted);
+
 int launch_bin_detections(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
 {
+  // a balanced batch: the block tables of orient_all / descr_all are built by one extra workgroup of this launch
+  bool balanced = false;
+  int rc = prepare_block_maps(ctx, P, &balanced);
+  if (rc) return rc;
+  FrameSharesArgs sh = {0, 0, nullptr, nullptr};
+  if (balanced) {
+    sh.t_a = ctx->map_t_orient; sh.t_b = ctx->map_t_descr;
+    sh.map_a = ctx->d_block_map; sh.map_b = ctx->d_block_map + ctx->map_t_orient;
+  }
   LaunchScope ls(ctx, "bin_detections");
-  hipLaunchKernelGGL(bin_detections_kernel, dim3(P.noct, P.nframes), dim3(256), 0, ctx->stream, P, ctx->d_counters,
-                     ctx->d_det, ctx->d_det_sorted, max_pts, ctx->opt.deterministic ? 1 : 0);
-  return ls.finish();
+  hipLaunchKernelGGL(bin_detections_kernel, dim3(P.noct + (balanced ? 1 : 0), P.nframes), dim3(256), 0, ctx->stream, P,
+                     ctx->d_counters, ctx->d_det, ctx->d_det_sorted, max_pts, ctx->opt.deterministic ? 1 : 0, sh);
+  rc = ls.finish();
+  if (rc == MISIFT_OK && balanced) ctx->cur_balanced = 1;
+  return rc;
 }
 
 int launch_renumber_dups(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
@@ -1778,9 +1809,9 @@ int launch_renumber_dups(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
 // Balanced batches (MISIFT_BALANCE=1): the block tables of this call's orient_all and descr_all launches, written by one
 // small kernel behind refine_all (the per-octave detection counts are final there; second orientations are done by the
 // wavefront of their keypoint, so the same counts weigh both launches).
-static int build_block_maps(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
+static int prepare_block_maps(misift_ctx *ctx, const PyramidInfo &P, bool *wanted)
 {
-  ctx->cur_balanced = 0;
+  *wanted = false;
   if (!ctx->balance_frames || P.nframes <= ctx->small_frames || ctx->in_capture || ctx->tile_orient || !ctx->tile_descr)
     return MISIFT_OK;
   const int t_orient = points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu) * P.nframes;
@@ -1793,10 +1824,21 @@ static int build_block_maps(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
     ctx->alloc_gen++;
   }
   ctx->map_t_orient = t_orient; ctx->map_t_descr = t_descr;
+  *wanted = true;
+  return MISIFT_OK;
+}
+
+// ... or, when the batch is not binned (MISIFT_BIN=0), by a small kernel of their own in front of orient_all
+static int build_block_maps(misift_ctx *ctx, const PyramidInfo &P, int max_pts)
+{
+  if (ctx->cur_balanced) return MISIFT_OK;            // launch_bin_detections has built them
+  bool wanted = false;
+  int rc = prepare_block_maps(ctx, P, &wanted);
+  if (rc || !wanted) return rc;
   LaunchScope ls(ctx, "frame_shares");
   hipLaunchKernelGGL(frame_shares_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_counters, P.nframes, P.noct, max_pts,
-                     t_orient, ctx->d_block_map, t_descr, ctx->d_block_map + t_orient);
-  int rc = ls.finish();
+                     ctx->map_t_orient, ctx->d_block_map, ctx->map_t_descr, ctx->d_block_map + ctx->map_t_orient);
+  rc = ls.finish();
   if (rc == MISIFT_OK) ctx->cur_balanced = 1;
   return rc;
 }

@@ -498,6 +498,8 @@ extern "C" int misift_ctx_set_early_return(misift_ctx *ctx, int on)
   return MISIFT_OK;
 }
 
+extern "C" int misift_ctx_last_call_balanced(misift_ctx *ctx) { return ctx ? ctx->cur_balanced : -1; }
+
 extern "C" int misift_ctx_chain_fallbacks(misift_ctx *ctx) { return ctx ? ctx->chain_fallbacks : -1; }
 
 extern "C" int misift_ctx_get_batches_in_flight(misift_ctx *ctx)
@@ -960,7 +962,8 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   ARG_CHECK(nframes >= 1 && width >= 1 && height >= 1 && pitch >= width);
   ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);       // before the shifts below
   const bool tiny = misift_tiny_call(width, height, num_octaves);
-  ARG_CHECK(!(tiny && ctx->opt.fused));        // the entry points route tiny calls to the dense kernels (TinyScope)
+  // the entry points route tiny calls and calls with the reference's extremum cap to the dense kernels (TinyScope)
+  ARG_CHECK(!((tiny || ctx->opt.reference_cap) && ctx->opt.fused));
   ARG_CHECK(max_pts >= 1);
   ARG_CHECK(width * (scale_up ? 2 : 1) < 16384 && height * (scale_up ? 2 : 1) < 16384);
   HIP_TRY(hipSetDevice(ctx->device));

@@ -247,6 +247,8 @@ extern "C" int misift_pipe_submit(misift_pipe *p, const void *host_frames, int n
   const int saved_split = ctx->split_tail;
   ctx->stream = p->s_compute;
   ctx->split_tail = 0;          // the pipe already overlaps batches on its own streams; the split measured -6 % here
+  const int fused_saved = ctx->opt.fused;
+  if (ctx->opt.reference_cap) ctx->opt.fused = 0;       // the cap is defined on the dense kernels' extremum list (misift.h)
   int rc = misift_extract_enqueue(ctx, s.d_frames, p->src_u8, nframes, (long long)p->frame_elems, p->width, p->height,
                                   p->width, p->num_octaves, p->init_blur, p->thresh, p->lowest_scale, 0, p->d_scratch,
                                   p->d_pts, p->max_pts);
@@ -254,6 +256,7 @@ extern "C" int misift_pipe_submit(misift_pipe *p, const void *host_frames, int n
   if (!rc) rc = launch_pack_records(ctx, p->d_pts, p->max_pts, nframes, s.d_counts + p->batch, s.d_packed);
   ctx->stream = saved;
   ctx->split_tail = saved_split;
+  ctx->opt.fused = fused_saved;
   if (rc) return rc;
   HIP_TRY(hipEventRecord(s.ev_done, p->s_compute));
   // 3. counts + offsets to the host on the read-back stream

@@ -809,42 +809,43 @@ def test_timed_path_16x1080p_packed_async_vs_oracle(ctx):
 
 
 def test_balanced_keypoint_launches_on_a_skewed_batch(ctx):
-    """MISIFT_BALANCE=1: the workgroups of orient_all / descr_all are dealt out in proportion to the frames' keypoint
-    counts (frame_shares_kernel writes a block -> (frame, sub-block, sub-blocks) table behind refine_all) instead of the same
-    number per frame.  A batch of eight frames from a busy one down to an empty one must come out record for record as
-    from the plain launch, and equal to the oracle."""
+    """MISIFT_BALANCE (on by default since r05): the workgroups of orient_all / descr_all are dealt out in proportion to the
+    frames' keypoint counts (a block -> (frame, sub-block, sub-blocks) table, built behind refine_all by one extra workgroup
+    of the bin_detections launch) instead of the same number per frame.  A batch of eight frames from a busy one down to an
+    empty one must come out record for record as from the plain launch (a context created under MISIFT_BALANCE=0), and equal
+    to the oracle."""
     import os
     from cudasift_amd import capi
     from synth import SYNTH_AMP
     w, h, mp = 640, 360, 8192
     amps = [3.0, 1.0, 1.5, 0.8, 0.6, 0.0, 2.0, 0.5]             # oracle: 7224, 207, 1654, 28, 3, 0, 4405, 0 keypoints
     frames = np.stack([synth_frame(9100 + i, w, h, amp=SYNTH_AMP * a) for i, a in enumerate(amps)])
-    was_fused = ctx.get_options().fused
-    ctx.set_options(fused=1)
+
+    def fresh(balance):
+        saved = os.environ.get("MISIFT_BALANCE")
+        os.environ["MISIFT_BALANCE"] = balance
+        try:
+            return capi.Context(0)
+        finally:
+            if saved is None:
+                del os.environ["MISIFT_BALANCE"]
+            else:
+                os.environ["MISIFT_BALANCE"] = saved
+    c1, c2 = fresh("0"), fresh("1")
     try:
-        pts_u, n_u = ctx.extract_batch(frames, num_octaves=5, thresh=3.0, max_pts=mp)
-    finally:
-        ctx.set_options(fused=was_fused)
-    saved = os.environ.get("MISIFT_BALANCE")
-    os.environ["MISIFT_BALANCE"] = "1"
-    try:
-        c2 = capi.Context(0)
-    finally:
-        if saved is None:
-            del os.environ["MISIFT_BALANCE"]
-        else:
-            os.environ["MISIFT_BALANCE"] = saved
-    try:
+        c1.set_options(fused=1)
         c2.set_options(fused=1)
+        pts_u, n_u = c1.extract_batch(frames, num_octaves=5, thresh=3.0, max_pts=mp)
+        assert c1.last_call_balanced() == 0
         c2.profile_enable(True)
         pts_b, n_b = c2.extract_batch(frames, num_octaves=5, thresh=3.0, max_pts=mp)
-        prof = c2.profile_read()
-        assert prof["frame_shares"]["calls"] == 1                        # the premise: the table was built and used
+        assert c2.last_call_balanced() == 1                              # the premise: the table was built and used ...
+        assert "frame_shares" not in c2.profile_read()                   # ... inside the bin_detections launch, no kernel of its own
         # ... and batches of a frame or two keep the plain launch (single-call path)
-        c2.profile_reset()
         c2.extract_batch(frames[:2], num_octaves=5, thresh=3.0, max_pts=mp)
-        assert "frame_shares" not in c2.profile_read()
+        assert c2.last_call_balanced() == 0
     finally:
+        c1.close()
         c2.close()
     assert np.array_equal(n_u, n_b), (n_u, n_b)
     assert n_u[5] == 0 and n_u[0] > 4 * n_u[1] > 0, n_u                   # skewed indeed, one frame empty
@@ -855,6 +856,29 @@ def test_balanced_keypoint_launches_on_a_skewed_batch(ctx):
     for f in range(len(amps)):
         compare_points(ref[f, :nref[f]], pts_b[f, :n_b[f]], "balanced_f%d" % f, record)
     record("balanced_skewed_batch", frames=len(amps), keypoints=[int(x) for x in n_b])
+
+
+def test_balanced_batch_without_binning_builds_its_tables_in_a_kernel_of_their_own():
+    """MISIFT_BIN=0: no bin_detections launch to ride in, so frame_shares_kernel runs as its own launch; same records."""
+    import os
+    from cudasift_amd import capi
+    frames = np.stack([synth_frame(9200 + i, 640, 360) for i in range(6)])
+    os.environ["MISIFT_BIN"] = "0"
+    try:
+        c = capi.Context(0)
+    finally:
+        del os.environ["MISIFT_BIN"]
+    try:
+        c.profile_enable(True)
+        pts, n = c.extract_batch(frames, num_octaves=4, thresh=3.0, max_pts=8192)
+        prof = c.profile_read()
+        assert c.last_call_balanced() == 1 and prof["frame_shares"]["calls"] == 1 and "bin_detections" not in prof
+    finally:
+        c.close()
+    ref, nref, _ = orc().extract_batch(frames, num_octaves=4, init_blur=1.0, thresh=3.0, max_pts=8192)
+    assert np.array_equal(n, nref)
+    for f in range(len(frames)):
+        compare_points(ref[f, :nref[f]], pts[f, :n[f]], "balanced_nobin_f%d" % f, record)
 
 
 def test_three_contexts_in_flight_equal_one_context(ctx):
