@@ -179,3 +179,38 @@ def test_launcher_mismatch_is_refused():
     """WORLD_SIZE from a launcher that disagrees with --gpus: no silent fallback to either number."""
     r = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 4 and "refusing to run" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+def _torchrun(args, env_extra=None, timeout=300):
+    """The driver's launcher shape: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ..."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = _bench()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(b._free_port()), os.path.join(root, "bench.py")] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_under_the_drivers_launcher_the_ranks_are_not_spawned_twice():
+    """`torch.distributed.run ... bench.py --gpus 2`: WORLD_SIZE comes from the launcher, bench.py must take its place as a
+    rank (no self-spawn) and rank 0's JSON must be on stdout (gloo stands in for RCCL: --spawn-check needs no GPU)."""
+    import json
+    r = _torchrun(["--gpus", "2", "--spawn-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    assert json.loads(lines[0])["world"] == 2
+
+
+def test_under_the_drivers_launcher_a_silent_rank_ends_the_job():
+    """The same with a rank that hangs: its watchdog (or its peer's, waiting in the barrier) exits with rc 6, the launcher
+    tears the job down — minutes before any driver-side time-out."""
+    import time
+    t0 = time.time()
+    r = _torchrun(["--gpus", "2", "--spawn-check"], {"BENCH_SPAWN_CHECK_HANG_RANK": "1", "BENCH_WATCHDOG_S": "3"}, timeout=240)
+    assert r.returncode != 0
+    assert "watchdog: rank" in r.stderr and "pretend_collective" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 120
