@@ -1492,12 +1492,43 @@ class Bench:
           roofline.single_launch  the same with all levels in one launch (no overlap possible: what rocprof of the kernel alone shows)
           roofline.hbm            the whole step against the HBM peak: PMC bytes actually moved, the structural floor of a
                                   fused design, and their ratio — the fraction BASELINE's metric names."""
-        args, torch = self.args, self.torch
-        kernels, alg, N, B, pmc, world = self.kernels, self.alg, self.N, self.B, self.pmc, self.world
+        kernels, alg, pmc = self.kernels, self.alg, self.pmc
         self.wd.stage("roofline")
         dom = "dog_scan" if "dog_scan" in kernels else max((k for k in kernels if k in alg), key=lambda k: kernels[k]["ms_per_step"])
         dom_ms = kernels[dom]["ms_per_step"]
         dom_launches = max(1, kernels[dom]["launches_per_step"])
+        roofline = self._roofline_dominant(dom, dom_ms, dom_launches)
+        roofline["hbm"] = self._roofline_hbm()        # the HBM answer (BASELINE: "frames/s ... as achieved fraction of HBM roofline")
+        roofline["pipeline"] = roofline["hbm"]        # (r01-r04 name of the same block)
+        roofline["issue"] = self._roofline_issue()    # issue budget of the step
+        roofline["issue_model"] = {
+            "cycles_per_wave64_instruction_per_simd": {"v_fma/mul/add/sub_f32, v_add_u32": 2.85, "v_pk_fma/mul/add_f32": 4.45,
+                                                       "DPP moves, v_max3, cvt, floor, integer mul/shift-add, v_cndmask": 4.7,
+                                                       "transcendentals": 8.5},
+            "note": "tools/valu_rates, tools/scan_rates (profiles/r02_valu_rates.txt, r02_scan_rates.txt; whole-kernel times): "
+                    "a SIMD is saturated from 2-3 resident wavefronts on, occupancy beyond that buys nothing.  One scan row is 96 "
+                    "v_pk_fma + 24 v_pk_mul + 56 v_pk_add + 48 DPP moves + 20 v_sub + 12 v_max/v_max3 = ~1085 cycles for 35.1 kflop "
+                    "executed (isolated: 1085 measured), i.e. 0.50 of 64 flop/cycle/SIMD is the ceiling of this instruction "
+                    "stream before halo lanes, segment prologues and the extremum tests"}
+        roofline["avg_launch_ms"] = round(dom_ms / dom_launches, 4)
+        roofline["duration_source"] = self.trace_note
+        roofline["launches_per_step"] = dom_launches
+        roofline["traffic"] = int((pmc[dom]["read"] + pmc[dom]["write"]) / dom_launches) if pmc and dom in pmc else None
+        roofline["traffic_note"] = self.pmc_note
+        roofline["pmc_calibration"] = self.calib
+        if self.trace and "_all" in self.trace:
+            roofline["child_run_step"] = {"gpu_busy_union_ms": round(self.trace["_all"]["busy_union_ms_per_step"], 4),
+                                          "span_ms": round(self.trace["_all"]["span_ms_per_step"], 4),
+                                          "note": "the kernel-trace child run (one context, batches queued back to back): wall time "
+                                                  "during which any extraction kernel ran, and first start to last end, per step"}
+        roofline["hbm_bound_kernels"] = self._roofline_hbm_kernels()
+        if self.rank == 0:
+            roofline["copy_ceiling_GBps"] = self._copy_ceiling_gbps()
+        self.roofline = roofline
+
+    def _roofline_dominant(self, dom, dom_ms, dom_launches):
+        """The dominant kernel against the roof that bounds it (dog_scan: fp32 vector peak; anything else: HBM)."""
+        kernels, alg, N, B = self.kernels, self.alg, self.N, self.B
         if dom == "dog_scan":
             fpp = dog_scan_flop_per_px()
             flops_step = float(fpp) * sum(N) * B
@@ -1534,7 +1565,11 @@ class Bench:
             ach = alg[dom] * B / (dom_ms * 1e-3) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(min(ach / HBM_PEAK_GBS, 1.0), 4)}
-        # ---- the HBM answer (BASELINE: "frames/s ... as achieved fraction of HBM roofline"), whole step
+        return roofline
+
+    def _roofline_hbm(self):
+        """The whole step against the HBM peak: PMC bytes actually moved, the structural floor, their ratio."""
+        pmc, B, world = self.pmc, self.B, self.world
         fps1 = self.fps / world
         hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "floor_bytes_per_frame": int(FLOOR_BYTES_PER_FRAME),
@@ -1548,9 +1583,10 @@ class Bench:
             hbm.update({"traffic_bytes_per_frame": int(tb), "achieved": round(tb * fps1 / 1e9, 1),
                         "traffic_frac": round(tb * fps1 / 1e9 / HBM_PEAK_GBS, 4), "frac": round(tb * fps1 / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic_over_floor": round(tb / FLOOR_BYTES_PER_FRAME, 3)})
-        roofline["hbm"] = hbm
-        roofline["pipeline"] = hbm                 # (r01-r04 name of the same block)
-        # ---- issue budget of the step
+        return hbm
+
+    def _roofline_issue(self):
+        """VALU issue budget of the step from the SQ counter pass."""
         issue = {"note": "insts = SQ_INSTS_VALU (wavefront-level VALU instructions) of all kernels of a step; "
                          "active = SQ_ACTIVE_INST_VALU x 4 (shader cycles a SIMD spent issuing them, summed over SIMDs); "
                          "valu_active_frac_of_step = active / (1024 SIMDs x clock x ms_per_step) with the clock the counters' own "
@@ -1578,28 +1614,11 @@ class Bench:
                           "valu_active_frac_of_step": round(active / simd_cycles, 4),
                           "issue_frac_of_step": round(insts * 4.1 / simd_cycles, 4),
                           "per_kernel_M_insts": {k: round(e["insts"] / 1e6, 1) for k, e in sorted(self.sq.items())}})
-        roofline["issue"] = issue
-        roofline["issue_model"] = {
-            "cycles_per_wave64_instruction_per_simd": {"v_fma/mul/add/sub_f32, v_add_u32": 2.85, "v_pk_fma/mul/add_f32": 4.45,
-                                                       "DPP moves, v_max3, cvt, floor, integer mul/shift-add, v_cndmask": 4.7,
-                                                       "transcendentals": 8.5},
-            "note": "tools/valu_rates, tools/scan_rates (profiles/r02_valu_rates.txt, r02_scan_rates.txt; whole-kernel times): "
-                    "a SIMD is saturated from 2-3 resident wavefronts on, occupancy beyond that buys nothing.  One scan row is 96 "
-                    "v_pk_fma + 24 v_pk_mul + 56 v_pk_add + 48 DPP moves + 20 v_sub + 12 v_max/v_max3 = ~1085 cycles for 35.1 kflop "
-                    "executed (isolated: 1085 measured), i.e. 0.50 of 64 flop/cycle/SIMD is the ceiling of this instruction "
-                    "stream before halo lanes, segment prologues and the extremum tests"}
-        roofline["avg_launch_ms"] = round(dom_ms / dom_launches, 4)
-        roofline["duration_source"] = self.trace_note
-        roofline["launches_per_step"] = dom_launches
-        roofline["traffic"] = int((pmc[dom]["read"] + pmc[dom]["write"]) / dom_launches) if pmc and dom in pmc else None
-        roofline["traffic_note"] = self.pmc_note
-        roofline["pmc_calibration"] = self.calib
-        if self.trace and "_all" in self.trace:
-            roofline["child_run_step"] = {"gpu_busy_union_ms": round(self.trace["_all"]["busy_union_ms_per_step"], 4),
-                                          "span_ms": round(self.trace["_all"]["span_ms_per_step"], 4),
-                                          "note": "the kernel-trace child run (one context, batches queued back to back): wall time "
-                                                  "during which any extraction kernel ran, and first start to last end, per step"}
-        # the genuinely HBM-bound kernels: algorithmic bytes AND bytes actually moved, each over the summed launch time
+        return issue
+
+    def _roofline_hbm_kernels(self):
+        """The genuinely HBM-bound kernels: algorithmic bytes AND bytes actually moved, each over the summed launch time."""
+        kernels, alg, pmc, B = self.kernels, self.alg, self.pmc, self.B
         hbm_kernels = {}
         split = kernels.get("dog_scan", {}).get("launches_per_step", 1) > 1
         for k in ("lowpass", "lowpass_down", "scaledown"):
@@ -1613,22 +1632,22 @@ class Bench:
                     t = (pmc[k]["read"] + pmc[k]["write"]) / (kms * 1e-3) / 1e9
                     hbm_kernels[k]["traffic_GBps"] = round(t, 1)
                     hbm_kernels[k]["traffic_frac"] = round(t / HBM_PEAK_GBS, 4)
-        roofline["hbm_bound_kernels"] = hbm_kernels
-        # achievable-copy ceiling: device-to-device copy of 1 GiB, read + write bytes counted
-        if self.rank == 0:
-            a = torch.empty(1 << 28, dtype=torch.float32, device=self.device)
-            b = torch.empty_like(a)
-            for _ in range(2):
-                b.copy_(a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                b.copy_(a)
-            e1.record()
-            torch.cuda.synchronize()
-            roofline["copy_ceiling_GBps"] = round(2.0 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del a, b
-        self.roofline = roofline
+        return hbm_kernels
+
+    def _copy_ceiling_gbps(self):
+        """Achievable-copy ceiling: device-to-device copy of 1 GiB, read + write bytes counted."""
+        torch = self.torch
+        a = torch.empty(1 << 28, dtype=torch.float32, device=self.device)
+        b = torch.empty_like(a)
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        return round(2.0 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
     # ------------------------------------------------------------------ self-validation + CPU baseline
     def leg_validate_and_cpu(self):
