@@ -52,6 +52,9 @@ struct PyramidInfo {
   int noct, nframes;
   float out_scale;                 // 0.5 when the frames were up-sampled first (RescalePositions, cudaSiftH.cu:130), else 1
   int fix_numpts;                  // options.fix_numpts: the finest octave's second orientations lie INSIDE numPts (and are rescaled)
+  float patch_reach;               // descr_all: keypoints whose samples reach further than this many texels go to descr_big
+                                   // (17.9 = what the 40 x 40 LDS window covers; MISIFT_TEST_PATCH_REACH lowers it so that tests
+                                   //  can send ordinary keypoints down the rare path)
   long long frame_stride;          // floats between frames' arenas
   OctaveInfo o[MISIFT_MAX_OCTAVES + 1];
 };
@@ -329,6 +332,7 @@ struct misift_ctx {
   // (160 KB per CU: > 53.4 KB -> 2, > 40 KB -> 3), leaving wave slots and registers to the kernels of the OTHER batches in
   // flight (MISIFT_LDS_PAD_LPD / _SCAN / _ORIENT / _DESCR; 0 = none)
   int lds_pad_lpd, lds_pad_scan, lds_pad_orient, lds_pad_descr;
+  float patch_reach;            // PyramidInfo.patch_reach of this context's calls
   unsigned *d_refcap;           // options.reference_cap: 240-bit extremum masks of the reference's 30 x 8 blocks (launch_refcap)
   size_t refcap_bytes;
   void *d_match_tmp;            // matcher partial results

@@ -90,13 +90,13 @@ struct PatchGeom {
 // [floor(xpos) - 18, floor(xpos) + 19], one column short of the window [floor(xpos) - 19, floor(xpos) + 20] on either
 // side (slack for the few ulps the float coordinate arithmetic can move a sample).  Larger scales (scale > 2.12:
 // only reachable through the refinement's unclamped fallback step) take the global-memory path.
-__device__ __forceinline__ PatchGeom patch_geom(float xpos, float ypos, float pscale, int w, int h)
+__device__ __forceinline__ PatchGeom patch_geom(float xpos, float ypos, float pscale, int w, int h, float max_reach)
 {
   PatchGeom g;
   const float reach = 10.6067f * (0.75f * pscale) + 1.0f;
   // coordinates far outside the image cannot come out of the refinement; guard the int conversion anyway
   const bool sane = xpos > -64.0f && ypos > -64.0f && xpos < (float)(w + 64) && ypos < (float)(h + 64);
-  g.fits = sane && reach <= PATCH_REACH;
+  g.fits = sane && reach <= max_reach;               // (max_reach <= PATCH_REACH: PyramidInfo.patch_reach)
   g.x0 = (int)floorf(sane ? xpos : 0.0f) - 19;
   g.y0 = (int)floorf(sane ? ypos : 0.0f) - 19;
   return g;
@@ -1317,7 +1317,7 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   };
   float4 h0 = head(o, i), h1 = h0, h2 = h0;
   if (more1) h1 = head(o1, i1);
-  PatchGeom g = patch_geom(h0.x, h0.y, h0.z, P.o[o].w, P.o[o].h), g1 = g;
+  PatchGeom g = patch_geom(h0.x, h0.y, h0.z, P.o[o].w, P.o[o].h, P.patch_reach), g1 = g;
   float R[PATCH_LOADS];
   if (g.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + P.o[o].img_off, P.o[o].w, P.o[o].h, P.o[o].p, g, lane, R);
   int cur_o = 0;
@@ -1335,7 +1335,7 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
     asm volatile("" : "+v"(lane_i));
     if (more1) {
       const OctaveInfo &L1 = P.o[o1];
-      g1 = patch_geom(h1.x, h1.y, h1.z, L1.w, L1.h);
+      g1 = patch_geom(h1.x, h1.y, h1.z, L1.w, L1.h, P.patch_reach);
       if (g1.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + L1.img_off, L1.w, L1.h, L1.p, g1, lane_i, R);
     }
     const bool more2 = more1 && advance(o2, i2, lim2, stride);

@@ -357,6 +357,11 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
   ctx->balance_frames = 1;       // r05: on by default (full GPU suite + bench A/B both ways: profiles/r05_balance_*); =0 restores per-frame grids
   if (const char *e = getenv("MISIFT_BALANCE")) ctx->balance_frames = atoi(e) != 0;
+  ctx->patch_reach = 17.9f;                   // = PATCH_REACH of kernels_points.hip: what the LDS window of descr_all covers
+  if (const char *e = getenv("MISIFT_TEST_PATCH_REACH")) {          // tests: ordinary keypoints down the descr_big path
+    const float v = (float)atof(e);
+    if (v > 0.0f && v < 17.9f) ctx->patch_reach = v;
+  }
   if (const char *e = getenv("MISIFT_LDS_PAD_LPD")) ctx->lds_pad_lpd = atoi(e);
   if (const char *e = getenv("MISIFT_LDS_PAD_SCAN")) ctx->lds_pad_scan = atoi(e);
   if (const char *e = getenv("MISIFT_LDS_PAD_ORIENT")) ctx->lds_pad_orient = atoi(e);
@@ -1063,6 +1068,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   if (ctx->opt.fused) {
     P.noct = num_octaves; P.nframes = nframes; P.frame_stride = SS;
     P.fix_numpts = ctx->opt.fix_numpts ? 1 : 0;
+    P.patch_reach = ctx->patch_reach;
     P.out_scale = scale_up ? 0.5f : 1.0f;             // RescalePositions (cudaSiftH.cu:130) folded into the record write
     unsigned off = 0;
     for (int o = 1; o <= num_octaves; o++) {

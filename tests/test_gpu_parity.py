@@ -1158,3 +1158,36 @@ def test_extract_ragged_widths_take_the_fast_kernels(ctx, w, h, noct):
         ref, nref, _ = orc().extract(imgs[f], noct, 1.0, 2.5, max_pts=16384)
         assert n[f] == nref and nref > 100
         compare_points(ref[:nref], pts[f, :nref], "ragged_%dx%d_f%d" % (w, h, f), record)
+
+
+@pytest.mark.parametrize("reach", ["9.0", "13.0"])
+def test_descr_big_path_on_ordinary_keypoints(reach):
+    """descr_big_kernel takes the keypoints whose descriptor window does not fit descr_all's 40 x 40 LDS tile (scale > 2.12
+    at its level: only reachable through the refinement's unclamped fallback — none among 40 synthetic frames + the stereo
+    pair, so the path was all but untested).  MISIFT_TEST_PATCH_REACH lowers the limit: with 13 texels every keypoint of
+    scale > 1.5, with 9 every keypoint of scale > 1.0 goes down the global-memory path — single call, batch and the packed
+    entry point must still return the oracle's records."""
+    import os
+    from cudasift_amd import capi
+    os.environ["MISIFT_TEST_PATCH_REACH"] = reach
+    try:
+        c = capi.Context(0)
+    finally:
+        del os.environ["MISIFT_TEST_PATCH_REACH"]
+    try:
+        img = synth_frame(31, 960, 540)
+        ref, nref, cref = orc().extract(img, 5, 1.0, 2.5)
+        got, n, cnt = c.extract(img, num_octaves=5, init_blur=1.0, thresh=2.5)
+        big = int(c.get_counter_block(0)[48])                                   # CNT_BIG: keypoints deferred to descr_big
+        assert n == nref and np.array_equal(cnt, cref)
+        assert big > (0.05 if reach == "13.0" else 0.3) * n, (big, n)           # the rare path is the busy one here
+        compare_points(ref[:nref], got[:n], "descr_big_reach%s" % reach, record)
+        frames = np.stack([synth_frame(32 + i, 640, 360) for i in range(6)])
+        rb, nb, _ = orc().extract_batch(frames, num_octaves=4, init_blur=1.0, thresh=3.0, max_pts=8192)
+        gb, gn = c.extract_batch(frames, num_octaves=4, thresh=3.0, max_pts=8192)[:2]
+        assert np.array_equal(gn, nb)
+        for f in range(len(frames)):
+            compare_points(rb[f, :nb[f]], gb[f, :gn[f]], "descr_big_batch_reach%s_f%d" % (reach, f), record)
+        record("descr_big_path/reach" + reach, deferred=big, keypoints=int(n))
+    finally:
+        c.close()
