@@ -47,6 +47,7 @@ SIGNATURES = {
     "misift_ctx_set_early_return": (_i, [_vp, _i]),
     "misift_ctx_chain_fallbacks": (_i, [_vp]),
     "misift_ctx_last_call_balanced": (_i, [_vp]),
+    "misift_ctx_descr_big_fallbacks": (_i, [_vp]),
     "misift_last_error": (C.c_char_p, []),
     "misift_default_options": (None, [C.POINTER(Options)]),
     "misift_set_options": (_i, [_vp, C.POINTER(Options)]),
@@ -236,6 +237,9 @@ class Context:
 
     def last_call_balanced(self):
         return lib().misift_ctx_last_call_balanced(self.h)
+
+    def descr_big_fallbacks(self):
+        return lib().misift_ctx_descr_big_fallbacks(self.h)
 
     def chain_fallbacks(self):
         return lib().misift_ctx_chain_fallbacks(self.h)

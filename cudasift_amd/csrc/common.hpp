@@ -26,6 +26,7 @@
 #define CNT_DET    32         // CNT_DET + octave : detections of that octave (merged-octave pipeline)
 #define CNT_DUP    40         // CNT_DUP + octave : second-orientation duplicates of that octave
 #define CNT_SPARE_BLOCKS 9    // counter blocks behind the last frame's: flags and ticket words of the call (dog_scan_all_kernel)
+#define CNT_BIG    48         // keypoints deferred to descr_big_kernel (descriptor window larger than descr_all's LDS tile)
 #define CNT_TICKET 49         // frame 0's block only: workgroups of the last kernel that have finished (host export)
 
 struct alignas(16) SiftPointD {   // device view of the 576-byte record
@@ -310,6 +311,19 @@ struct ProfEntry {
   int calls;
 };
 
+// A folded single call (launch_descr_all): what descr_big_kernel needs should the host find a deferred keypoint afterwards.
+struct PendingBig {
+  int valid;
+  const float *scratch;
+  PyramidInfo P;
+  const Detection *det;
+  SiftPointD *pts;
+  int max_pts;
+  const int *pack_offsets;
+  SiftPointD *pack_dst;
+  unsigned big_stride;
+};
+
 struct misift_ctx {
   int device;
   hipStream_t stream;
@@ -333,6 +347,9 @@ struct misift_ctx {
   // flight (MISIFT_LDS_PAD_LPD / _SCAN / _ORIENT / _DESCR; 0 = none)
   int lds_pad_lpd, lds_pad_scan, lds_pad_orient, lds_pad_descr;
   float patch_reach;            // PyramidInfo.patch_reach of this context's calls
+  int fold_descr_tail;          // 1 = single calls: descr_all's last workgroup exports the counters, descr_big only on demand (MISIFT_FOLD_TAIL)
+  int descr_big_fallbacks;      // folded calls that needed descr_big after all (misift_ctx_descr_big_fallbacks)
+  PendingBig pending_big;
   unsigned *d_refcap;           // options.reference_cap: 240-bit extremum masks of the reference's 30 x 8 blocks (launch_refcap)
   size_t refcap_bytes;
   void *d_match_tmp;            // matcher partial results
@@ -390,6 +407,7 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap);
 hipStream_t misift_ctx_result_stream(misift_ctx *ctx);
 int misift_ensure_tmp(misift_ctx *ctx, size_t bytes);
 int launch_refcap(misift_ctx *ctx, int w, int h, int nframes, int octave);
+int launch_descr_big_pending(misift_ctx *ctx);
 bool misift_tiny_call(int width, int height, int num_octaves);
 int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int nframes, long long frame_stride,
                            int width, int height, int pitch, int num_octaves, float init_blur, float thresh,

@@ -1235,7 +1235,6 @@ __device__ __forceinline__ void descr_write(SiftPointD *sift, SiftPointD *pack_d
 #ifndef DESCR_OCC
 #define DESCR_OCC 4
 #endif
-#define CNT_BIG 48            // counter slot: keypoints deferred to descr_big_kernel
 #ifndef DESCR_UNROLL_SAMPLES
 #define DESCR_UNROLL_SAMPLES 1
 #endif
@@ -1486,6 +1485,35 @@ __device__ __forceinline__ bool last_workgroup(unsigned *counters)
   return s_last != 0;
 }
 
+// The same for a launch of a thousand workgroups of ONE frame (single-call path, r05): tickets in two levels — 16 words in
+// cache lines of their own, then one more for the workgroups that drew the last ticket of theirs — because same-address
+// atomics are served one at a time (10-50 ns each: r04 measured a single-level ticket of descr_all at more than the
+// dispatch it saved).  The words live in the spare counter blocks behind the last frame's (cleared by the prefilter; the
+// scan's embedded chain uses words 0, 32 and 64 + 32 k of the same blocks, these are 48 and 80 + 32 k).
+__device__ __forceinline__ bool last_workgroup_2level(unsigned *spare)
+{
+  __shared__ unsigned s_last2;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // records and published counters acknowledged BEFORE the ticket
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned nwg = gridDim.x * gridDim.y, lb = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned sub = lb & 15u, members = (nwg - sub + 15u) / 16u;
+    unsigned last = 0u;
+    if (atomicAdd(&spare[80 + 32 * sub], 1u) == members - 1u) {
+      const unsigned nsub = nwg < 16u ? nwg : 16u;
+      if (atomicAdd(&spare[48], 1u) == nsub - 1u) last = 1u;
+    }
+    s_last2 = last;
+  }
+  __syncthreads();
+  return s_last2 != 0;
+}
+
+// tail_host_out != NULL (single-call path, r05): this launch is the call's LAST one — the workgroup that finishes last hands
+// the counter blocks to the host, and descr_big_kernel is launched only if the host then finds a keypoint deferred to it
+// (CNT_BIG != 0: a descriptor window larger than the LDS tile, i.e. next to never) — five dependent dispatches per call
+// instead of six.
 template <bool Q8, int OCC, bool BAL>
 __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                         unsigned *__restrict__ counters,
@@ -1494,11 +1522,16 @@ __global__ __launch_bounds__(256, OCC) void descr_all_kernel(const float *__rest
                                                         const int *__restrict__ pack_offsets,
                                                         SiftPointD *__restrict__ pack_dst,
                                                         unsigned *__restrict__ big_list, unsigned big_stride,
-                                                        const int4 *__restrict__ block_map)
+                                                        const int4 *__restrict__ block_map,
+                                                        unsigned *__restrict__ tail_host_out, unsigned tail_seq)
 {
   __shared__ DescrWaveLds s_w[WAVES_PER_BLOCK];
   descr_all_body<Q8, BAL>(scratch, P, counters, det, pts, max_pts, pack_offsets, pack_dst, big_list, big_stride, s_w,
                           block_map);
+  if (!BAL && tail_host_out) {                      // (wave-uniform kernel argument; batches never take this branch)
+    if (last_workgroup_2level(counters + (size_t)P.nframes * CNT_STRIDE))
+      export_counters_host(counters, (unsigned)P.nframes, tail_host_out, tail_seq);
+  }
 }
 
 // The few keypoints descr_all_kernel deferred (window larger than 40x40 texels): bilinear fetches from global memory.
@@ -1888,24 +1921,51 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
       ctx->exported = 1;
     }
     const bool bal = ctx->cur_balanced != 0;
+    // single-call path: descr_all itself is the last kernel (its last workgroup exports); descr_big follows only if the
+    // host finds a deferred keypoint in the exported counters (launch_descr_big_pending, called by read_counts)
+    const bool fold = host_out && !bal && ctx->fold_descr_tail && P.nframes <= ctx->small_frames;
     const dim3 dgrid = bal ? dim3(ctx->map_t_descr) : grid;
     const int4 *bmap = bal ? ctx->d_block_map + ctx->map_t_orient : nullptr;
+    unsigned *tail_out = fold ? host_out : nullptr;
 #define DESCR_LAUNCH(Q, O, B) hipLaunchKernelGGL((descr_all_kernel<Q, O, B>), dgrid, dim3(256), (size_t)ctx->lds_pad_descr, ctx->stream, scratch, P, \
                                                  ctx->d_counters, det, pts, max_pts, 0, pack_offsets, pack_dst, ctx->d_cand, \
-                                                 big_stride, bmap)
+                                                 big_stride, bmap, tail_out, ctx->export_seq)
 #define DESCR_LAUNCH_B(Q, O) do { if (bal) DESCR_LAUNCH(Q, O, true); else DESCR_LAUNCH(Q, O, false); } while (0)
     const bool q8 = ctx->opt.texfrac_bits == 8;
     if (ctx->descr_occ >= 4) { if (q8) DESCR_LAUNCH_B(true, 4); else DESCR_LAUNCH_B(false, 4); }
     else { if (q8) DESCR_LAUNCH_B(true, 3); else DESCR_LAUNCH_B(false, 3); }
 #undef DESCR_LAUNCH_B
 #undef DESCR_LAUNCH
-    // (r04 tried folding this launch into descr_all's last workgroup by ticket: a thousand same-address tickets and the
-    //  extra registers cost more than the 4 us dispatch — profiles/r04_single_call_sweep_step4.txt)
-    LAUNCH_Q8(descr_big_kernel, dim3(2, P.nframes), dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts,
-              pack_offsets, pack_dst, ctx->d_cand, big_stride, host_out, ctx->export_seq);
+    PendingBig &pb = ctx->pending_big;
+    pb.valid = 0;
+    if (fold) {
+      pb.valid = 1; pb.scratch = scratch; pb.P = P; pb.det = det; pb.pts = pts; pb.max_pts = max_pts;
+      pb.pack_offsets = pack_offsets; pb.pack_dst = pack_dst; pb.big_stride = big_stride;
+    } else {
+      LAUNCH_Q8(descr_big_kernel, dim3(2, P.nframes), dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts,
+                pack_offsets, pack_dst, ctx->d_cand, big_stride, host_out, ctx->export_seq);
+    }
   } else
     LAUNCH_Q8(descr_all_gather_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts, 0, pack_offsets,
               pack_dst);
+  return ls.finish();
+}
+
+// The rare second half of a folded single call: the host found keypoints deferred to descr_big in the counters descr_all's
+// last workgroup exported.  Runs descr_big_kernel on the launch recorded by launch_descr_all; it exports the counters again
+// under a new sequence number (the caller waits for that one).
+int launch_descr_big_pending(misift_ctx *ctx)
+{
+  PendingBig &pb = ctx->pending_big;
+  if (!pb.valid) return MISIFT_OK;
+  pb.valid = 0;
+  ctx->export_seq++;
+  ctx->descr_big_fallbacks++;
+  const float *scratch = pb.scratch;
+  const PyramidInfo &P = pb.P;
+  LaunchScope ls(ctx, "descr_big");
+  LAUNCH_Q8(descr_big_kernel, dim3(2, P.nframes), dim3(256), scratch, P, ctx->d_counters, pb.det, pb.pts, pb.max_pts,
+            pb.pack_offsets, pb.pack_dst, ctx->d_cand, pb.big_stride, ctx->h_counters, ctx->export_seq);
   return ls.finish();
 }
 

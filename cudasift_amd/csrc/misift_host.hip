@@ -357,6 +357,8 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
   ctx->balance_frames = 1;       // r05: on by default (full GPU suite + bench A/B both ways: profiles/r05_balance_*); =0 restores per-frame grids
   if (const char *e = getenv("MISIFT_BALANCE")) ctx->balance_frames = atoi(e) != 0;
+  ctx->fold_descr_tail = 1;
+  if (const char *e = getenv("MISIFT_FOLD_TAIL")) ctx->fold_descr_tail = atoi(e) != 0;
   ctx->patch_reach = 17.9f;                   // = PATCH_REACH of kernels_points.hip: what the LDS window of descr_all covers
   if (const char *e = getenv("MISIFT_TEST_PATCH_REACH")) {          // tests: ordinary keypoints down the descr_big path
     const float v = (float)atof(e);
@@ -504,6 +506,8 @@ extern "C" int misift_ctx_set_early_return(misift_ctx *ctx, int on)
 }
 
 extern "C" int misift_ctx_last_call_balanced(misift_ctx *ctx) { return ctx ? ctx->cur_balanced : -1; }
+
+extern "C" int misift_ctx_descr_big_fallbacks(misift_ctx *ctx) { return ctx ? ctx->descr_big_fallbacks : -1; }
 
 extern "C" int misift_ctx_chain_fallbacks(misift_ctx *ctx) { return ctx ? ctx->chain_fallbacks : -1; }
 
@@ -1262,8 +1266,20 @@ static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pt
 {
   if (ctx->exported) {
     // the last kernel of the call has written the counter blocks into h_counters and stores export_seq behind them
-    const int rc = wait_host_flag(ctx, ctx->h_counters + (size_t)nframes * CNT_STRIDE, ctx->export_seq);
+    int rc = wait_host_flag(ctx, ctx->h_counters + (size_t)nframes * CNT_STRIDE, ctx->export_seq);
     if (rc) return rc;
+    if (ctx->pending_big.valid) {
+      // a folded single call (launch_descr_all): descr_all exported the counters; descr_big runs only if some keypoint was
+      // deferred to it — next to never — and exports them again
+      bool any = false;
+      for (int f = 0; f < nframes; f++) any = any || ctx->h_counters[(size_t)f * CNT_STRIDE + CNT_BIG] != 0;
+      if (!any) ctx->pending_big.valid = 0;
+      else {
+        rc = launch_descr_big_pending(ctx);
+        if (!rc) rc = wait_host_flag(ctx, ctx->h_counters + (size_t)nframes * CNT_STRIDE, ctx->export_seq);
+        if (rc) return rc;
+      }
+    }
   } else {
     HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * (size_t)nframes,
                            hipMemcpyDeviceToHost, ctx->stream));

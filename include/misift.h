@@ -109,6 +109,10 @@ int misift_ctx_chain_fallbacks(misift_ctx *ctx);
 /* Diagnostics: 1 if the last extraction enqueued on this context dealt the workgroups of its per-keypoint kernels out
  * in proportion to the frames' keypoint counts (batches of more than MISIFT_SMALL_FRAMES frames, MISIFT_BALANCE != 0). */
 int misift_ctx_last_call_balanced(misift_ctx *ctx);
+/* Diagnostics: synchronous calls of a frame or two whose descriptor launch was the last one (r05) but that then needed the
+ * global-memory descriptor kernel after all, for a keypoint larger than the LDS window (next to never; MISIFT_FOLD_TAIL=0
+ * always launches it). */
+int misift_ctx_descr_big_fallbacks(misift_ctx *ctx);
 int misift_ctx_sync(misift_ctx *ctx);
 const char *misift_last_error(void);
 

@@ -1181,6 +1181,9 @@ def test_descr_big_path_on_ordinary_keypoints(reach):
         big = int(c.get_counter_block(0)[48])                                   # CNT_BIG: keypoints deferred to descr_big
         assert n == nref and np.array_equal(cnt, cref)
         assert big > (0.05 if reach == "13.0" else 0.3) * n, (big, n)           # the rare path is the busy one here
+        # a synchronous single call ends with descr_all (its last workgroup exports the counters, r05); descr_big is
+        # launched only because the host found deferred keypoints in them — this IS that case
+        assert c.descr_big_fallbacks() == 1
         compare_points(ref[:nref], got[:n], "descr_big_reach%s" % reach, record)
         frames = np.stack([synth_frame(32 + i, 640, 360) for i in range(6)])
         rb, nb, _ = orc().extract_batch(frames, num_octaves=4, init_blur=1.0, thresh=3.0, max_pts=8192)
@@ -1188,6 +1191,34 @@ def test_descr_big_path_on_ordinary_keypoints(reach):
         assert np.array_equal(gn, nb)
         for f in range(len(frames)):
             compare_points(rb[f, :nb[f]], gb[f, :gn[f]], "descr_big_batch_reach%s_f%d" % (reach, f), record)
+        assert c.descr_big_fallbacks() == 1                                     # (batches launch descr_big unconditionally)
         record("descr_big_path/reach" + reach, deferred=big, keypoints=int(n))
     finally:
         c.close()
+
+
+def test_single_call_ends_with_the_descriptor_launch(ctx):
+    """The single-call path is five dependent dispatches (r05): descr_all's last workgroup hands the counters to the host, no
+    descr_big launch unless a keypoint was deferred to it; MISIFT_FOLD_TAIL=0 is the r04 sequence.  Same records either way."""
+    import os
+    from cudasift_amd import capi
+    img = synth_frame(44, 1280, 960)
+    ref, nref, cref = orc().extract(img, 5, 1.0, 3.0)
+    out = {}
+    for fold in ("1", "0"):
+        os.environ["MISIFT_FOLD_TAIL"] = fold
+        try:
+            c = capi.Context(0)
+        finally:
+            del os.environ["MISIFT_FOLD_TAIL"]
+        try:
+            for rep in range(3):
+                got, n, cnt = c.extract(img, num_octaves=5, init_blur=1.0, thresh=3.0)
+                assert n == nref and np.array_equal(cnt, cref), (fold, rep)
+            out[fold] = int(n)
+            assert c.descr_big_fallbacks() == 0
+            compare_points(ref[:nref], got[:n], "fold_tail%s" % fold, record)
+        finally:
+            c.close()
+    record("single_call_fold_tail", keypoints=out["1"])
+    assert out["1"] == out["0"]            # (the number of GPU activities per call is in profiles/r05_single_call_budget_*.txt)
