@@ -186,6 +186,62 @@ __device__ __forceinline__ Pair4 blur_pair(const Taps2 &t, float4 c, float4 p1, 
   h.w = conv9p(t, v.w, v.z + rx, v.y + ry, v.x + rz, lw + rw);
   return h;
 }
+// ---- the same blur_pair in two halves with the neighbour lanes' vertical sums travelling through LDS (r06, SCAN_XCH).
+// The 16 DPP moves per scale pair cost the SIMD as much as 16 packed FMAs (4.7 issue cycles each: 21 % of the row);
+// two ds_write_b128 + four ds_read_b128 take no VALU issue slot.  Layout per wavefront: two planes of 66 float4 slots
+// (plane 0: the (x, y) pixels' scale pairs, plane 1: (z, w)); lane l owns slot l + 1, slots 0 and 65 stay zero (what
+// DPP's bound_ctrl hands lanes 0 and 63).  A wavefront's DS instructions execute in issue order, so the ONE buffer serves
+// the three scale pairs of a row back to back — write pair p+1 behind the reads of pair p — with no wait in between;
+// the wavefront-scope fences only keep the compiler from reordering accesses that alias across lanes.
+#define XCH_PLANE 66
+#define XCH_FLOAT4S (2 * XCH_PLANE)
+__device__ __forceinline__ void wave_lds_order()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ Pair4 vert_pair(const Taps2 &t, float4 c, float4 p1, float4 p2, float4 p3, float4 p4)
+{
+  Pair4 v;
+  v.x = conv9p(t, mk2(c.x, c.x), mk2(p1.x, p1.x), mk2(p2.x, p2.x), mk2(p3.x, p3.x), mk2(p4.x, p4.x));
+  v.y = conv9p(t, mk2(c.y, c.y), mk2(p1.y, p1.y), mk2(p2.y, p2.y), mk2(p3.y, p3.y), mk2(p4.y, p4.y));
+  v.z = conv9p(t, mk2(c.z, c.z), mk2(p1.z, p1.z), mk2(p2.z, p2.z), mk2(p3.z, p3.z), mk2(p4.z, p4.z));
+  v.w = conv9p(t, mk2(c.w, c.w), mk2(p1.w, p1.w), mk2(p2.w, p2.w), mk2(p3.w, p3.w), mk2(p4.w, p4.w));
+  return v;
+}
+struct Nbr4 { v2f lx, ly, lz, lw, rx, ry, rz, rw; };
+__device__ __forceinline__ void xch_put(float4 *xch, const Pair4 &v)       // xch = the wavefront's buffer + lane
+{
+  wave_lds_order();
+  xch[1] = make_float4(v.x.x, v.x.y, v.y.x, v.y.y);
+  xch[XCH_PLANE + 1] = make_float4(v.z.x, v.z.y, v.w.x, v.w.y);
+  wave_lds_order();
+}
+__device__ __forceinline__ Nbr4 xch_get(const float4 *xch)
+{
+  const float4 la = xch[0], lb = xch[XCH_PLANE], ra = xch[2], rb = xch[XCH_PLANE + 2];
+  Nbr4 n;
+  n.lx = mk2(la.x, la.y); n.ly = mk2(la.z, la.w); n.lz = mk2(lb.x, lb.y); n.lw = mk2(lb.z, lb.w);
+  n.rx = mk2(ra.x, ra.y); n.ry = mk2(ra.z, ra.w); n.rz = mk2(rb.x, rb.y); n.rw = mk2(rb.z, rb.w);
+  return n;
+}
+__device__ __forceinline__ Nbr4 dpp_get(const Pair4 &v)
+{
+  Nbr4 n;
+  n.lx = lane_from_left2(v.x); n.ly = lane_from_left2(v.y); n.lz = lane_from_left2(v.z); n.lw = lane_from_left2(v.w);
+  n.rx = lane_from_right2(v.x); n.ry = lane_from_right2(v.y); n.rz = lane_from_right2(v.z); n.rw = lane_from_right2(v.w);
+  return n;
+}
+__device__ __forceinline__ Pair4 horiz_pair(const Taps2 &t, const Pair4 &v, const Nbr4 &n)
+{
+  Pair4 h;
+  h.x = conv9p(t, v.x, n.lw + v.y, n.lz + v.z, n.ly + v.w, n.lx + n.rx);
+  h.y = conv9p(t, v.y, v.x + v.z, n.lw + v.w, n.lz + n.rx, n.ly + n.ry);
+  h.z = conv9p(t, v.z, v.y + v.w, v.x + n.rx, n.lw + n.ry, n.lz + n.rz);
+  h.w = conv9p(t, v.w, v.z + n.rx, v.y + n.ry, v.x + n.rz, n.lw + n.rw);
+  return h;
+}
 // tap pairs of the three scale pairs (1,2), (3,4), (5,6) the scan needs: dst[5*p + j] = {k[1+2p][j], k[2+2p][j]}
 #define NUM_SCAN_PAIRS 3
 __device__ __forceinline__ v2f scan_pair_tap(const LaplaceTaps &taps, int i)
@@ -395,6 +451,9 @@ __global__ __launch_bounds__(256) void detect_kernel(const float *__restrict__ d
 #ifndef SCAN_UNROLL3
 #define SCAN_UNROLL3 1
 #endif
+#ifndef SCAN_UNROLL9
+#define SCAN_UNROLL9 0           // SCAN_RING = 0: the register window walks nine rows per trip with rotating names (r06)
+#endif
 // ------------------------------------------------------- fused DoG + scan
 // dog_scan_kernel: blur -> DoG in registers (nothing but the base image is read, nothing but
 // a short candidate list is written) and a cheap NECESSARY test per pixel and scale:
@@ -414,6 +473,14 @@ struct LdsTaps {
   __device__ __forceinline__ Taps2 pair(int p) const { return load_taps2(tk + 5 * p); }
 };
 
+// The same 15 tap pairs held in registers for the whole segment (SCAN_TAPS_REG: 30 VGPRs, no LDS re-reads).  They are
+// VGPR pairs, not SGPR pairs, so the op_sel_hi trap described above does not apply.
+struct RegTaps {
+  Taps2 t[NUM_SCAN_PAIRS];
+  __device__ __forceinline__ explicit RegTaps(const v2f *tk) { for (int p = 0; p < NUM_SCAN_PAIRS; p++) t[p] = load_taps2(tk + 5 * p); }
+  __device__ __forceinline__ const Taps2 &pair(int p) const { return t[p]; }
+};
+
 #ifndef SCAN_RING
 #define SCAN_RING 1
 #endif
@@ -422,6 +489,15 @@ struct LdsTaps {
 #endif
 #ifndef SCAN_TAP_PREFETCH
 #define SCAN_TAP_PREFETCH (!SCAN_RING)
+#endif
+#ifndef SCAN_XCH
+#define SCAN_XCH 0               // 1 = neighbour lanes' vertical sums through LDS instead of DPP (r06)
+#endif
+#ifndef SCAN_XCH_DPP
+#define SCAN_XCH_DPP 0           // SCAN_XCH: how many of the three scale pairs (the last ones) still use DPP
+#endif
+#ifndef SCAN_TAPS_REG
+#define SCAN_TAPS_REG 0          // 1 = the 15 tap pairs live in 30 VGPRs across the row loop instead of being re-read from LDS
 #endif
 // d = a - b as ONE v_sub_f32.  Written as asm because the SLP vectoriser otherwise pairs two of the row's twenty DoG
 // subtractions into a v_pk_add_f32 with a negated operand and spends three v_mov assembling its register pairs (r03 ISA:
@@ -461,6 +537,7 @@ struct ScanRowCtx {
   unsigned cand_cap;
   int octave;
   unsigned *wq;                          // this wavefront's candidate queue (LDS, CQ_CAP words)
+  float4 *xch;                           // SCAN_XCH: this wavefront's neighbour-exchange buffer + lane (LDS)
 };
 // ---- candidate queue (r04).  Every appended candidate used to cost its lane an atomicAdd-with-return on ONE word per
 // (frame, octave): harmless in a 64-frame batch (64 x 5 words, four wavefronts per SIMD to hide the round trip) but the
@@ -545,7 +622,32 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
   // The six blurs are computed as three scale pairs (see blur_pair); the tap pairs of the next scale pair
   // are fetched from LDS while the current one is computed.
   float4 d[NUM_SCALES];
-#if SCAN_TAP_PREFETCH
+#if SCAN_XCH
+  // r06: the three vertical passes first, each handing its sums to the neighbour lanes through LDS while the next one
+  // is computed; then the three horizontal passes.  SCAN_XCH_DPP pairs (the last ones) still travel by DPP, which
+  // balances the VALU against the LDS pipe.
+  Pair4 b0, b1, b2;
+  {
+    const Pair4 v0 = vert_pair(taps_src.pair(0), c, p1, p2, p3, p4);
+    if (SCAN_XCH_DPP < 3) xch_put(g.xch, v0);
+    const Pair4 v1 = vert_pair(taps_src.pair(1), c, p1, p2, p3, p4);
+    Nbr4 n0, n1, n2;
+    if (SCAN_XCH_DPP < 3) n0 = xch_get(g.xch);
+    if (SCAN_XCH_DPP < 2) xch_put(g.xch, v1);
+    const Pair4 v2 = vert_pair(taps_src.pair(2), c, p1, p2, p3, p4);
+    if (SCAN_XCH_DPP < 2) n1 = xch_get(g.xch);
+    if (SCAN_XCH_DPP < 1) { xch_put(g.xch, v2); n2 = xch_get(g.xch); }
+    if (SCAN_XCH_DPP >= 3) n0 = dpp_get(v0);
+    b0 = horiz_pair(taps_src.pair(0), v0, n0);
+    if (SCAN_XCH_DPP >= 2) n1 = dpp_get(v1);
+    b1 = horiz_pair(taps_src.pair(1), v1, n1);
+    if (SCAN_XCH_DPP >= 1) n2 = dpp_get(v2);
+    b2 = horiz_pair(taps_src.pair(2), v2, n2);
+  }
+  d[0] = make_float4(sub1(b0.x.y, b0.x.x), sub1(b0.y.y, b0.y.x), sub1(b0.z.y, b0.z.x), sub1(b0.w.y, b0.w.x));
+  d[1] = make_float4(sub1(b1.x.x, b0.x.y), sub1(b1.y.x, b0.y.y), sub1(b1.z.x, b0.z.y), sub1(b1.w.x, b0.w.y));
+  d[2] = make_float4(sub1(b1.x.y, b1.x.x), sub1(b1.y.y, b1.y.x), sub1(b1.z.y, b1.z.x), sub1(b1.w.y, b1.w.x));
+#elif SCAN_TAP_PREFETCH
   Taps2 tcur = taps_src.pair(0), tnext = taps_src.pair(1);
   __builtin_amdgcn_sched_barrier(0);
   const Pair4 b0 = blur_pair(tcur, c, p1, p2, p3, p4);          // blurs 1, 2
@@ -674,11 +776,11 @@ template <int FAST, typename TAPS>
 __device__ __forceinline__ void scan_strip(const float *img, int width, int height, int pitch, int q, int lane,
                                            int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
                                            unsigned *list, unsigned cand_cap, int octave, bool al, unsigned *wq,
-                                           unsigned &qn)
+                                           unsigned &qn, float4 *xch = nullptr)
 {
   struct { int width, height, pitch; } g = {width, height, pitch};
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
-  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave, wq};
+  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave, wq, xch};
   const QuadCol qc = make_quadcol(q, g.width);
   auto ld = [&](int y) -> float4 {
     return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
@@ -690,12 +792,39 @@ __device__ __forceinline__ void scan_strip(const float *img, int width, int heig
   auto row = [&](const float4 &r0, const float4 &r1, const float4 &r2, const float4 &r3, const float4 &r4,
                  const float4 &r5, const float4 &r6, const float4 &r7, const float4 &r8, const int y) {
     // re-read the taps from LDS every row instead of pinning 80 VGPRs across the loop
-    asm volatile("" ::: "memory");
+    if (!SCAN_TAPS_REG) asm volatile("" ::: "memory");
     const float4 c = r4, p1 = add4p(r3, r5), p2 = add4p(r2, r6), p3 = add4p(r1, r7), p4 = add4p(r0, r8);
     scan_row(taps_src, rc, c, p1, p2, p3, p4, y, qn);
   };
   int y = y0;
-#if SCAN_UNROLL3
+#if SCAN_UNROLL9
+  // r06: nine rows per trip with the window's NAMES rotating — the row that leaves the window (only its pair sum with
+  // the newest row needs it) hands its registers to the load of the row that enters five rows later: no copies at all
+  // (the 3x form below moves 36 registers per three rows).
+  {
+    float4 w0 = r0, w1 = r1, w2 = r2, w3 = r3, w4 = r4, w5 = r5, w6 = r6, w7 = r7, w8 = r8;
+    auto step = [&](float4 &a0, const float4 &a1, const float4 &a2, const float4 &a3, const float4 &a4,
+                    const float4 &a5, const float4 &a6, const float4 &a7, const float4 &a8, const int yy)
+                    __attribute__((always_inline)) {
+      if (!SCAN_TAPS_REG) asm volatile("" ::: "memory");
+      const float4 c = a4, p1 = add4p(a3, a5), p2 = add4p(a2, a6), p3 = add4p(a1, a7), p4 = add4p(a0, a8);
+      a0 = ld(yy + 5);                           // lands under this row's math; first needed at the start of the next row
+      scan_row(taps_src, rc, c, p1, p2, p3, p4, yy, qn);
+    };
+    for (; y + 8 < y1; y += 9) {
+      step(w0, w1, w2, w3, w4, w5, w6, w7, w8, y);
+      step(w1, w2, w3, w4, w5, w6, w7, w8, w0, y + 1);
+      step(w2, w3, w4, w5, w6, w7, w8, w0, w1, y + 2);
+      step(w3, w4, w5, w6, w7, w8, w0, w1, w2, y + 3);
+      step(w4, w5, w6, w7, w8, w0, w1, w2, w3, y + 4);
+      step(w5, w6, w7, w8, w0, w1, w2, w3, w4, y + 5);
+      step(w6, w7, w8, w0, w1, w2, w3, w4, w5, y + 6);
+      step(w7, w8, w0, w1, w2, w3, w4, w5, w6, y + 7);
+      step(w8, w0, w1, w2, w3, w4, w5, w6, w7, y + 8);
+    }
+    r0 = w0; r1 = w1; r2 = w2; r3 = w3; r4 = w4; r5 = w5; r6 = w6; r7 = w7; r8 = w8;
+  }
+#elif SCAN_UNROLL3
   for (; y + 2 < y1; y += 3) {
     const float4 n0 = ld(y + 5);                 // prefetch: latency hides under the row's math
     row(r0, r1, r2, r3, r4, r5, r6, r7, r8, y);
@@ -728,11 +857,11 @@ template <int FAST, typename TAPS>      // 0 = generic loads, 1 = fast (width % 
 __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int height, int pitch, int q, int lane,
                                                 int y0, int y1, const TAPS &taps_src, float thresh, unsigned *cnt,
                                                 unsigned *list, unsigned cand_cap, int octave, bool al, float4 *mine,
-                                                unsigned *wq, unsigned &qn)
+                                                unsigned *wq, unsigned &qn, float4 *xch = nullptr)
 {
   struct { int width, height, pitch; } g = {width, height, pitch};
   const bool tester = lane >= 2 && lane <= OUT_LANES - 1 && 4 * q < g.width;
-  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave, wq};
+  const ScanRowCtx rc = {width, height, q, tester, __builtin_amdgcn_ballot_w64(tester), thresh, cnt, list, cand_cap, octave, wq, xch};
   const QuadCol qc = make_quadcol(q, g.width);
   auto ld = [&](int y) -> float4 {
     return load_quad_t<FAST>(img + (size_t)clampi(y, 0, g.height - 1) * g.pitch, q, g.width, al, qc);
@@ -785,6 +914,15 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
   __shared__ v2f s_taps[NUM_SCAN_PAIRS * 5];
   __shared__ unsigned s_cq[WAVES_PER_BLOCK][CQ_CAP];
   if (threadIdx.x < NUM_SCAN_PAIRS * 5) s_taps[threadIdx.x] = scan_pair_tap(taps, threadIdx.x);
+  float4 *xch = nullptr;
+#if SCAN_XCH
+  __shared__ float4 s_xch[WAVES_PER_BLOCK][XCH_FLOAT4S];
+  {
+    const int w_ = threadIdx.x >> 6, l_ = threadIdx.x & 63;
+    if (l_ < 4) s_xch[w_][(l_ >> 1) * XCH_PLANE + (l_ & 1) * (XCH_PLANE - 1)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xch = &s_xch[w_][l_];
+  }
+#endif
   __syncthreads();
   const ItemCoord it = decode_item(g);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -796,15 +934,20 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
     const int y0 = it.seg * g.seg_rows;
     cnt = counters + (size_t)it.frame * CNT_STRIDE;
     list = cand + (size_t)it.frame * cand_cap;
+#if SCAN_TAPS_REG
+    const RegTaps tsrc(s_taps);
+#else
+    const LdsTaps tsrc{s_taps};
+#endif
 #if SCAN_RING
     __shared__ float4 s_win[WAVES_PER_BLOCK][RING_FLOAT4S];
     scan_strip_ring<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
-                          min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh, cnt, list, cand_cap, octave,
-                          aligned != 0, &s_win[wave][lane], s_cq[wave], qn);
+                          min(y0 + g.seg_rows, g.height), tsrc, thresh, cnt, list, cand_cap, octave,
+                          aligned != 0, &s_win[wave][lane], s_cq[wave], qn, xch);
 #else
     scan_strip<FAST>(base + (long long)it.frame * g.frame_stride, g.width, g.height, g.pitch, q, lane, y0,
-                     min(y0 + g.seg_rows, g.height), LdsTaps{s_taps}, thresh, cnt, list, cand_cap, octave, aligned != 0,
-                     s_cq[wave], qn);
+                     min(y0 + g.seg_rows, g.height), tsrc, thresh, cnt, list, cand_cap, octave, aligned != 0,
+                     s_cq[wave], qn, xch);
 #endif
   }
   scan_queue_finish(s_cq[wave], qn, it.valid ? cnt + CNT_CAND + octave : nullptr, cnt, list, cand_cap);
@@ -855,7 +998,11 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   static_assert(sizeof(float4) * WAVES_PER_BLOCK * RING_FLOAT4S >= sizeof(float) * CHAIN_LDS_FLOATS_EMBED,
                 "the chain borrows the scan's row ring");
 #else
-  static_assert(!CHAIN, "the embedded chain borrows the LDS ring of SCAN_RING");
+  // (register window: the embedded chain gets an LDS area of its own in the CHAIN instantiations)
+  __shared__ float s_chain_lds[CHAIN ? CHAIN_LDS_FLOATS_EMBED : 4];
+#endif
+#if SCAN_XCH
+  __shared__ float4 s_xch[WAVES_PER_BLOCK][XCH_FLOAT4S];
 #endif
   // no XCD remap here: items of different levels cost differently, and the hardware's round-robin
   // block -> XCD placement is what keeps the eight XCDs evenly loaded across the level boundaries
@@ -863,7 +1010,11 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   bool chain_failed = false;
-#if SCAN_RING
+  float4 *xch = nullptr;
+#if SCAN_XCH
+  if (lane < 4) s_xch[wave][(lane >> 1) * XCH_PLANE + (lane & 1) * (XCH_PLANE - 1)] = make_float4(0.f, 0.f, 0.f, 0.f);
+  xch = &s_xch[wave][lane];
+#endif
   if (CHAIN) {
 #if SCAN_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[(size_t)G.nframes * CNT_STRIDE + 8] = (unsigned)wall_clock64();
@@ -873,8 +1024,12 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
 #endif
     if (lb < (unsigned)nchain) {                  // workgroup-uniform
       const int tiles = C.tiles_x * C.tiles_y;
-      scaledown_chain_block(const_cast<float *>(scratch), C, k5, (int)(lb % tiles), (int)(lb / tiles),
-                            reinterpret_cast<float *>(&s_win[0][0]));
+#if SCAN_RING
+      float *chain_lds = reinterpret_cast<float *>(&s_win[0][0]);
+#else
+      float *chain_lds = s_chain_lds;
+#endif
+      scaledown_chain_block(const_cast<float *>(scratch), C, k5, (int)(lb % tiles), (int)(lb / tiles), chain_lds);
       // the chain's stores are write-through (chain.hpp): once they have been acknowledged they are in memory, where
       // every XCD finds them — no L2 write-back (an agent-scope release fence per workgroup: +45 us per frame, r04).
       // "Once they have been acknowledged" is THIS wait: the workgroup-scope fence compiles to s_waitcnt lgkmcnt(0) only,
@@ -935,7 +1090,6 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
       chain_failed = s_chain_ok == 0u;             // workgroup-uniform
     }
   }
-#endif
   long long item = (long long)lb * WAVES_PER_BLOCK + wave;
   const bool valid = item < G.total_items && !chain_failed;      // (no early return: scan_queue_finish is a workgroup barrier)
   __shared__ unsigned s_cq[WAVES_PER_BLOCK][CQ_CAP];
@@ -966,14 +1120,19 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
     list = cand + (size_t)frame * G.cand_stride + L.cand_off;
     cand_cap = L.cand_cap;
     octave = L.octave;
+#if SCAN_TAPS_REG
+    const RegTaps tsrc(s_taps[wave]);
+#else
+    const LdsTaps tsrc{s_taps[wave]};
+#endif
 #if SCAN_RING
     scan_strip_ring<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
-                          min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, cnt, list, cand_cap, octave, true,
-                          &s_win[wave][lane], s_cq[wave], qn);
+                          min(y0 + L.seg_rows, L.h), tsrc, thresh, cnt, list, cand_cap, octave, true,
+                          &s_win[wave][lane], s_cq[wave], qn, xch);
 #else
     scan_strip<FAST>(scratch + (long long)frame * G.frame_stride + L.img_off, L.w, L.h, L.p, q, lane, y0,
-                     min(y0 + L.seg_rows, L.h), LdsTaps{s_taps[wave]}, thresh, cnt, list, cand_cap, octave, true,
-                     s_cq[wave], qn);
+                     min(y0 + L.seg_rows, L.h), tsrc, thresh, cnt, list, cand_cap, octave, true,
+                     s_cq[wave], qn, xch);
 #endif
   }
 #if SCAN_STAMPS
@@ -1488,7 +1647,7 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
     long long want = (target + (long long)P.nframes * S.nstrips - 1) / ((long long)P.nframes * S.nstrips);
     if (want < 1) want = 1;
     int seg = (int)((L.h + want - 1) / want);
-#if SCAN_RING
+#if SCAN_RING || SCAN_UNROLL9
     if (P.nframes <= ctx->small_frames) {
       // a frame or two: the launch is latency-bound (rows per wavefront x ~1 us), so short segments on every SIMD —
       // shorter still on the levels behind the embedded ScaleDown chain, whose rows are the tail of the launch's

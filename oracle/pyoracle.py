@@ -202,10 +202,11 @@ def extract(img, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, sca
     return pts, n, np.array(list(cnt), dtype=np.uint32)
 
 
-def descriptor_bounds(img, pts, n, num_octaves=5, init_blur=1.0, ulps=3.0, dtheta_deg=None):
-    """orc_descriptor_bounds: for the first n records of one ExtractSift call on `img`, the largest change of every
+def descriptor_bounds(img, pts, n, num_octaves=5, init_blur=1.0, ulps=3.0, dtheta_deg=None, scale_up=False, coord_scale=None):
+    """orc_descriptor_bounds2: for the first n records of one ExtractSift call on `img`, the largest change of every
     descriptor element that a last-bit difference of the sample coordinates can cause through the 8-bit texture weights
     (see sift_oracle.c).  dtheta_deg[n]: difference of the two sides' orientations (it turns the whole sample grid).
+    scale_up: the call up-sampled the image first; coord_scale[n]: 2 for the records RescalePositions has halved.
     Returns (bound[n,128], flips[n], wraps[n])."""
     img = _f32(img)
     h, w = img.shape
@@ -213,11 +214,35 @@ def descriptor_bounds(img, pts, n, num_octaves=5, init_blur=1.0, ulps=3.0, dthet
     bound = np.zeros((n, 128), np.float32)
     flips, wraps = np.zeros(n, np.int32), np.zeros(n, np.int32)
     L = lib()
-    L.orc_descriptor_bounds.restype = None
+    L.orc_descriptor_bounds2.restype = None
     dth = None if dtheta_deg is None else np.ascontiguousarray(dtheta_deg, np.float32)
-    L.orc_descriptor_bounds(_p(img), w, h, w, num_octaves, C.c_float(init_blur), _p(pts), n, C.c_float(ulps),
-                            None if dth is None else _p(dth), _p(bound), _p(flips), _p(wraps))
+    cs = None if coord_scale is None else np.ascontiguousarray(coord_scale, np.float32)
+    L.orc_descriptor_bounds2(_p(img), w, h, w, num_octaves, C.c_float(init_blur), int(bool(scale_up)), _p(pts), n,
+                             None if cs is None else _p(cs), C.c_float(ulps), None if dth is None else _p(dth),
+                             _p(bound), _p(flips), _p(wraps))
     return bound, flips, wraps
+
+
+def descriptor_explain(img, pts, targets, target_orient=None, num_octaves=5, init_blur=1.0, ulps=3.0, scale_up=False,
+                       coord_scale=None, tol=1e-5, max_flips=48):
+    """orc_descriptor_explains: for each record, search for the set of tie-weight roundings / seam decisions that turns
+    this side's descriptor (sampled on the grid of the OTHER side's orientation, target_orient) into `targets` (the other
+    side's descriptor).  Returns (residual[n], overrides used[n], candidates[n])."""
+    img = _f32(img)
+    h, w = img.shape
+    n = len(pts)
+    pts = np.ascontiguousarray(pts)
+    targets = np.ascontiguousarray(targets, np.float32)
+    res = np.zeros(n, np.float32)
+    nset, ncand = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    L = lib()
+    L.orc_descriptor_explains.restype = None
+    to = None if target_orient is None else np.ascontiguousarray(target_orient, np.float32)
+    cs = None if coord_scale is None else np.ascontiguousarray(coord_scale, np.float32)
+    L.orc_descriptor_explains(_p(img), w, h, w, num_octaves, C.c_float(init_blur), int(bool(scale_up)), _p(pts), n,
+                              None if cs is None else _p(cs), _p(targets), None if to is None else _p(to),
+                              C.c_float(ulps), C.c_float(tol), int(max_flips), _p(res), _p(nset), _p(ncand))
+    return res, nset, ncand
 
 
 def extract_batch(imgs, num_octaves=5, init_blur=1.0, thresh=3.0, lowest_scale=0.0, max_pts=32768, fracbits=8,

@@ -599,3 +599,33 @@ def test_det_functions_accuracy():
     assert es <= 1.2e-7 and ec <= 1.2e-7, (es, ec)                                 # 1 ulp at 1.0; __sinf is ~4e-7
     s, c = orc.det_eval(3, np.array([0.0], np.float32))
     assert s[0] == 0.0 and c[0] == 1.0
+
+
+def test_descriptor_explanation_accepts_ties_and_rejects_anything_else(stereo):
+    """util.descriptor_tail_bound's tight form (oracle.descriptor_explain): a descriptor difference counts as explained only
+    if flipping a few 8-bit texture weights that sit on a rounding tie reproduces the other side's descriptor.
+    Positive control: the model reproduces the oracle's own descriptors with no toggle (<= 2e-6).
+    Negative controls — differences of the tail's size (1e-4 ... 3e-4) but of another origin — must leave their residual:
+    every weight rounded differently (full-precision weights), and one element moved by 1.5e-4 ... 3e-4."""
+    import util
+    from util import associate
+    img = stereo[0][300:540, 400:720].copy()
+    pts, n, _ = orc.extract(img, 4, 1.0, 2.0)
+    A = pts[:n]
+    own, nset, _ = orc.descriptor_explain(img, A, A["data"], A["orientation"], 4, 1.0, ulps=0.0, tol=1.0)
+    assert n > 400 and own.max() <= 2e-6 and nset.max() == 0
+    p23, n23, _ = orc.extract(img, 4, 1.0, 2.0, fracbits=23)
+    ia, ib, _, _ = associate(A, p23[:n23])
+    a, b = A[ia], p23[:n23][ib]
+    sel = np.where(np.abs(a["data"] - b["data"]).max(axis=1) > 1e-4)[0][:40]
+    assert len(sel) >= 20
+    res, _, _ = orc.descriptor_explain(img, a[sel], b["data"][sel], b["orientation"][sel], 4, 1.0, ulps=util.EXPLAIN_ULPS,
+                                       tol=util.EXPLAIN_TOL)
+    assert res.min() > util.EXPLAIN_PARTIAL, res.min()
+    rng = np.random.default_rng(1)
+    T = a["data"][:40].copy()
+    for i in range(len(T)):
+        T[i, rng.integers(128)] += rng.uniform(1.5e-4, 3e-4)
+        T[i] /= np.linalg.norm(T[i])
+    res, _, _ = orc.descriptor_explain(img, a[:40], T, a["orientation"][:40], 4, 1.0, ulps=util.EXPLAIN_ULPS, tol=util.EXPLAIN_TOL)
+    assert res.min() > util.EXPLAIN_PARTIAL, res.min()

@@ -178,10 +178,10 @@ def test_extract_pinned_to_reference_kernels(stereo, case):
         img, noct, th = synth_frame(5, 333, 251), 3, 2.5
     r_pts, r_n, r_cnt = ref.extract(img, noct, 1.0, th, flavour="fast")
     orc.stats_reset()
-    with orc.contract(1):
+    with orc.contract(1):          # (the comparison too: the explanation model of util.descriptor_tail_bound follows the mode)
         o_pts, o_n, o_cnt = orc.extract(img, noct, 1.0, th)
-    assert o_n == r_n
-    compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, "refemul_fast_vs_oracle_nvcc/" + case, "bits", record, img=img)
+        assert o_n == r_n
+        compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, noct, "refemul_fast_vs_oracle_nvcc/" + case, "bits", record, img=img)
     # the mode every HIP parity test uses (no contraction outside the filters): same set, values within 3e-7
     orc.stats_reset()
     o_pts, o_n, o_cnt = orc.extract(img, noct, 1.0, th)
@@ -198,8 +198,8 @@ def test_extract_scaleup_and_lowest_scale_pinned(stereo):
     orc.stats_reset()
     with orc.contract(1):
         o_pts, o_n, o_cnt = orc.extract(img, 4, 1.0, 3.0, lowest_scale=1.5, scale_up=True)
-    assert o_n == r_n and o_n > 50
-    compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, 4, "refemul_scaleup", "bits")
+        assert o_n == r_n and o_n > 50
+        compare_with_reference(o_pts, o_cnt, r_pts, r_cnt, 4, "refemul_scaleup", "bits", img=img, scale_up=True)
 
 
 @needs_ref

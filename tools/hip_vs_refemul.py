@@ -2,7 +2,7 @@
 """The HIP path against the reference's OWN code, no oracle in between, at scale: N synthetic 1920x1080 frames (+ the stereo
 pair) extracted by libmisift.so on the GPU and by the emulated reference (oracle/_ref/libcudasift_refemul_fast.so: the
 reference's kernels and host code on the CPU SIMT emulator, prebuilt — it travels to the GPU box) -> pooled statistics,
-gpurun_out/r05_hip_vs_refemul.json.  Test infrastructure, like tests/test_gpu_golden.py, which asserts the same on five
+gpurun_out/<HVR_TAG>_hip_vs_refemul.json.  Test infrastructure, like tests/test_gpu_golden.py, which asserts the same on five
 committed golden cases."""
 import json
 import os
@@ -21,6 +21,7 @@ from synth import synth_frame                      # noqa: E402
 from refemul_report import stats                   # noqa: E402
 
 N = int(os.environ.get("HVR_FRAMES", "32"))
+TAG = os.environ.get("HVR_TAG", "r06")
 z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_pair_u8.npz"))
 cases = [("left.pgm thresh 3.0", z["left"].astype(np.float32), 5, 3.0), ("righ.pgm thresh 3.0", z["right"].astype(np.float32), 5, 3.0)]
 cases += [("synthetic 1920x1080 frame %d" % f, None, 5, 3.0) for f in range(N)]
@@ -54,7 +55,8 @@ for name, img, noct, th, blur, lowest, up in cases:
     st = stats(hp, hc, rp, rc, noct, img=img, init_blur=blur, scale_up=up)
     out["images"].append({"image": name, "numPts_hip": hn, "numPts_reference": rn, "only_hip": st["only_oracle"], **{k: st[k] for k in (
         "records", "counters_equal", "only_reference", "orientation_flips", "desc_over_0.0001", "desc_over_0.001")},
-        "desc_over_bound": st.get("desc_over_bound")})
+        "desc_over_bound": st.get("desc_over_bound"), "desc_explained": st.get("desc_explained"),
+        "desc_unexplained": st.get("desc_unexplained")})
     for kk, v in st.items():
         if isinstance(v, bool):
             pooled[kk] = pooled.get(kk, True) and v
@@ -68,8 +70,8 @@ for name, img, noct, th, blur, lowest, up in cases:
 pooled["only_hip"] = pooled.pop("only_oracle")          # stats() names its first argument "oracle"
 out["pooled_hip_vs_reference"] = pooled
 out["seconds"] = {"hip_single_frame_calls_incl_upload": round(t_hip, 2), "emulated_reference": round(t_ref, 2)}
-path = os.path.join(ROOT, "gpurun_out", "r05_hip_vs_refemul_variants.json" if os.environ.get("HVR_VARIANTS") else
-                    "r05_hip_vs_refemul.json" if N else "r05_hip_vs_refemul_match.json")
+path = os.path.join(ROOT, "gpurun_out", TAG + "_hip_vs_refemul_variants.json" if os.environ.get("HVR_VARIANTS") else
+                    TAG + "_hip_vs_refemul.json" if N else TAG + "_hip_vs_refemul_match.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(pooled, indent=1))

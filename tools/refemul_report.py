@@ -19,8 +19,10 @@ import util                                             # noqa: E402
 
 
 def stats(o_pts, o_cnt, r_pts, r_cnt, noct, img=None, init_blur=1.0, scale_up=False):
-    """img: the image both sides extracted from -> every descriptor pair over 1e-4 is also checked element by element against
-    its texture-weight bound (oracle.descriptor_bounds, tests/util.py BOUND_*): desc_over_bound counts the failures."""
+    """img: the image both sides extracted from -> every descriptor pair over 1e-4 is also EXPLAINED (oracle.descriptor_explain:
+    the other side's descriptor reproduced by flipping a few 8-bit texture weights that sit on a rounding tie; tests/util.py
+    EXPLAIN_*) and checked element by element against its worst-case texture-weight bound (oracle.descriptor_bounds,
+    BOUND_*): desc_unexplained / desc_over_bound count the failures."""
     total = int(o_cnt[2 * noct + 1])
     st = {"counters_equal": bool(np.array_equal(o_cnt, r_cnt)), "records": total}
     O, R = o_pts[:total], r_pts[:int(r_cnt[2 * noct + 1])]
@@ -41,13 +43,27 @@ def stats(o_pts, o_cnt, r_pts, r_cnt, noct, img=None, init_blur=1.0, scale_up=Fa
         st["desc_over_%g" % t] = int((dd > t).sum())
     st["desc_max"] = float(dd.max()) if len(dd) else 0.0
     st["desc_min_cos"] = float((A["data"][ok].astype(np.float64) * B["data"][ok]).sum(axis=1).min()) if ok.any() else 1.0
-    if img is not None and not scale_up:
+    if img is not None:
         big = np.where(dd > 1e-4)[0]
         st["desc_bound_checked"], st["desc_over_bound"], st["desc_diff_over_bound_max"] = int(len(big)), 0, 0.0
+        st["desc_explained"], st["desc_partly_explained"], st["desc_unexplained"], st["desc_residual_max"] = 0, 0, 0, 0.0
         if len(big):
             Ab, Bb = A[ok][big], B[ok][big]
+            cs = None
+            if scale_up:         # records below numPts were halved by RescalePositions (cudaSiftD.cu:753-761)
+                cs = np.where(np.asarray(ia)[ok][big] < int(o_cnt[2 * noct]), 2.0, 1.0).astype(np.float32)
+            # the tight form (r06): the other side's descriptor reproduced by flipping a few tie weights / seam decisions
+            res, nset, _ = orc.descriptor_explain(img, Ab, Bb["data"], Bb["orientation"], noct, init_blur, ulps=util.EXPLAIN_ULPS,
+                                                  scale_up=scale_up, coord_scale=cs, tol=util.EXPLAIN_TOL)
+            st["desc_explained"] = int((res <= util.EXPLAIN_TOL).sum())
+            st["desc_partly_explained"] = int(((res > util.EXPLAIN_TOL) & (res <= util.EXPLAIN_PARTIAL)).sum())
+            st["desc_unexplained"] = int((res > util.EXPLAIN_PARTIAL).sum())
+            st["desc_residual_max"] = float(res.max())
+            st["desc_toggles_median"] = float(np.median(nset))
+            # the worst case (r05): every candidate fetch flipping the same way
             bound, _, _ = orc.descriptor_bounds(img, Ab, len(big), noct, init_blur, util.BOUND_ULPS,
-                                                dtheta_deg=util.circ_diff_deg(Ab["orientation"], Bb["orientation"]))
+                                                dtheta_deg=util.circ_diff_deg(Ab["orientation"], Bb["orientation"]),
+                                                scale_up=scale_up, coord_scale=cs)
             r = (np.abs(Ab["data"].astype(np.float64) - Bb["data"]) / (bound + util.BOUND_SLACK)).max(axis=1)
             st["desc_over_bound"] = int((r > 1.0).sum())
             st["desc_diff_over_bound_max"] = float(r.max())
