@@ -91,6 +91,8 @@ SIGNATURES = {
     "misift_test_match_split": (_i, [_vp, _vp, _i, _vp, _i, _i, _i]),
     "misift_test_match_plan": (_i, [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "misift_test_frame_shares": (_i, [_i, _i, C.c_void_p, C.c_void_p]),
+    "misift_test_set_guard": (_i, [_i]),
+    "misift_test_check_guards": (_i, [C.POINTER(_i)]),
     "misift_comm_unique_id": (_i, [_vp]),
     "misift_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "misift_comm_adopt": (_i, [_vp, _vp, C.POINTER(_vp)]),
@@ -162,6 +164,21 @@ def laplace_taps(num_octaves):
     k = np.zeros(8 * 12 * 16, np.float32)
     check(lib().misift_laplace_taps(num_octaves, k.ctypes.data_as(_fp)), "misift_laplace_taps")
     return k
+
+
+def set_guard(on=True):
+    """Test mode: every device allocation made from now on (DevBuf and the library's own buffers) gets 64 KiB guard bands
+    and a NaN-poisoned payload (misift_test_set_guard).  Returns the previous mode."""
+    return bool(lib().misift_test_set_guard(int(on)))
+
+
+def check_guards():
+    """Verify the guard bands of every live guarded allocation; raises MisiftError on damage, returns how many were checked."""
+    n = _i(0)
+    bad = lib().misift_test_check_guards(C.byref(n))
+    if bad != 0:
+        raise MisiftError("guard check: %d damaged allocation(s): %s" % (bad, lib().misift_last_error().decode()))
+    return n.value
 
 
 class DevBuf:
@@ -277,9 +294,11 @@ class Context:
         check(lib().misift_download_2d(self.h, out.ctypes.data, w, ptr, pitch, w, h), "misift_download_2d")
         return out
 
+    poison_outputs = False        # tests (guard mode): output buffers start as 0xFF instead of zero
+
     def zeros(self, nbytes):
         buf = DevBuf(nbytes)
-        check(lib().misift_memset(self.h, buf.ptr, 0, nbytes), "misift_memset")
+        check(lib().misift_memset(self.h, buf.ptr, 0xFF if self.poison_outputs else 0, nbytes), "misift_memset")
         self.sync()
         return buf
 

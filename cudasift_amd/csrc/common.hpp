@@ -401,6 +401,13 @@ struct misift_ctx {
 };
 
 void misift_set_error(const char *fmt, ...);
+// Every device allocation of the library (its own buffers and misift_malloc's) goes through these two.  Normally they ARE
+// hipMalloc / hipFree.  In guard mode (misift_test_set_guard, MISIFT_GUARD=1: the test build of SURVEY section 5's
+// "guard-paged scratch arenas") an allocation gets MISIFT_GUARD_BYTES of a byte pattern in front of and behind the payload
+// and the payload is pre-filled with 0xFF (NaN as float, -1 as int); misift_test_check_guards() verifies every band.
+#define MISIFT_GUARD_BYTES 65536
+hipError_t misift_dev_alloc(void **out, size_t bytes, const char *tag);
+hipError_t misift_dev_free(void *ptr);
 void misift_warn_hw_queues(const char *who);   // once per process: GPU_MAX_HW_QUEUES unset or < 8 (stderr + misift_last_error)
 int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap);
 // the stream the most recent batch of `ctx` ran on (its own, or a pipeline's with batches in flight)

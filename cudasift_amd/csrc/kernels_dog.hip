@@ -1559,9 +1559,9 @@ int launch_refcap(misift_ctx *ctx, int w, int h, int nframes, int octave)
   const int tiles_x = (w + REFCAP_W - 1) / REFCAP_W, tiles_y = (h + REFCAP_H - 1) / REFCAP_H;
   const size_t words = (size_t)NUM_SCALES * tiles_x * tiles_y * REFCAP_WORDS;
   if (sizeof(unsigned) * words * nframes > ctx->refcap_bytes) {
-    if (ctx->d_refcap) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->d_refcap)); }
+    if (ctx->d_refcap) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(misift_dev_free(ctx->d_refcap)); }
     ctx->d_refcap = nullptr; ctx->refcap_bytes = 0;
-    HIP_TRY(hipMalloc((void **)&ctx->d_refcap, sizeof(unsigned) * words * nframes));
+    HIP_TRY(misift_dev_alloc((void **)&ctx->d_refcap, sizeof(unsigned) * words * nframes, "refcap_masks"));
     ctx->refcap_bytes = sizeof(unsigned) * words * nframes;
   }
   HIP_TRY(hipMemsetAsync(ctx->d_refcap, 0, sizeof(unsigned) * words * nframes, ctx->stream));

@@ -1850,9 +1850,9 @@ static int prepare_block_maps(misift_ctx *ctx, const PyramidInfo &P, bool *wante
   const int t_orient = points_grid_x(ctx, P.nframes, ctx->orient_blocks_per_cu) * P.nframes;
   const int t_descr = points_grid_x(ctx, P.nframes) * P.nframes;
   if (ctx->block_map_cap < t_orient + t_descr) {
-    if (ctx->d_block_map) HIP_TRY(hipFree(ctx->d_block_map));
+    if (ctx->d_block_map) HIP_TRY(misift_dev_free(ctx->d_block_map));
     ctx->d_block_map = nullptr; ctx->block_map_cap = 0;
-    HIP_TRY(hipMalloc((void **)&ctx->d_block_map, sizeof(int4) * (size_t)(t_orient + t_descr)));
+    HIP_TRY(misift_dev_alloc((void **)&ctx->d_block_map, sizeof(int4) * (size_t)(t_orient + t_descr), "block_maps"));
     ctx->block_map_cap = t_orient + t_descr;
     ctx->alloc_gen++;
   }

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <map>
 #include <mutex>
 #include <vector>
 #include "common.hpp"
@@ -384,7 +385,7 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   if (const char *e = getenv("MISIFT_HOST_SPIN")) ctx->host_spin = atoi(e) != 0;
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
-  HIP_TRY(hipMalloc((void **)&ctx->d_flags, sizeof(unsigned) * 64));
+  HIP_TRY(misift_dev_alloc((void **)&ctx->d_flags, sizeof(unsigned) * 64, "flags"));
   HIP_TRY(hipMemsetAsync(ctx->d_flags, 0, sizeof(unsigned) * 64, ctx->stream));
   HIP_TRY(hipHostMalloc((void **)&ctx->h_flags, sizeof(unsigned) * 64, hipHostMallocDefault));
   memset(ctx->h_flags, 0, sizeof(unsigned) * 64);
@@ -570,17 +571,17 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   if (x->gev_out) hipEventDestroy(x->gev_out);
   for (auto &p : x->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : x->pool) hipEventDestroy(e);
-  if (ctx->d_counters) hipFree(ctx->d_counters);
+  if (ctx->d_counters) misift_dev_free(ctx->d_counters);
   if (ctx->h_counters) hipHostFree(ctx->h_counters);
-  if (ctx->d_flags) hipFree(ctx->d_flags);
+  if (ctx->d_flags) misift_dev_free(ctx->d_flags);
   if (ctx->h_flags) hipHostFree(ctx->h_flags);
-  if (ctx->d_cand) hipFree(ctx->d_cand);
-  if (ctx->d_det) hipFree(ctx->d_det);
-  if (ctx->d_det_sorted) hipFree(ctx->d_det_sorted);
-  if (ctx->d_block_map) hipFree(ctx->d_block_map);
-  if (ctx->d_own_scratch) hipFree(ctx->d_own_scratch);
-  if (ctx->d_match_tmp) hipFree(ctx->d_match_tmp);
-  if (ctx->d_refcap) hipFree(ctx->d_refcap);
+  if (ctx->d_cand) misift_dev_free(ctx->d_cand);
+  if (ctx->d_det) misift_dev_free(ctx->d_det);
+  if (ctx->d_det_sorted) misift_dev_free(ctx->d_det_sorted);
+  if (ctx->d_block_map) misift_dev_free(ctx->d_block_map);
+  if (ctx->d_own_scratch) misift_dev_free(ctx->d_own_scratch);
+  if (ctx->d_match_tmp) misift_dev_free(ctx->d_match_tmp);
+  if (ctx->d_refcap) misift_dev_free(ctx->d_refcap);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
@@ -630,11 +631,11 @@ extern "C" int misift_get_options(misift_ctx *ctx, misift_options *opt)
 int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
 {
   if (nframes > ctx->cap_frames) {
-    if (ctx->d_counters) HIP_TRY(hipFree(ctx->d_counters));
+    if (ctx->d_counters) HIP_TRY(misift_dev_free(ctx->d_counters));
     if (ctx->h_counters) HIP_TRY(hipHostFree(ctx->h_counters));
     ctx->d_counters = nullptr; ctx->h_counters = nullptr;
     // (CNT_SPARE_BLOCKS more than frames: the call's flags and ticket words live behind the last frame's counters)
-    HIP_TRY(hipMalloc((void **)&ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + CNT_SPARE_BLOCKS)));
+    HIP_TRY(misift_dev_alloc((void **)&ctx->d_counters, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + CNT_SPARE_BLOCKS), "counters"));
     ctx->alloc_gen++;
     // one block more than frames: the word behind the last frame's counters is the host-export flag (descr_big_kernel)
     HIP_TRY(hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned) * CNT_STRIDE * ((size_t)nframes + 1), hipHostMallocDefault));
@@ -644,9 +645,9 @@ int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
   if (nframes > ctx->cap_frames || cand_cap > ctx->cand_cap) {
     const int nf = nframes > ctx->cap_frames ? nframes : ctx->cap_frames;
     const size_t cc = cand_cap > ctx->cand_cap ? cand_cap : ctx->cand_cap;
-    if (ctx->d_cand) HIP_TRY(hipFree(ctx->d_cand));
+    if (ctx->d_cand) HIP_TRY(misift_dev_free(ctx->d_cand));
     ctx->d_cand = nullptr;
-    HIP_TRY(hipMalloc((void **)&ctx->d_cand, sizeof(unsigned) * cc * nf));
+    HIP_TRY(misift_dev_alloc((void **)&ctx->d_cand, sizeof(unsigned) * cc * nf, "candidates"));
     ctx->alloc_gen++;
     ctx->cand_cap = cc;
     ctx->cap_frames = nf;
@@ -660,10 +661,10 @@ int misift_ensure_tmp(misift_ctx *ctx, size_t bytes)
   if (bytes > ctx->match_tmp_bytes) {
     if (ctx->d_match_tmp) {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(hipFree(ctx->d_match_tmp));
+      HIP_TRY(misift_dev_free(ctx->d_match_tmp));
     }
     ctx->d_match_tmp = nullptr; ctx->match_tmp_bytes = 0;
-    HIP_TRY(hipMalloc(&ctx->d_match_tmp, bytes));
+    HIP_TRY(misift_dev_alloc(&ctx->d_match_tmp, bytes, "match_tmp"));
     ctx->match_tmp_bytes = bytes;
   }
   return MISIFT_OK;
@@ -674,11 +675,11 @@ static int ensure_det(misift_ctx *ctx, int nframes, int max_pts)
   if (nframes > ctx->cap_det_frames || max_pts > ctx->det_max_pts) {
     const int nf = nframes > ctx->cap_det_frames ? nframes : ctx->cap_det_frames;
     const int mp = max_pts > ctx->det_max_pts ? max_pts : ctx->det_max_pts;
-    if (ctx->d_det) HIP_TRY(hipFree(ctx->d_det));
-    if (ctx->d_det_sorted) HIP_TRY(hipFree(ctx->d_det_sorted));
+    if (ctx->d_det) HIP_TRY(misift_dev_free(ctx->d_det));
+    if (ctx->d_det_sorted) HIP_TRY(misift_dev_free(ctx->d_det_sorted));
     ctx->d_det = nullptr; ctx->d_det_sorted = nullptr; ctx->cap_det_frames = 0; ctx->det_max_pts = 0;
-    HIP_TRY(hipMalloc((void **)&ctx->d_det, sizeof(Detection) * (size_t)nf * MISIFT_MAX_OCTAVES * mp));
-    HIP_TRY(hipMalloc((void **)&ctx->d_det_sorted, sizeof(Detection) * (size_t)nf * MISIFT_MAX_OCTAVES * mp));
+    HIP_TRY(misift_dev_alloc((void **)&ctx->d_det, sizeof(Detection) * (size_t)nf * MISIFT_MAX_OCTAVES * mp, "detections"));
+    HIP_TRY(misift_dev_alloc((void **)&ctx->d_det_sorted, sizeof(Detection) * (size_t)nf * MISIFT_MAX_OCTAVES * mp, "detections_binned"));
     ctx->alloc_gen++;
     ctx->cap_det_frames = nf;
     ctx->det_max_pts = mp;
@@ -687,12 +688,105 @@ static int ensure_det(misift_ctx *ctx, int nframes, int max_pts)
 }
 
 // ------------------------------------------------------------------ memory
+// ---- guard mode (test infrastructure inside the product library; inert unless switched on)
+#define GUARD_BAND_BYTE 0xA5
+#define GUARD_POISON_BYTE 0xFF
+struct GuardRec { char *base; size_t bytes; char tag[24]; };
+static std::mutex g_guard_mu;
+static std::map<void *, GuardRec> g_guard_map;
+static int g_guard_mode = -1;                  // -1: not decided yet (MISIFT_GUARD is read at the first allocation)
+static bool guard_on()
+{
+  if (g_guard_mode < 0) {
+    const char *e = getenv("MISIFT_GUARD");
+    g_guard_mode = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return g_guard_mode == 1;
+}
+hipError_t misift_dev_alloc(void **out, size_t bytes, const char *tag)
+{
+  if (!guard_on()) return hipMalloc(out, bytes);
+  char *base = nullptr;
+  const size_t padded = (bytes + 255) / 256 * 256;          // the rear band starts 256-byte aligned behind the payload's end
+  hipError_t e = hipMalloc((void **)&base, padded + 2 * (size_t)MISIFT_GUARD_BYTES);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemset(base, GUARD_BAND_BYTE, padded + 2 * (size_t)MISIFT_GUARD_BYTES)) != hipSuccess) return e;
+  if ((e = hipMemset(base + MISIFT_GUARD_BYTES, GUARD_POISON_BYTE, bytes)) != hipSuccess) return e;
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+  GuardRec r;
+  r.base = base; r.bytes = bytes;
+  snprintf(r.tag, sizeof(r.tag), "%s", tag ? tag : "?");
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guard_map[base + MISIFT_GUARD_BYTES] = r;
+  *out = base + MISIFT_GUARD_BYTES;
+  return hipSuccess;
+}
+hipError_t misift_dev_free(void *ptr)
+{
+  if (!ptr) return hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    auto it = g_guard_map.find(ptr);
+    if (it != g_guard_map.end()) {
+      char *base = it->second.base;
+      g_guard_map.erase(it);
+      return hipFree(base);
+    }
+  }
+  return hipFree(ptr);
+}
+// Switch guard mode on / off for the allocations made FROM NOW ON (live allocations keep what they have).  Returns the old mode.
+extern "C" int misift_test_set_guard(int on)
+{
+  const int old = guard_on() ? 1 : 0;
+  g_guard_mode = on ? 1 : 0;
+  return old;
+}
+// Verify the bands of every live guarded allocation (the whole device is synchronised first).  Returns the number of damaged
+// allocations (misift_last_error() names the first: tag, size, band, offset of the first wrong byte), or a negative status;
+// *allocations (optional) = live guarded allocations checked.  The payload between tail and rear band (the padding to 256
+// bytes) counts as band.
+extern "C" int misift_test_check_guards(int *allocations)
+{
+  if (hipDeviceSynchronize() != hipSuccess) { misift_set_error("misift_test_check_guards: hipDeviceSynchronize failed"); return -MISIFT_EHIP; }
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  std::vector<unsigned char> host;
+  int bad = 0, n = 0;
+  for (auto &kv : g_guard_map) {
+    const GuardRec &r = kv.second;
+    const size_t padded = (r.bytes + 255) / 256 * 256;
+    const size_t rear = padded - r.bytes + MISIFT_GUARD_BYTES;
+    host.resize(MISIFT_GUARD_BYTES + rear);
+    if (hipMemcpy(host.data(), r.base, MISIFT_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(host.data() + MISIFT_GUARD_BYTES, r.base + MISIFT_GUARD_BYTES + r.bytes, rear, hipMemcpyDeviceToHost) != hipSuccess) {
+      misift_set_error("misift_test_check_guards: copy of the bands of '%s' failed", r.tag);
+      return -MISIFT_EHIP;
+    }
+    n++;
+    for (size_t i = 0; i < host.size(); i++)
+      if (host[i] != GUARD_BAND_BYTE) {
+        if (bad == 0) {
+          if (i < MISIFT_GUARD_BYTES)
+            misift_set_error("guard band damaged: allocation '%s' (%zu bytes), %zu bytes IN FRONT of the payload", r.tag, r.bytes,
+                             (size_t)MISIFT_GUARD_BYTES - i);
+          else
+            misift_set_error("guard band damaged: allocation '%s' (%zu bytes), %zu bytes BEHIND the payload's end", r.tag, r.bytes,
+                             i - MISIFT_GUARD_BYTES);
+        }
+        bad++;
+        break;
+      }
+  }
+  if (allocations) *allocations = n;
+  return bad;
+}
+
 extern "C" int misift_malloc(size_t bytes, void **out)
 {
   ARG_CHECK(out != nullptr);
   *out = nullptr;
   if (bytes == 0) bytes = 16;
-  hipError_t e = hipMalloc(out, bytes);
+  hipError_t e = misift_dev_alloc(out, bytes, "misift_malloc");
   if (e != hipSuccess) {
     misift_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     return MISIFT_ENOMEM;
@@ -715,7 +809,7 @@ extern "C" int misift_malloc_managed(size_t bytes, void **out)
 
 extern "C" int misift_free(void *ptr)
 {
-  if (ptr) HIP_TRY(hipFree(ptr));
+  if (ptr) HIP_TRY(misift_dev_free(ptr));
   return MISIFT_OK;
 }
 
@@ -985,9 +1079,9 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   const size_t S = misift_scratch_floats(width, height, num_octaves, scale_up);
   if (!d_scratch) {
     if (ctx->own_scratch_floats < S * nframes) {
-      if (ctx->d_own_scratch) HIP_TRY(hipFree(ctx->d_own_scratch));
+      if (ctx->d_own_scratch) HIP_TRY(misift_dev_free(ctx->d_own_scratch));
       ctx->d_own_scratch = nullptr; ctx->own_scratch_floats = 0;
-      HIP_TRY(hipMalloc((void **)&ctx->d_own_scratch, sizeof(float) * S * nframes));
+      HIP_TRY(misift_dev_alloc((void **)&ctx->d_own_scratch, sizeof(float) * S * nframes, "own_scratch"));
       ctx->own_scratch_floats = S * nframes;
     }
     d_scratch = ctx->d_own_scratch;

@@ -193,7 +193,7 @@ static int mg_alloc_counts(misift_comm *c, size_t ints)
     if (!c->d_all_counts || !c->h_all_counts) { misift_set_error("out of host memory"); return MISIFT_ENOMEM; }
     return MISIFT_OK;
   }
-  if (!c->d_all_counts) HIP_TRY(hipMalloc((void **)&c->d_all_counts, sizeof(int) * ints));
+  if (!c->d_all_counts) HIP_TRY(misift_dev_alloc((void **)&c->d_all_counts, sizeof(int) * ints, "gather_counts"));
   if (!c->h_all_counts) HIP_TRY(hipHostMalloc((void **)&c->h_all_counts, sizeof(int) * ints, hipHostMallocDefault));
   return MISIFT_OK;
 }
@@ -201,7 +201,7 @@ static int mg_free_counts(misift_comm *c)
 {
   if (c->host) { free(c->d_all_counts); free(c->h_all_counts); }
   else {
-    if (c->d_all_counts) HIP_TRY(hipFree(c->d_all_counts));
+    if (c->d_all_counts) HIP_TRY(misift_dev_free(c->d_all_counts));
     if (c->h_all_counts) HIP_TRY(hipHostFree(c->h_all_counts));
   }
   c->d_all_counts = nullptr; c->h_all_counts = nullptr; c->cap_frames = 0;
@@ -456,7 +456,7 @@ extern "C" void misift_comm_destroy(misift_comm *c)
     if (s.ready) hipEventDestroy(s.ready);
   if (c->ev_gathered) hipEventDestroy(c->ev_gathered);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
-  if (c->d_all_counts) hipFree(c->d_all_counts);
+  if (c->d_all_counts) misift_dev_free(c->d_all_counts);
   if (c->h_all_counts) hipHostFree(c->h_all_counts);
   delete c;
 }

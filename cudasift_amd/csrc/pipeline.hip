@@ -155,16 +155,16 @@ extern "C" void misift_pipe_destroy(misift_pipe *p)
   if (p->s_rec) hipStreamSynchronize(p->s_rec);
   if (p->ctx->stream == p->s_compute) p->ctx->stream = p->saved_stream;
   for (PipeSlot &s : p->slots) {
-    if (s.d_frames) hipFree(s.d_frames);
-    if (s.d_packed) hipFree(s.d_packed);
-    if (s.d_counts) hipFree(s.d_counts);
+    if (s.d_frames) misift_dev_free(s.d_frames);
+    if (s.d_packed) misift_dev_free(s.d_packed);
+    if (s.d_counts) misift_dev_free(s.d_counts);
     if (s.h_counts) hipHostFree(s.h_counts);
     if (s.ev_uploaded) hipEventDestroy(s.ev_uploaded);
     if (s.ev_done) hipEventDestroy(s.ev_done);
     if (s.ev_counts) hipEventDestroy(s.ev_counts);
   }
-  if (p->d_scratch) hipFree(p->d_scratch);
-  if (p->d_pts) hipFree(p->d_pts);
+  if (p->d_scratch) misift_dev_free(p->d_scratch);
+  if (p->d_pts) misift_dev_free(p->d_pts);
   if (p->s_up) hipStreamDestroy(p->s_up);
   if (p->s_compute) hipStreamDestroy(p->s_compute);
   if (p->s_down) hipStreamDestroy(p->s_down);
@@ -204,15 +204,15 @@ extern "C" int misift_pipe_create(misift_ctx *ctx, int width, int height, int ba
   PIPE_TRY(hipStreamCreateWithFlags(&p->s_down, hipStreamNonBlocking));
   PIPE_TRY(hipStreamCreateWithFlags(&p->s_rec, hipStreamNonBlocking));
   const size_t S = misift_scratch_floats(width, height, num_octaves, 0);
-  PIPE_TRY(hipMalloc((void **)&p->d_scratch, sizeof(float) * S * batch_frames));
-  PIPE_TRY(hipMalloc((void **)&p->d_pts, sizeof(SiftPointD) * (size_t)max_pts * batch_frames));
+  PIPE_TRY(misift_dev_alloc((void **)&p->d_scratch, sizeof(float) * S * batch_frames, "pipe_scratch"));
+  PIPE_TRY(misift_dev_alloc((void **)&p->d_pts, sizeof(SiftPointD) * (size_t)max_pts * batch_frames, "pipe_points"));
   p->slots.resize(depth);
   for (PipeSlot &s : p->slots) memset(&s, 0, sizeof(s));
   const size_t elem = src_u8 ? 1 : sizeof(float);
   for (PipeSlot &s : p->slots) {
-    PIPE_TRY(hipMalloc(&s.d_frames, elem * p->frame_elems * batch_frames));
-    PIPE_TRY(hipMalloc((void **)&s.d_packed, sizeof(SiftPointD) * (size_t)max_pts * batch_frames));
-    PIPE_TRY(hipMalloc((void **)&s.d_counts, sizeof(int) * (2 * (size_t)batch_frames + 1)));
+    PIPE_TRY(misift_dev_alloc(&s.d_frames, elem * p->frame_elems * batch_frames, "pipe_frames"));
+    PIPE_TRY(misift_dev_alloc((void **)&s.d_packed, sizeof(SiftPointD) * (size_t)max_pts * batch_frames, "pipe_packed"));
+    PIPE_TRY(misift_dev_alloc((void **)&s.d_counts, sizeof(int) * (2 * (size_t)batch_frames + 1), "pipe_counts"));
     PIPE_TRY(hipHostMalloc((void **)&s.h_counts, sizeof(int) * (2 * (size_t)batch_frames + 1), hipHostMallocDefault));
     PIPE_TRY(hipEventCreateWithFlags(&s.ev_uploaded, hipEventDisableTiming));
     PIPE_TRY(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));

@@ -465,6 +465,16 @@ int misift_test_match_plan(int num_cus, int n1, int n2, int *nchunks, int *tiles
  * frame_shares_kernel evaluates on the device.  nblocks >= nframes. */
 int misift_test_frame_shares(int nblocks, int nframes, const unsigned *points, int *shares);
 
+/* Test-only: guard mode (out-of-bounds policing in the test build).  While it is on, every device
+ * allocation the library makes — misift_malloc for the caller, and its own counters, candidate lists, detection staging,
+ * block tables, matcher scratch, pipeline buffers — carries 64 KiB of a byte pattern in front of and behind the payload,
+ * and the payload starts out filled with 0xFF (NaN as a float, -1 as an int: nothing may rely on fresh memory being zero).
+ * misift_test_check_guards synchronises the device, verifies the bands of every live guarded allocation and returns the
+ * number of damaged ones (0 = intact; misift_last_error() names the first), negative on error.  MISIFT_GUARD=1 in the
+ * environment switches the mode on from the first allocation.  Allocations made while the mode is off are not guarded. */
+int misift_test_set_guard(int on);                 /* returns the previous mode */
+int misift_test_check_guards(int *allocations);    /* allocations (optional): how many were checked */
+
 /* ------------------------------------------------------------------- timing */
 
 /* TimerGPU (cudautils.h:61-81): event pair on the context stream. */
