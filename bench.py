@@ -955,7 +955,7 @@ class Bench:
         if not args.no_cpu and rank == 0:
             from oracle import pyoracle as orc
             self.orc = orc
-        self.match = self.latency = self.pcie = self.skewed = self.gather_info = self.step_ms = None
+        self.cfg2 = self.match = self.latency = self.pcie = self.skewed = self.gather_info = self.step_ms = None
         self.cpu = self.validated = self.no_preroll = None
 
     def barrier(self):
@@ -1614,6 +1614,20 @@ class Bench:
                           "valu_active_frac_of_step": round(active / simd_cycles, 4),
                           "issue_frac_of_step": round(insts * 4.1 / simd_cycles, 4),
                           "per_kernel_M_insts": {k: round(e["insts"] / 1e6, 1) for k, e in sorted(self.sq.items())}})
+            # the per-keypoint kernels against what the reference's algorithm asks for per keypoint (r06)
+            kp = max(1.0, self.kp_per_frame * self.B)
+            per_kp = {k: round(self.sq[k]["insts"] / kp, 1) for k in ("orient_all", "descr_all", "refine") if k in self.sq}
+            issue["per_keypoint"] = {
+                "keypoints_per_step": int(kp), "wave_instructions_per_keypoint": per_kp,
+                "floor_note": "one wavefront per keypoint.  descr_all: the reference's descriptor is 256 samples x 4 bilinear "
+                              "fetches + 256 x 8 votes (cudaSiftD.cu:340-386) = 16 fetches per lane at ~27 VALU each (coordinate, "
+                              "fract/floor, two 8-bit weight roundings, address, 4-texel blend) = 432, + 4 x (sqrt, FastAtan2, "
+                              "vote split) ~ 120, + two 64-tap footprint sums per lane = 128 fmaf, + two wave reductions and the "
+                              "normalisations ~ 60: ~740 per orientation against ~1040 measured per keypoint (1.1 orientations "
+                              "per keypoint on these frames: ~0.87 of the measured count is the algorithm itself).  orient_all: "
+                              "15 x 15 gradient samples (cudaSiftD.cu:972-1057) = 3.5 per lane x (4-texel gradient, exp weight, "
+                              "atan2, bin) ~ 60 = 210, + 32-bin histogram smoothing, two peak searches and the parabola fits "
+                              "~ 120: ~330 of the ~430 measured"}
         return issue
 
     def _roofline_hbm_kernels(self):
@@ -1752,7 +1766,13 @@ class Bench:
                           "contexts_note": "the steps rotate over this many misift contexts per GPU (own stream, staging and "
                                            "scratch arena each): that many batches are in flight on the GPU",
                           "path": "unfused" if args.unfused else "fused dog+detect",
-                          "keypoints_per_frame": round(self.kp_per_frame, 1)},
+                          "keypoints_per_frame": round(self.kp_per_frame, 1),
+                          "timing_definition": "T2 of BASELINE.md section 2: device-resident end to end, LowPass ... descriptors + "
+                                               "count read-back (T1 and T3 of the same run: `timing_definitions`)",
+                          "preroll_steps": self.PRE,
+                          "value_without_preroll": self.no_preroll["value"] if self.no_preroll else None},
+               "timing_definitions": self.timing_definitions(),
+               "config2_1280x960": self.cfg2,
                "no_preroll": self.no_preroll,
                "validated_frames": validated,
                "validation": ("frames 0..%d of the LAST timed step: counts and every record equal to the oracle (tests/util.py "
@@ -1774,6 +1794,73 @@ class Bench:
                                "neighbours and alone_ms_per_step gives the same kernels with one batch at a time on one context"}
         C.CDLL(None).fflush(None)          # RCCL's version banner sits in the C stdio buffer: get it out first,
         print(json.dumps(out), flush=True)  # the JSON line is the LAST line of stdout
+
+    def timing_definitions(self):
+        """the three extraction timings, always side by side."""
+        td = {"T2": {"frames_per_s": round(self.fps, 1), "what": "`value`: LowPass ... descriptors + count read-back, frames resident in HBM"},
+              "T3": {"frames_per_s_f32": self.pcie.get("frames_per_s_f32") if isinstance(self.pcie, dict) else None,
+                     "frames_per_s_u8": self.pcie.get("frames_per_s_u8") if isinstance(self.pcie, dict) else None,
+                     "what": "T2 + H2D upload of the frames + D2H of the SiftPoint records (`pcie_inclusive`: the host-fed pipeline; "
+                             "fp32 frames as the reference uploads them, and 8-bit frames converted in registers)"}}
+        k = self.kernels or {}
+        alone = {n: e.get("alone_ms_per_step", e.get("ms_per_step")) for n, e in k.items() if isinstance(e, dict)}
+        if alone and "lowpass_down" in alone and all(v is not None for v in alone.values()):
+            tot = sum(alone.values())
+            t1 = tot - alone["lowpass_down"]
+            sd = alone.get("scaledown", 0.0)
+            td["T1"] = {"ms_per_step_one_batch_at_a_time": [round(t1, 4), round(t1 + 4.0 * sd / 1.3125, 4)],
+                        "frames_per_s": [round(self.world * self.B / (t1 + 4.0 * sd / 1.3125) * 1e3, 1), round(self.world * self.B / t1 * 1e3, 1)],
+                        "T2_same_basis_ms": round(tot, 4),
+                        "what": "the reference's `timer1` scope (cudaSiftH.cu:113-117): everything but the initial LowPass.  Here "
+                                "LowPass and the first ScaleDown are ONE launch (lowpass_down), so T1 is bracketed: summed "
+                                "one-batch-at-a-time launch durations without lowpass_down (the first ScaleDown is missing: a lower "
+                                "bound on the time), and the same plus a first ScaleDown priced at the measured scaledown launches' "
+                                "rate (they process 1/4 + 1/16 + 1/64 of its pixels).  Same basis as T2_same_basis_ms, not as `value` "
+                                "(which overlaps batches)"}
+        return td
+
+    def leg_config2(self):
+        """BASELINE config 2's shape through the batch path: 64 synthetic 1280x960 frames per step, reported with its fraction
+        of the 117.3 MB/frame HBM roofline.  A side leg; never `value`."""
+        args, torch = self.args, self.torch
+        self.cfg2 = None
+        if not (self.rank == 0 and self.world == 1 and not args.no_latency and not args.unfused):
+            return
+        self.wd.stage("config 2: 1280x960 batches")
+        capi = self.capi
+        w2, h2, B = 1280, 960, self.B
+        try:
+            fr = gen_frames_torch(torch, B, 7000, self.device)[:, :h2, :w2].contiguous()
+            K = max(1, self.RING)
+            S = capi.scratch_floats(w2, h2, NUM_OCTAVES, False)
+            scr = [torch.empty(S * B, dtype=torch.float32, device=self.device) for _ in range(K)]
+            cnt = torch.zeros(2 * B + 1, dtype=torch.int32, device=self.device)
+            packed = torch.empty(576 * 8192 * B, dtype=torch.uint8, device=self.device)
+
+            def loop(n):
+                for i in range(n):
+                    capi.check(capi.lib().misift_extract_batch_packed_async(
+                        self.ctx.h, fr.data_ptr(), B, h2 * w2, w2, h2, w2, NUM_OCTAVES, INIT_BLUR, THRESH, 0.0, scr[i % K].data_ptr(),
+                        None, 8192, cnt.data_ptr(), cnt.data_ptr() + 4 * B, packed.data_ptr()), "config2")
+            loop(8)
+            torch.cuda.synchronize()
+            n = 24
+            t0 = time.perf_counter()
+            loop(n)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            fps = B / dt
+            alg = 117.3e6
+            self.cfg2 = {"frames_per_s": round(fps, 1), "ms_per_step": round(1e3 * dt, 4), "frames_per_step": B,
+                         "keypoints_per_frame": round(float(cnt[:B].float().mean().item()), 1),
+                         "alg_bytes_per_frame": int(alg), "alg_TBps": round(fps * alg / 1e12, 3),
+                         "frac_of_117MB_roofline": round(fps * alg / (HBM_PEAK_GBS * 1e9), 4),
+                         "note": "BASELINE config 2 (1280x960, 5 octaves) as 64-frame batches on the headline's context, %d batches in "
+                                 "flight; crops of the synthetic 1920x1080 generator; 117.3 MB/frame = SURVEY 8d's algorithmic bytes, "
+                                 "most of which the fused scan never moves (the fraction may exceed 1)" % K}
+            del fr, scr, packed
+        except Exception as e:                                   # noqa: BLE001 — a side leg must not cost the line
+            self.cfg2 = {"error": repr(e)[:200]}
 
     def close(self):
         self.wd.stage("teardown")
@@ -1814,6 +1901,7 @@ def main():
     b.leg_kernel_events()
     b.leg_single_frame()          # BASELINE configs 2 and 3
     b.leg_skewed_batch()
+    b.leg_config2()
     b.leg_pcie()
     b.leg_counters_and_trace()    # rocprofv3 child passes (rank 0, N = 1)
     b.leg_roofline()
