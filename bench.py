@@ -1454,15 +1454,8 @@ class Bench:
         shows — no overlap with the coarse ScaleDowns, so an upper bound of what the step sees."""
         torch, capi, pl, B, NB = self.torch, self.capi, self.pl, self.B, self.NB
         self.wd.stage("single-launch scan")
-        saved = os.environ.get("MISIFT_SPLIT_TAIL")
-        os.environ["MISIFT_SPLIT_TAIL"] = "0"
-        try:
-            c1 = capi.Context(self.local_rank, self.stream.cuda_stream)
-        finally:
-            if saved is None:
-                del os.environ["MISIFT_SPLIT_TAIL"]
-            else:
-                os.environ["MISIFT_SPLIT_TAIL"] = saved
+        c1 = capi.Context(self.local_rank, self.stream.cuda_stream)
+        c1.set_knob("split_tail", 0)
         c1.set_options(quiet=1)
         c1.profile_enable(True)
         n1 = 8
@@ -1476,7 +1469,7 @@ class Bench:
         ms1 = p1["dog_scan"]["total_ms"] / n1
         if self.trace is not None:                 # the same from dispatch durations (rocprofv3 --kernel-trace, MISIFT_SPLIT_TAIL=0 child)
             self.wd.stage("single-launch scan, kernel-trace child pass")
-            t1, _ = collect_trace(B, steps=self.tsteps, skip=self.tskip, extra_env={"MISIFT_SPLIT_TAIL": "0"})
+            t1, _ = collect_trace(B, steps=self.tsteps, skip=self.tskip, extra_env={"MISIFT_SPLIT_TAIL": "0", "MISIFT_TUNABLES": "1"})
             if t1 and "dog_scan" in t1 and t1["dog_scan"]["launches_per_step"] == 1:
                 ms1 = t1["dog_scan"]["ms_per_step"]
         a1 = flops_step / (ms1 * 1e-3) / 1e12

@@ -50,8 +50,11 @@ SIGNATURES = {
     "misift_ctx_descr_big_fallbacks": (_i, [_vp]),
     "misift_last_error": (C.c_char_p, []),
     "misift_default_options": (None, [C.POINTER(Options)]),
+    "misift_default_options_sized": (None, [C.POINTER(Options), C.c_size_t]),
     "misift_set_options": (_i, [_vp, C.POINTER(Options)]),
     "misift_get_options": (_i, [_vp, C.POINTER(Options)]),
+    "misift_set_options_sized": (_i, [_vp, C.POINTER(Options), C.c_size_t]),
+    "misift_get_options_sized": (_i, [_vp, C.POINTER(Options), C.c_size_t]),
     "misift_malloc": (_i, [_sz, C.POINTER(_vp)]),
     "misift_free": (_i, [_vp]),
     "misift_memset": (_i, [_vp, _vp, _i, _sz]),
@@ -91,6 +94,8 @@ SIGNATURES = {
     "misift_test_match_split": (_i, [_vp, _vp, _i, _vp, _i, _i, _i]),
     "misift_test_match_plan": (_i, [_i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "misift_test_frame_shares": (_i, [_i, _i, C.c_void_p, C.c_void_p]),
+    "misift_test_set_knob": (_i, [_vp, C.c_char_p, C.c_double]),
+    "misift_test_knob_names": (C.c_char_p, []),
     "misift_test_set_guard": (_i, [_i]),
     "misift_test_check_guards": (_i, [C.POINTER(_i)]),
     "misift_comm_unique_id": (_i, [_vp]),
@@ -166,6 +171,11 @@ def laplace_taps(num_octaves):
     return k
 
 
+def knob_names():
+    """{knob: environment variable honoured under MISIFT_TUNABLES=1}."""
+    return dict(kv.split("=") for kv in lib().misift_test_knob_names().decode().split(","))
+
+
 def set_guard(on=True):
     """Test mode: every device allocation made from now on (DevBuf and the library's own buffers) gets 64 KiB guard bands
     and a NaN-poisoned payload (misift_test_set_guard).  Returns the previous mode."""
@@ -225,7 +235,7 @@ class Context:
     # ---- options
     def get_options(self):
         o = Options()
-        check(lib().misift_get_options(self.h, C.byref(o)), "misift_get_options")
+        check(lib().misift_get_options_sized(self.h, C.byref(o), C.sizeof(o)), "misift_get_options")
         return o
 
     def set_options(self, **kw):
@@ -234,7 +244,7 @@ class Context:
             if not hasattr(o, k):
                 raise KeyError(k)
             setattr(o, k, int(v))
-        check(lib().misift_set_options(self.h, C.byref(o)), "misift_set_options")
+        check(lib().misift_set_options_sized(self.h, C.byref(o), C.sizeof(o)), "misift_set_options")
 
     def set_batches_in_flight(self, k):
         """K pipelines behind this context (misift_ctx_set_batches_in_flight): consecutive packed-async calls overlap."""
@@ -247,6 +257,10 @@ class Context:
     def wait_batch(self, stream):
         """Make `stream` (a raw hipStream_t value) wait for the most recently enqueued batch of this context."""
         check(lib().misift_ctx_wait_batch(self.h, stream), "misift_ctx_wait_batch")
+
+    def set_knob(self, name, value):
+        """Developer / test knob of this context (misift_test_set_knob; capi.knob_names() lists them)."""
+        check(lib().misift_test_set_knob(self.h, name.encode(), float(value)), "misift_test_set_knob")
 
     def set_early_return(self, on=True):
         """Synchronous calls return at the last kernel's completion flag instead of after a stream synchronisation."""

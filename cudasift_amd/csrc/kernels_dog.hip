@@ -690,7 +690,7 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
   // border rows can never hold an extremum (a clamped neighbour equals the pixel itself)
   // (tester lanes only: the halo lanes' blurs see zeros beyond the wavefront and would trip the test in every row —
   //  with them masked, 99 % of the finest level's rows of a typical frame skip the extremum tests)
-  if (!SCAN_DO_TEST) {                           // register-pressure probe only (tools/kres.sh -DSCAN_DO_TEST=0)
+  if (!SCAN_DO_TEST) {                           // register-pressure probe only (tools/variants.sh ... "-DSCAN_DO_TEST=0")
     if (wave_any(tester && amax > thresh)) {
 #pragma unroll
       for (int p = 0; p < NUM_SCALES; p++) reinterpret_cast<float4 *>(list)[p * 64 + (q & 63)] = d[p];

@@ -14,6 +14,8 @@
 #include <math.h>
 #include <map>
 #include <mutex>
+#include <string>
+#include <utility>
 #include <vector>
 #include "common.hpp"
 #include "chain.hpp"
@@ -114,6 +116,7 @@ struct CtxExtra {
   misift_ctx *last_lane = nullptr;     // the pipeline that took the most recent batch (nullptr: the context itself)
   hipEvent_t last_done = nullptr;
   hipStream_t own_stream = nullptr;    // a child context owns its stream
+  std::vector<std::pair<std::string, double>> knobs;   // misift_test_set_knob calls so far: replayed on pipelines built later
   // host-side tap tables of the last call's (num_octaves, init_blur)
   int taps_noct = -1;
   float taps_table[8 * 12 * 16];
@@ -285,7 +288,20 @@ extern "C" int misift_device_arch(int device, char *arch, int arch_len)
   return MISIFT_OK;
 }
 
-extern "C" void misift_default_options(misift_options *opt)
+#undef misift_default_options
+static void default_options_full(misift_options *opt);
+extern "C" void misift_default_options_sized(misift_options *opt, size_t struct_size)
+{
+  if (!opt) return;
+  misift_options o;
+  default_options_full(&o);
+  memcpy(opt, &o, struct_size < sizeof(o) ? struct_size : sizeof(o));
+}
+extern "C" void misift_default_options(misift_options *opt)      // binaries built against the r04 header: its seven fields
+{
+  misift_default_options_sized(opt, 7 * sizeof(int));
+}
+static void default_options_full(misift_options *opt)
 {
   memset(opt, 0, sizeof(*opt));
   opt->texfrac_bits = 8;
@@ -306,6 +322,72 @@ extern "C" void misift_default_options(misift_options *opt)
   if ((e = getenv("MISIFT_REFERENCE_CAP"))) opt->reference_cap = atoi(e) != 0;
 }
 
+// ---- developer / test knobs (launch shapes, path selection).  ONE table: knob name <-> the environment variable that sets it
+// when MISIFT_TUNABLES=1.  README.md lists them; tests/test_cabi_cpu.py checks that list against this table.
+struct KnobName { const char *name, *env; };
+static const KnobName KNOBS[] = {
+  {"graph", "MISIFT_GRAPH"}, {"split_tail", "MISIFT_SPLIT_TAIL"}, {"bin", "MISIFT_BIN"}, {"descr_occ", "MISIFT_DESCR_OCC"},
+  {"tile", "MISIFT_TILE"}, {"tile_descr", "MISIFT_TILE_DESCR"}, {"tile_orient", "MISIFT_TILE_ORIENT"},
+  {"orient_blocks", "MISIFT_ORIENT_BLOCKS"}, {"point_blocks", "MISIFT_POINT_BLOCKS"}, {"strip_waves", "MISIFT_STRIP_WAVES"},
+  {"scan_waves", "MISIFT_SCAN_WAVES"}, {"chain_frames", "MISIFT_CHAIN_FRAMES"}, {"chain_embed", "MISIFT_CHAIN_EMBED"},
+  {"chain_wait_us", "MISIFT_CHAIN_WAIT_US"}, {"bin_min_frames", "MISIFT_BIN_MIN_FRAMES"}, {"small_frames", "MISIFT_SMALL_FRAMES"},
+  {"balance", "MISIFT_BALANCE"}, {"fold_tail", "MISIFT_FOLD_TAIL"}, {"patch_reach", "MISIFT_TEST_PATCH_REACH"},
+  {"lds_pad_lpd", "MISIFT_LDS_PAD_LPD"}, {"lds_pad_scan", "MISIFT_LDS_PAD_SCAN"}, {"lds_pad_orient", "MISIFT_LDS_PAD_ORIENT"},
+  {"lds_pad_descr", "MISIFT_LDS_PAD_DESCR"}, {"lowpass_tile", "MISIFT_LOWPASS_TILE"}, {"strip_rows_small", "MISIFT_STRIP_ROWS_SMALL"},
+  {"scan_rows_small_coarse", "MISIFT_SCAN_ROWS_SMALL_COARSE"}, {"scan_rows_small", "MISIFT_SCAN_ROWS_SMALL"},
+  {"host_spin", "MISIFT_HOST_SPIN"},
+};
+static bool tunables_from_env()
+{
+  const char *e = getenv("MISIFT_TUNABLES");
+  return e && atoi(e) != 0;
+}
+static int apply_knob(misift_ctx *ctx, const char *name, double v)
+{
+  const int i = (int)v;
+  const auto is = [&](const char *n) { return strcmp(name, n) == 0; };
+  if (is("graph")) extra(ctx)->graph_mode = i != 0;
+  else if (is("split_tail")) ctx->split_tail = i;
+  else if (is("bin")) ctx->bin_detections = i != 0;
+  else if (is("descr_occ")) ctx->descr_occ = i;
+  else if (is("tile")) ctx->tile_descr = ctx->tile_orient = i != 0;
+  else if (is("tile_descr")) ctx->tile_descr = i != 0;
+  else if (is("tile_orient")) ctx->tile_orient = i != 0;
+  else if (is("orient_blocks")) ctx->orient_blocks_per_cu = i > 0 ? i : 5;
+  else if (is("point_blocks")) ctx->point_blocks_per_cu = i > 0 ? i : 8;
+  else if (is("strip_waves")) ctx->strip_waves_per_cu = i > 0 ? i : 16;
+  else if (is("scan_waves")) ctx->scan_waves_per_cu = i > 0 ? i : 16;
+  else if (is("chain_frames")) ctx->chain_max_frames = i;
+  else if (is("chain_embed")) ctx->chain_embed = i != 0;
+  else if (is("chain_wait_us")) ctx->chain_wait_ticks = (unsigned)(v * 100.0);
+  else if (is("bin_min_frames")) ctx->bin_min_frames = i;
+  else if (is("small_frames")) ctx->small_frames = i;
+  else if (is("balance")) ctx->balance_frames = i != 0;
+  else if (is("fold_tail")) ctx->fold_descr_tail = i != 0;
+  else if (is("patch_reach")) { if (v > 0.0 && v < 17.9) ctx->patch_reach = (float)v; else if (v >= 17.9) ctx->patch_reach = 17.9f; }
+  else if (is("lds_pad_lpd")) ctx->lds_pad_lpd = i;
+  else if (is("lds_pad_scan")) ctx->lds_pad_scan = i;
+  else if (is("lds_pad_orient")) ctx->lds_pad_orient = i;
+  else if (is("lds_pad_descr")) ctx->lds_pad_descr = i;
+  else if (is("lowpass_tile")) ctx->lowpass_tile = i != 0;
+  else if (is("strip_rows_small")) ctx->strip_rows_small = i >= 2 ? i / 2 * 2 : 6;
+  else if (is("scan_rows_small_coarse")) ctx->scan_rows_small_coarse = i > 0 ? i : 2;
+  else if (is("scan_rows_small")) ctx->scan_rows_small = i > 0 ? i : 4;
+  else if (is("host_spin")) ctx->host_spin = i != 0;
+  else { misift_set_error("misift_test_set_knob: unknown knob '%s'", name); return MISIFT_EINVAL; }
+  return MISIFT_OK;
+}
+// Test / tuning entry point: set one knob of this context (and of its pipelines behind misift_ctx_set_batches_in_flight).
+// name = NULL: *names_out (optional) receives the comma-separated list "knob=ENV,..." of everything there is.
+extern "C" int misift_test_set_knob(misift_ctx *ctx, const char *name, double value);
+extern "C" const char *misift_test_knob_names(void)
+{
+  static std::string all;
+  if (all.empty())
+    for (const KnobName &k : KNOBS) all += std::string(all.empty() ? "" : ",") + k.name + "=" + k.env;
+  return all.c_str();
+}
+
 extern "C" void misift_ctx_destroy(misift_ctx *ctx);
 // Everything misift_ctx_create sets up after `new CtxFull()`; on any failure the caller destroys the
 // half-built context (misift_ctx_destroy tolerates null members), so nothing leaks.
@@ -313,17 +395,18 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
 {
   ctx->device = device;
   ctx->stream = (hipStream_t)stream;
-  misift_default_options(&ctx->opt);
+  default_options_full(&ctx->opt);
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char *e = getenv("MISIFT_GRAPH")) f->x.graph_mode = atoi(e) != 0;
-  // work decomposition of the streaming kernels: wavefronts aimed at per CU and launch (developer knobs)
+  // ---- launch shapes and path selection: DEFAULTS ONLY.  The developer / test knobs that change them are applied by
+  // apply_knob() — through misift_test_set_knob, or from the environment when MISIFT_TUNABLES=1 (tools/, the variant runs of
+  // the test suite); a production process reads none of those variables (r06: they were 30 getenv calls right here).
+  // work decomposition of the streaming kernels: wavefronts aimed at per CU and launch
   ctx->strip_waves_per_cu = 32;   // measured: lowpass_down 0.247 -> 0.220 ms vs 16 (better balance over the CUs, 64-row segments)
   ctx->scan_waves_per_cu = 32;
-  ctx->split_tail = 8;            // batches of >= 8 frames: measured +2.8 % frames/s (MISIFT_SPLIT_TAIL=0 disables,
-                                  // =N sets the smallest batch; a single frame is launch-latency bound and loses)
-  if (const char *e = getenv("MISIFT_SPLIT_TAIL")) ctx->split_tail = atoi(e);
+  ctx->split_tail = 8;            // batches of >= 8 frames: measured +2.8 % frames/s (0 disables, N sets the smallest batch;
+                                  // a single frame is launch-latency bound and loses)
   {
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -332,57 +415,32 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }
   ctx->bin_detections = 1;
-  if (const char *e = getenv("MISIFT_BIN")) ctx->bin_detections = atoi(e) != 0;
   ctx->descr_occ = 4;
-  if (const char *e = getenv("MISIFT_DESCR_OCC")) ctx->descr_occ = atoi(e);
   ctx->tile_descr = 1;
   ctx->tile_orient = 0;
-  if (const char *e = getenv("MISIFT_TILE")) ctx->tile_descr = ctx->tile_orient = atoi(e) != 0;
-  if (const char *e = getenv("MISIFT_TILE_DESCR")) ctx->tile_descr = atoi(e) != 0;
-  if (const char *e = getenv("MISIFT_TILE_ORIENT")) ctx->tile_orient = atoi(e) != 0;
   ctx->orient_blocks_per_cu = 5;          // one round of resident workgroups: orient_all runs 5 waves/SIMD
-  if (const char *e = getenv("MISIFT_ORIENT_BLOCKS")) ctx->orient_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 5;
   ctx->point_blocks_per_cu = 8;
-  if (const char *e = getenv("MISIFT_POINT_BLOCKS")) ctx->point_blocks_per_cu = atoi(e) > 0 ? atoi(e) : 8;
-  if (const char *e = getenv("MISIFT_STRIP_WAVES")) ctx->strip_waves_per_cu = atoi(e) > 0 ? atoi(e) : 16;
-  if (const char *e = getenv("MISIFT_SCAN_WAVES")) ctx->scan_waves_per_cu = atoi(e) > 0 ? atoi(e) : 16;
   ctx->chain_max_frames = 4;
-  if (const char *e = getenv("MISIFT_CHAIN_FRAMES")) ctx->chain_max_frames = atoi(e);
   ctx->chain_embed = 1;
-  if (const char *e = getenv("MISIFT_CHAIN_EMBED")) ctx->chain_embed = atoi(e) != 0;
   ctx->chain_wait_ticks = 10000000u;          // 100 ms of the 100 MHz wall clock: ~4 orders of magnitude above the chain's own time
-  if (const char *e = getenv("MISIFT_CHAIN_WAIT_US")) ctx->chain_wait_ticks = (unsigned)(atof(e) * 100.0);
   ctx->bin_min_frames = 4;
-  if (const char *e = getenv("MISIFT_BIN_MIN_FRAMES")) ctx->bin_min_frames = atoi(e);
   ctx->small_frames = 4;
-  if (const char *e = getenv("MISIFT_SMALL_FRAMES")) ctx->small_frames = atoi(e);
-  ctx->balance_frames = 1;       // r05: on by default (full GPU suite + bench A/B both ways: profiles/r05_balance_*); =0 restores per-frame grids
-  if (const char *e = getenv("MISIFT_BALANCE")) ctx->balance_frames = atoi(e) != 0;
+  ctx->balance_frames = 1;       // r05: on by default (full GPU suite + bench A/B both ways: profiles/r05_balance_*); 0 restores per-frame grids
   ctx->fold_descr_tail = 1;
-  if (const char *e = getenv("MISIFT_FOLD_TAIL")) ctx->fold_descr_tail = atoi(e) != 0;
   ctx->patch_reach = 17.9f;                   // = PATCH_REACH of kernels_points.hip: what the LDS window of descr_all covers
-  if (const char *e = getenv("MISIFT_TEST_PATCH_REACH")) {          // tests: ordinary keypoints down the descr_big path
-    const float v = (float)atof(e);
-    if (v > 0.0f && v < 17.9f) ctx->patch_reach = v;
-  }
-  if (const char *e = getenv("MISIFT_LDS_PAD_LPD")) ctx->lds_pad_lpd = atoi(e);
-  if (const char *e = getenv("MISIFT_LDS_PAD_SCAN")) ctx->lds_pad_scan = atoi(e);
-  if (const char *e = getenv("MISIFT_LDS_PAD_ORIENT")) ctx->lds_pad_orient = atoi(e);
-  if (const char *e = getenv("MISIFT_LDS_PAD_DESCR")) ctx->lds_pad_descr = atoi(e);
   ctx->lowpass_tile = 1;
-  if (const char *e = getenv("MISIFT_LOWPASS_TILE")) ctx->lowpass_tile = atoi(e) != 0;
   ctx->strip_rows_small = 6;
-  if (const char *e = getenv("MISIFT_STRIP_ROWS_SMALL")) ctx->strip_rows_small = atoi(e) >= 2 ? atoi(e) / 2 * 2 : 6;
   // (r04 sweep, profiles/r04_single_call_sweep_step5.txt: fine / coarse rows 9/9 31.0 us, 9/4 25.2, 6/4 23.2, 4/3 21.8, 4/2 21.2, 3/3 22.5)
   ctx->scan_rows_small_coarse = 2;
-  if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL_COARSE")) ctx->scan_rows_small_coarse = atoi(e) > 0 ? atoi(e) : 2;
   ctx->scan_rows_small = 4;
-  if (const char *e = getenv("MISIFT_SCAN_ROWS_SMALL")) ctx->scan_rows_small = atoi(e) > 0 ? atoi(e) : 4;
   // 0 = a synchronous call returns after hipStreamSynchronize (everything the call wrote is complete and visible to any
   // stream, device or host copy: the reference's contract).  1 = it returns as soon as the last kernel's flag reaches
   // pinned host memory (opt-in: misift_ctx_set_early_return; the cudaSift.h shim does, its read-back is same-stream).
   ctx->host_spin = 0;
-  if (const char *e = getenv("MISIFT_HOST_SPIN")) ctx->host_spin = atoi(e) != 0;
+  if (tunables_from_env()) {
+    for (const KnobName &k : KNOBS)
+      if (const char *e = getenv(k.env)) apply_knob(ctx, k.name, atof(e));
+  }
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
   HIP_TRY(misift_dev_alloc((void **)&ctx->d_flags, sizeof(unsigned) * 64, "flags"));
@@ -478,7 +536,10 @@ extern "C" int misift_ctx_set_batches_in_flight(misift_ctx *ctx, int k)
   for (int i = 0; i < k && !rc; i++) {
     misift_ctx *l = nullptr;
     rc = ctx_create_physical(ctx->device, nullptr, true, &l);
-    if (!rc) lanes.push_back(l);
+    if (!rc) {
+      lanes.push_back(l);
+      for (const auto &kv : x->knobs) apply_knob(l, kv.first.c_str(), kv.second);
+    }
   }
   for (int i = 0; i < 2 * k && !rc; i++) {
     hipEvent_t e = nullptr;
@@ -499,10 +560,21 @@ extern "C" int misift_ctx_set_batches_in_flight(misift_ctx *ctx, int k)
   return MISIFT_OK;
 }
 
+extern "C" int misift_test_set_knob(misift_ctx *ctx, const char *name, double value)
+{
+  ARG_CHECK(ctx != nullptr && name != nullptr);
+  int rc = apply_knob(ctx, name, value);
+  if (rc) return rc;
+  CtxExtra *x = extra(ctx);
+  x->knobs.emplace_back(name, value);
+  for (misift_ctx *l : x->lanes) apply_knob(l, name, value);
+  return MISIFT_OK;
+}
+
 extern "C" int misift_ctx_set_early_return(misift_ctx *ctx, int on)
 {
   ARG_CHECK(ctx != nullptr);
-  if (!getenv("MISIFT_HOST_SPIN")) ctx->host_spin = on ? 1 : 0;     // the environment has the last word (A/B runs)
+  if (!(tunables_from_env() && getenv("MISIFT_HOST_SPIN"))) ctx->host_spin = on ? 1 : 0;     // A/B runs: the environment has the last word
   return MISIFT_OK;
 }
 
@@ -613,19 +685,35 @@ extern "C" int misift_ctx_sync(misift_ctx *ctx)
   return MISIFT_OK;
 }
 
+#undef misift_set_options
+#undef misift_get_options
+#define MISIFT_OPTIONS_R04_BYTES (7 * sizeof(int))       // texfrac_bits ... deterministic: the struct of the r04 header
+extern "C" int misift_set_options_sized(misift_ctx *ctx, const misift_options *opt, size_t struct_size)
+{
+  ARG_CHECK(ctx && opt && struct_size >= sizeof(int) && struct_size % sizeof(int) == 0);
+  misift_options o = ctx->opt;                                   // fields the caller's header does not have keep their value
+  memcpy(&o, opt, struct_size < sizeof(o) ? struct_size : sizeof(o));
+  ARG_CHECK(o.texfrac_bits == 8 || o.texfrac_bits == 23 || o.texfrac_bits == 0);
+  ctx->opt = o;
+  return MISIFT_OK;
+}
+
+extern "C" int misift_get_options_sized(misift_ctx *ctx, misift_options *opt, size_t struct_size)
+{
+  ARG_CHECK(ctx && opt && struct_size >= sizeof(int));
+  memcpy(opt, &ctx->opt, struct_size < sizeof(ctx->opt) ? struct_size : sizeof(ctx->opt));
+  return MISIFT_OK;
+}
+
+// the symbols binaries built against the r04 header call: its seven fields, nothing behind them
 extern "C" int misift_set_options(misift_ctx *ctx, const misift_options *opt)
 {
-  ARG_CHECK(ctx && opt);
-  ARG_CHECK(opt->texfrac_bits == 8 || opt->texfrac_bits == 23 || opt->texfrac_bits == 0);
-  ctx->opt = *opt;
-  return MISIFT_OK;
+  return misift_set_options_sized(ctx, opt, MISIFT_OPTIONS_R04_BYTES);
 }
 
 extern "C" int misift_get_options(misift_ctx *ctx, misift_options *opt)
 {
-  ARG_CHECK(ctx && opt);
-  *opt = ctx->opt;
-  return MISIFT_OK;
+  return misift_get_options_sized(ctx, opt, MISIFT_OPTIONS_R04_BYTES);
 }
 
 int misift_ensure_frames(misift_ctx *ctx, int nframes, size_t cand_cap)
@@ -1471,8 +1559,13 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
                         int scale_up, float *d_scratch, SiftPointD *pts, int max_pts, int *num_pts_out)
 {
   ARG_CHECK(ctx != nullptr && num_pts_out != nullptr);
-  const int fused_saved = ctx->opt.fused;
-  if (dense_call(ctx, width, height, num_octaves)) ctx->opt.fused = 0;       // restored on every way out below
+  // the option is restored on EVERY way out (incl. the HIP_TRY returns below) by a scope guard, not by hand
+  struct FusedGuard {
+    misift_ctx *c; int saved;
+    ~FusedGuard() { c->opt.fused = saved; }
+  } fused_guard{ctx, ctx->opt.fused};
+  const int fused_saved = fused_guard.saved;
+  if (dense_call(ctx, width, height, num_octaves)) ctx->opt.fused = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = MISIFT_OK;
     int queued = 0;

@@ -176,14 +176,14 @@ extern "C" int misift_pipe_create(misift_ctx *ctx, int width, int height, int ba
                                   int num_octaves, float init_blur, float thresh, float lowest_scale, int max_pts,
                                   int depth, misift_pipe **out)
 {
-  if (!ctx || !out || width < 16 || height < 16 || batch_frames < 1 || max_pts < 1 || depth < 1 || depth > 8 ||
+  if (!ctx || !out || width < 1 || height < 1 || batch_frames < 1 || max_pts < 1 || depth < 1 || depth > 8 ||
       num_octaves < 1 || num_octaves > MISIFT_MAX_OCTAVES) {
     misift_set_error("misift_pipe_create: invalid argument");
     return MISIFT_EINVAL;
   }
-  // same size rule as misift_extract: the coarsest level must keep >= 8 pixels per side (fail here, not at the first submit)
-  if ((width >> (num_octaves - 1)) < 8 || (height >> (num_octaves - 1)) < 8 || width >= 16384 || height >= 16384) {
-    misift_set_error("misift_pipe_create: %dx%d is too small (or too large) for %d octaves", width, height, num_octaves);
+  // same size rule as misift_extract (r06: any size from 1 x 1; tiny frames / deep pyramids run on the dense kernels)
+  if (width >= 16384 || height >= 16384) {
+    misift_set_error("misift_pipe_create: %dx%d is too large (candidate codes hold 14-bit coordinates)", width, height);
     return MISIFT_EINVAL;
   }
   *out = nullptr;
@@ -248,7 +248,8 @@ extern "C" int misift_pipe_submit(misift_pipe *p, const void *host_frames, int n
   ctx->stream = p->s_compute;
   ctx->split_tail = 0;          // the pipe already overlaps batches on its own streams; the split measured -6 % here
   const int fused_saved = ctx->opt.fused;
-  if (ctx->opt.reference_cap) ctx->opt.fused = 0;       // the cap is defined on the dense kernels' extremum list (misift.h)
+  // the cap is defined on the dense kernels' extremum list (misift.h); tiny frames / deep pyramids run there as well
+  if (ctx->opt.reference_cap || misift_tiny_call(p->width, p->height, p->num_octaves)) ctx->opt.fused = 0;
   int rc = misift_extract_enqueue(ctx, s.d_frames, p->src_u8, nframes, (long long)p->frame_elems, p->width, p->height,
                                   p->width, p->num_octaves, p->init_blur, p->thresh, p->lowest_scale, 0, p->d_scratch,
                                   p->d_pts, p->max_pts);

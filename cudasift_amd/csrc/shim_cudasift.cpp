@@ -228,6 +228,10 @@ void ExtractSift(SiftData &siftData, CudaImage &img, int numOctaves, double init
 #else
   if (siftData.h_data && siftData.numPts > 0)
     SAFE(misift_copy_d2h(ctx(), siftData.h_data, siftData.d_data, sizeof(SiftPoint) * (size_t)siftData.numPts));
+  else
+    // no same-stream read-back behind the kernels: the early return (the last kernel's flag) must not stand in for the
+    // reference's blocking contract — a caller reading d_data from its own stream or another device would be unordered
+    SAFE(misift_ctx_sync(ctx()));
 #endif
   const double t2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!q) printf("Incl prefiltering & memcpy =  %.2f ms %d\n\n", t2, siftData.numPts);
@@ -317,6 +321,10 @@ double MatchSiftData(SiftData &data1, SiftData &data2)
 #ifndef MANAGEDMEM
   if (data1.h_data != NULL)      // score, ambiguity, match, match_xpos, match_ypos (matching.cu:1195-1199)
     SAFE(misift_download_fields(ctx(), data1.h_data, data1.d_data, data1.numPts, offsetof(SiftPoint, score), 5));
+  else
+    SAFE(misift_ctx_sync(ctx()));                        // (see ExtractSift: nothing same-stream follows the early return)
+#else
+  SAFE(misift_ctx_sync(ctx()));
 #endif
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!quiet()) printf("MatchSiftData time =          %.2f ms\n", ms);

@@ -117,8 +117,21 @@ int misift_ctx_sync(misift_ctx *ctx);
 const char *misift_last_error(void);
 
 void misift_default_options(misift_options *opt);
+/* misift_options grows at its END (reference_cap was added in r05) and has no size member, so the caller's sizeof
+ * travels with the call: the _sized entry points copy min(struct_size, the library's sizeof) bytes — fields the caller's
+ * header does not know keep their current value (set) / are not written (get) — and nothing is read or written past the
+ * caller's struct.  Code compiled against THIS header gets them through the two macros below; the plain exported
+ * symbols stay for binaries built against the r04 header and touch the seven fields that header had, no more. */
+void misift_default_options_sized(misift_options *opt, size_t struct_size);
+int misift_set_options_sized(misift_ctx *ctx, const misift_options *opt, size_t struct_size);
+int misift_get_options_sized(misift_ctx *ctx, misift_options *opt, size_t struct_size);
 int misift_set_options(misift_ctx *ctx, const misift_options *opt);
 int misift_get_options(misift_ctx *ctx, misift_options *opt);
+#ifndef MISIFT_NO_OPTION_MACROS
+#define misift_default_options(opt) misift_default_options_sized((opt), sizeof(*(opt)))
+#define misift_set_options(ctx, opt) misift_set_options_sized((ctx), (opt), sizeof(*(opt)))
+#define misift_get_options(ctx, opt) misift_get_options_sized((ctx), (opt), sizeof(*(opt)))
+#endif
 
 /* ------------------------------------------------------------------- memory */
 
@@ -464,6 +477,16 @@ int misift_test_match_plan(int num_cus, int n1, int n2, int *nchunks, int *tiles
  * `nframes` frames holding points[f] keypoints: shares[f] = 1 + floor((nblocks - nframes) * points[f] / sum), the formula
  * frame_shares_kernel evaluates on the device.  nblocks >= nframes. */
 int misift_test_frame_shares(int nblocks, int nframes, const unsigned *points, int *shares);
+
+/* Test / tuning only: developer knobs of a context — launch shapes (segment lengths, workgroups per CU, dynamic-LDS padding)
+ * and path selection (spatial binning, balanced per-keypoint launches, embedded ScaleDown chain, split pyramid tail, hipGraph
+ * replay, LDS-window vs global-memory sampling, descr_big threshold ...).  Defaults are the measured optimum
+ * (profiles/r05_knob_sweep.txt) and a production process never changes them: the library reads none of the corresponding
+ * MISIFT_* environment variables unless MISIFT_TUNABLES=1 is set (tools/, the variant runs of the test suite).
+ * misift_test_knob_names() = "knob=ENVIRONMENT_VARIABLE,..." of everything there is.  Applies to the context's pipelines
+ * (misift_ctx_set_batches_in_flight) as well, also to those built later. */
+int misift_test_set_knob(misift_ctx *ctx, const char *name, double value);
+const char *misift_test_knob_names(void);
 
 /* Test-only: guard mode (out-of-bounds policing in the test build).  While it is on, every device
  * allocation the library makes — misift_malloc for the caller, and its own counters, candidate lists, detection staging,

@@ -55,8 +55,17 @@ def test_host_only_entry_points():
     from oracle import pyoracle as orc
     assert np.array_equal(capi.laplace_taps(5), orc.laplace_taps(5))     # same host formula, same libm
     o = capi.Options()
-    capi.lib().misift_default_options(C.byref(o))
+    capi.lib().misift_default_options_sized(C.byref(o), C.sizeof(o))
     assert (o.texfrac_bits, o.fix_numpts, o.match_full, o.match_exact_top2, o.reference_cap) == (8, 0, 0, 0, 0)
+    # the struct grows at its end and carries no size: the _sized entry points never touch bytes past the caller's struct,
+    # and the plain symbols (binaries built against the r04 header) stop after that header's seven fields
+    o = capi.Options()
+    o.reference_cap = 77
+    capi.lib().misift_default_options(C.byref(o))
+    assert o.texfrac_bits == 8 and o.reference_cap == 77
+    o.texfrac_bits = -1
+    capi.lib().misift_default_options_sized(C.byref(o), 4 * 4)
+    assert o.texfrac_bits == 8 and o.reference_cap == 77
 
 
 def test_point_record_layout():
@@ -223,6 +232,11 @@ def test_every_environment_knob_of_the_library_is_documented():
             text = src.read_text()
             knobs |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', text))
             knobs |= set(re.findall(r'match_plan_param\("([A-Z_0-9]+)"', text))
+            knobs |= set(re.findall(r'\{"[a-z_]+", "(MISIFT_[A-Z_0-9]+)"\}', text))       # the knob table (MISIFT_TUNABLES=1)
     docs = "".join((root / f).read_text() for f in ("README.md", "INTEGRATION.md", "include/misift.h"))
     missing = sorted(k for k in knobs if k not in docs)
     assert len(knobs) > 20 and not missing, missing
+    # the knob table and the test entry point agree, and the library exports it without a GPU
+    from cudasift_amd import capi
+    names = capi.knob_names()
+    assert len(names) >= 25 and all(v in knobs for v in names.values()) and "MISIFT_TUNABLES" in knobs

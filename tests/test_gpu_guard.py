@@ -145,15 +145,11 @@ def test_reference_cap_and_dense_kernels(ctx, guarded):
 
 def test_descr_big_path(ctx):
     """Keypoints sent down descr_big (global-memory descriptor path) by the patch-reach test hook."""
-    import os
     from cudasift_amd import capi
     old = capi.set_guard(True)
-    os.environ["MISIFT_TEST_PATCH_REACH"] = "9.0"
+    g = capi.Context(0)
     try:
-        g = capi.Context(0)
-    finally:
-        del os.environ["MISIFT_TEST_PATCH_REACH"]
-    try:
+        g.set_knob("patch_reach", 9.0)
         g.poison_outputs = True
         img = synth_frame(31, 960, 540)
         a, na, ca = g.extract(img, num_octaves=5, thresh=2.5)

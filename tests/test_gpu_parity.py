@@ -552,6 +552,28 @@ def test_pipe_error_paths(ctx):
     pipe.close()
 
 
+@pytest.mark.parametrize("h,w,noct", [(9, 12, 2), (40, 100, 5), (15, 15, 1)])
+def test_pipe_takes_tiny_frames(ctx, h, w, noct):
+    """misift_pipe accepts every size the other entry points accept (r06; r05 refused frames under 16 x 16 and pyramids
+    whose coarsest level is under 8 px): same records as the batch call."""
+    from cudasift_amd import capi
+    B = 3
+    frames = np.random.default_rng(w).integers(0, 256, (B, h, w)).astype(np.uint8)
+    pin = capi.PinnedArray(frames.shape, np.uint8)
+    pin.array[...] = frames
+    out = capi.PinnedArray((B * 2048,), capi.POINT_DTYPE)
+    pipe = capi.Pipe(ctx, w, h, B, src_u8=True, num_octaves=noct, thresh=0.5, max_pts=2048, depth=2)
+    pipe.submit(pin.ptr, B)
+    counts, nrec = pipe.collect(out.ptr, B * 2048)
+    pipe.close()
+    rp, rn = ctx.extract_batch_ex(frames, num_octaves=noct, thresh=0.5, max_pts=2048)
+    assert np.array_equal(counts, rn)
+    off = 0
+    for f in range(B):
+        assert _canon(out.array[off:off + rn[f]]) == _canon(rp[f, :rn[f]])
+        off += rn[f]
+
+
 @pytest.mark.parametrize("h,w", [(1080, 1920), (960, 1280), (135, 240), (37, 260), (8, 4), (270, 480), (539, 484),
                                  (67, 1024), (135, 241), (64, 1281), (270, 483), (33, 17), (100, 250), (77, 999)])
 def test_fused_lowpass_scaledown_bit_exact(ctx, h, w):
@@ -786,15 +808,8 @@ def test_timed_path_16x1080p_packed_async_vs_oracle(ctx):
     for f in range(B):
         compare_points(ref[f, :nref[f]], recs[offs[f]:offs[f + 1]], "timed_path_f%d" % f, record)
     record("timed_path", frames=B, keypoints=int(counts.sum()), split_tail=True)
-    saved = os.environ.get("MISIFT_SPLIT_TAIL")
-    os.environ["MISIFT_SPLIT_TAIL"] = "0"
-    try:
-        c2 = capi.Context(0)
-    finally:
-        if saved is None:
-            del os.environ["MISIFT_SPLIT_TAIL"]
-        else:
-            os.environ["MISIFT_SPLIT_TAIL"] = saved
+    c2 = capi.Context(0)
+    c2.set_knob("split_tail", 0)
     try:
         c2.set_options(fused=1)
         packed2 = c2.upload(np.full(576 * mp * B, 0x5A, np.uint8))
@@ -822,16 +837,10 @@ def test_balanced_keypoint_launches_on_a_skewed_batch(ctx):
     frames = np.stack([synth_frame(9100 + i, w, h, amp=SYNTH_AMP * a) for i, a in enumerate(amps)])
 
     def fresh(balance):
-        saved = os.environ.get("MISIFT_BALANCE")
-        os.environ["MISIFT_BALANCE"] = balance
-        try:
-            return capi.Context(0)
-        finally:
-            if saved is None:
-                del os.environ["MISIFT_BALANCE"]
-            else:
-                os.environ["MISIFT_BALANCE"] = saved
-    c1, c2 = fresh("0"), fresh("1")
+        c = capi.Context(0)
+        c.set_knob("balance", balance)
+        return c
+    c1, c2 = fresh(0), fresh(1)
     try:
         c1.set_options(fused=1)
         c2.set_options(fused=1)
@@ -863,11 +872,8 @@ def test_balanced_batch_without_binning_builds_its_tables_in_a_kernel_of_their_o
     import os
     from cudasift_amd import capi
     frames = np.stack([synth_frame(9200 + i, 640, 360) for i in range(6)])
-    os.environ["MISIFT_BIN"] = "0"
-    try:
-        c = capi.Context(0)
-    finally:
-        del os.environ["MISIFT_BIN"]
+    c = capi.Context(0)
+    c.set_knob("bin", 0)
     try:
         c.profile_enable(True)
         pts, n = c.extract_batch(frames, num_octaves=4, thresh=3.0, max_pts=8192)
@@ -1169,11 +1175,8 @@ def test_descr_big_path_on_ordinary_keypoints(reach):
     entry point must still return the oracle's records."""
     import os
     from cudasift_amd import capi
-    os.environ["MISIFT_TEST_PATCH_REACH"] = reach
-    try:
-        c = capi.Context(0)
-    finally:
-        del os.environ["MISIFT_TEST_PATCH_REACH"]
+    c = capi.Context(0)
+    c.set_knob("patch_reach", float(reach))
     try:
         img = synth_frame(31, 960, 540)
         ref, nref, cref = orc().extract(img, 5, 1.0, 2.5)
@@ -1206,11 +1209,8 @@ def test_single_call_ends_with_the_descriptor_launch(ctx):
     ref, nref, cref = orc().extract(img, 5, 1.0, 3.0)
     out = {}
     for fold in ("1", "0"):
-        os.environ["MISIFT_FOLD_TAIL"] = fold
-        try:
-            c = capi.Context(0)
-        finally:
-            del os.environ["MISIFT_FOLD_TAIL"]
+        c = capi.Context(0)
+        c.set_knob("fold_tail", int(fold))
         try:
             for rep in range(3):
                 got, n, cnt = c.extract(img, num_octaves=5, init_blur=1.0, thresh=3.0)

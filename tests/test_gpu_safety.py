@@ -41,7 +41,7 @@ print("RESULT " + json.dumps({"frames": out, "fallbacks": ctx.chain_fallbacks()}
 
 
 def _child(env_extra):
-    env = dict(os.environ, MISIFT_QUIET="0", **env_extra)
+    env = dict(os.environ, MISIFT_QUIET="0", MISIFT_TUNABLES="1", **env_extra)
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (env_extra, r.stdout[-1500:], r.stderr[-1500:])
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]

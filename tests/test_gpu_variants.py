@@ -33,8 +33,11 @@ def _canon(recs):
 @pytest.fixture(params=VARIANTS, ids=lambda v: ",".join("%s=%s" % kv for kv in v.items()))
 def vctx(request):
     from cudasift_amd import capi
-    saved = {k: os.environ.get(k) for k in request.param}
-    os.environ.update(request.param)
+    # (MISIFT_TUNABLES=1: the launch-shape / path variables are read only under this master switch — a production process
+    #  ignores them; MISIFT_FUSED is a behaviour option and is always honoured)
+    env = dict(request.param, MISIFT_TUNABLES="1")
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         c = capi.Context(0)               # the switches are read when the context is created
     finally:

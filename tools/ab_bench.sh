@@ -1,6 +1,7 @@
 #!/bin/bash
 # Developer aid: A/B the default batch bench between libmisift.so builds on ONE box, alternating (clock / box drift).
 #   gpurun -- 'bash tools/ab_bench.sh tag "" build/variants/libmisift_x.so ...'   ("" = the in-tree library)
+export MISIFT_TUNABLES=1      # the library reads its launch-shape / path variables only under this switch
 tag=$1; shift
 export TMPDIR=/tmp; mkdir -p gpurun_out
 out=gpurun_out/${tag}_ab.txt; : > $out

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Developer aid: for each libmisift.so build — a short parity run (the scan-facing GPU tests) and, alternating over two
 # repetitions, the default batch bench.  gpurun -- 'bash tools/ab_parity_bench.sh tag "" build/variants/libmisift_x.so ...'
+export MISIFT_TUNABLES=1      # the library reads its launch-shape / path variables only under this switch
 tag=$1; shift
 export TMPDIR=/tmp; mkdir -p gpurun_out
 out=gpurun_out/${tag}_ab.txt; : > $out

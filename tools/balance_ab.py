@@ -30,15 +30,8 @@ def batch(kind):
 
 
 def make_ctx(balance):
-    saved = os.environ.get("MISIFT_BALANCE")
-    os.environ["MISIFT_BALANCE"] = "1" if balance else "0"
-    try:
-        c = capi.Context(0)
-    finally:
-        if saved is None:
-            del os.environ["MISIFT_BALANCE"]
-        else:
-            os.environ["MISIFT_BALANCE"] = saved
+    c = capi.Context(0)
+    c.set_knob("balance", 1 if balance else 0)
     c.set_options(quiet=1, fused=1)
     return c
 

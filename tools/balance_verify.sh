@@ -2,6 +2,7 @@
 # What had to be green before MISIFT_BALANCE became the default (r05: profiles/r05_balance_default_ab.txt): the whole GPU suite with
 # every context of the session balanced, the A/B of tools/balance_ab.py, and the default bench line both ways.
 #   gpurun --timeout 1500 -- 'bash tools/balance_verify.sh'   -> gpurun_out/balance_*.{log,txt,json}
+export MISIFT_TUNABLES=1      # the library reads its launch-shape / path variables only under this switch
 export TMPDIR=/tmp; mkdir -p gpurun_out
 MISIFT_BALANCE=1 timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/balance_pytest_gpu.log 2>&1
 grep -E "passed|failed|error" gpurun_out/balance_pytest_gpu.log | tail -3

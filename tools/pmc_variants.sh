@@ -1,6 +1,7 @@
 #!/bin/bash
 # Developer aid (GPU box): the SQ counters that say what bounds the kernels, for several libmisift.so builds.
 #   tools/pmc_variants.sh <tag> "" build/variants/libmisift_x.so ...   -> gpurun_out/<tag>_<name>.csv (+ kernel durations)
+export MISIFT_TUNABLES=1      # the library reads its launch-shape / path variables only under this switch
 tag=$1; shift
 for lib in "$@"; do
   name=$(basename "${lib:-intree}" .so); name=${name#libmisift_}

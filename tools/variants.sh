@@ -2,6 +2,7 @@
 # Developer aid: build A/B variants of libmisift.so that differ in -D macros of ONE source file.
 #   tools/variants.sh kernels_points.hip name1 "-DDESCR_OCC=3" name2 "-DDESCR_OCC=2" ...
 # -> build/variants/libmisift_<name>.so ; select at run time with MISIFT_LIB=<path>.
+export MISIFT_TUNABLES=1      # the library reads its launch-shape / path variables only under this switch
 set -e
 cd "$(dirname "$0")/.."
 make -s -j cudasift_amd/libmisift.so >/dev/null
