@@ -352,6 +352,9 @@ struct misift_ctx {
   PendingBig pending_big;
   unsigned *d_refcap;           // options.reference_cap: 240-bit extremum masks of the reference's 30 x 8 blocks (launch_refcap)
   size_t refcap_bytes;
+  unsigned *d_capcnt;           // ... on the fused path: byte counters of true extrema per block (launch_refine_all)
+  size_t capcnt_bytes;
+  int refcap_limit;             // extrema a block may hold before its frame is redone with the cap applied (32; test knob)
   void *d_match_tmp;            // matcher partial results
   size_t match_tmp_bytes;
   int num_cus;

@@ -1212,9 +1212,10 @@ __device__ __forceinline__ float det_exp2(float x)
 struct Refined { float xpos, ypos, scale, sharpness, edgeness; };
 __device__ __forceinline__ bool refine_math(const float (&d)[3][3][3], int x, int y, int s, float thresh,
                                             float edge_limit, float factor, float lowest_scale,
-                                            const float (&scmul)[NUM_SCALES], Refined &out)
+                                            const float (&scmul)[NUM_SCALES], Refined &out, bool *extremum = nullptr)
 {
   const float val = d[1][1][1];
+  if (extremum) *extremum = false;
   {
     // candidates are interior pixels, so the reference's clamped neighbour addressing never applies here
     float minv = INFINITY, maxv = -INFINITY;
@@ -1229,6 +1230,7 @@ __device__ __forceinline__ bool refine_math(const float (&d)[3][3][3], int x, in
             maxv = fmaxf(maxv, d[p][dy][dx]);
           }
     if (!((val < fminf(-thresh, minv)) || (val > fmaxf(thresh, maxv)))) return false;
+    if (extremum) *extremum = true;      // what the reference's 32-per-block cap counts (cudaSiftD.cu:1354-1377)
   }
   const float dxx = 2.0f * val - d[1][1][0] - d[1][1][2];
   const float dyy = 2.0f * val - d[1][0][1] - d[1][2][1];
@@ -1340,6 +1342,9 @@ __global__ __launch_bounds__(64) void refine_kernel(const float *__restrict__ sr
   }
 }
 
+#define REFCAP_W 30               // a block of FindPointsMultiNew: MINMAX_W x MINMAX_H pixels of one scale (cudaSiftD.h)
+#define REFCAP_H 8
+#define REFCAP_WORDS 8            // 240 bits per block
 // Merged-octave refine: all candidates of all octaves of a frame in one launch; survivors go to the
 // per-octave staging area as Detection records (orient_all_kernel / descr_all_kernel take it from there).
 struct RefineAllParams {
@@ -1347,6 +1352,14 @@ struct RefineAllParams {
   float scmul[NUM_SCALES];
   int max_pts;
   unsigned cand_stride;
+  // options.reference_cap on the fused path (r06): byte counters of TRUE extrema per (octave, scale, 30 x 8 block), four to
+  // a word; a block that reaches a 33rd extremum raises the frame's CNT_CANDOVF and the callers redo that frame on the
+  // dense kernels, which apply the cap in the reference's order (launch_refcap) — frames in which no block reaches it
+  // (every natural image) ARE the reference's result as they stand.  cap_words = 0: off.
+  unsigned cap_words;                               // words per frame
+  unsigned cap_limit;                               // 32 (MEMWID)
+  unsigned cap_off[MISIFT_MAX_OCTAVES + 1];         // first counter of octave o
+  int cap_tx[MISIFT_MAX_OCTAVES + 1], cap_ty[MISIFT_MAX_OCTAVES + 1];
 };
 // Work decomposition (rocprof: the one-lane-per-candidate version needed 326 VGPRs -> 1 wave/SIMD, and each
 // of its 121 gathers touched 64 different cache lines): SIXTEEN lanes share one candidate, four candidates
@@ -1367,7 +1380,7 @@ __global__ __launch_bounds__(256) void refine_all_kernel(const float *__restrict
                                                          AllTaps taps, RefineAllParams R,
                                                          unsigned *__restrict__ counters,
                                                          const unsigned *__restrict__ cand,
-                                                         Detection *__restrict__ det)
+                                                         Detection *__restrict__ det, unsigned *__restrict__ capcnt)
 {
   const int frame = blockIdx.y;
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
@@ -1445,8 +1458,15 @@ __global__ __launch_bounds__(256) void refine_all_kernel(const float *__restrict
         dd[p][dy][2] = row_dpp<ROW_SHL(1)>(d[p][dy]);
       }
     Refined rr;
+    bool extremum = false;
     const bool ok = live && c == 5 &&
-                    refine_math(dd, x, y, s, R.thresh, R.edge_limit, R.factor, P.o[o].lowest_scale, R.scmul, rr);
+                    refine_math(dd, x, y, s, R.thresh, R.edge_limit, R.factor, P.o[o].lowest_scale, R.scmul, rr, &extremum);
+    if (R.cap_words && live && c == 5 && extremum) {
+      const unsigned idx = R.cap_off[o] + ((unsigned)s * R.cap_ty[o] + (unsigned)(y / REFCAP_H)) * R.cap_tx[o] + (unsigned)(x / REFCAP_W);
+      const unsigned sh = 8u * (idx & 3u);
+      const unsigned old = atomicAdd(&capcnt[(size_t)frame * R.cap_words + (idx >> 2)], 1u << sh);      // (<= 240 per block: no carry)
+      if (((old >> sh) & 0xffu) == R.cap_limit) atomicAdd(&cnt[CNT_CANDOVF], 1u);      // the 33rd: this frame needs the cap applied
+    }
     // Staging slots are handed out per WORKGROUP and octave: the survivors of a round take a rank from an LDS counter
     // and one thread per octave asks the frame's counter for that many slots.  (One atomicAdd-with-return per survivor
     // on the same word serialises at the memory side: ~2000 of them were 17 us of a single frame's 22 us refine, r04.)
@@ -1512,9 +1532,6 @@ int launch_detect(misift_ctx *ctx, const float *dog, const StripGeom &g, long lo
 // (columns), each thread listing its own by row, and only the first MEMWID = 32 are handed on.  Here: every true extremum
 // of the dense detect_kernel sets ITS bit in a 240-bit mask of its block (bit = column * 8 + row: the reference's order),
 // then every one whose rank — the number of set bits below its own — is 32 or more is struck from the candidate list.
-#define REFCAP_W 30
-#define REFCAP_H 8
-#define REFCAP_WORDS 8            // 240 bits per block
 __device__ __forceinline__ void refcap_locate(unsigned code, int tiles_x, int tiles_y, size_t *word0, unsigned *bit)
 {
   const int x = code & 0x3fff, y = (code >> 14) & 0x3fff, s = code >> 28;
@@ -1715,13 +1732,34 @@ int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
   unsigned cand_stride = 0;
   for (int o = 1; o <= P.noct; o++) cand_stride += P.o[o].cand_cap;
   R.cand_stride = cand_stride;
+  R.cap_words = 0;
+  if (ctx->opt.reference_cap) {
+    unsigned n = 0;
+    for (int o = 1; o <= P.noct; o++) {
+      R.cap_off[o] = n;
+      R.cap_tx[o] = (P.o[o].w + REFCAP_W - 1) / REFCAP_W;
+      R.cap_ty[o] = (P.o[o].h + REFCAP_H - 1) / REFCAP_H;
+      n += (unsigned)NUM_SCALES * R.cap_tx[o] * R.cap_ty[o];
+    }
+    R.cap_words = (n + 3u) / 4u;
+    R.cap_limit = (unsigned)ctx->refcap_limit;
+    const size_t bytes = sizeof(unsigned) * (size_t)R.cap_words * P.nframes;
+    if (bytes > ctx->capcnt_bytes) {
+      if (ctx->d_capcnt) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(misift_dev_free(ctx->d_capcnt)); }
+      ctx->d_capcnt = nullptr; ctx->capcnt_bytes = 0;
+      HIP_TRY(misift_dev_alloc((void **)&ctx->d_capcnt, bytes, "refcap_counts"));
+      ctx->capcnt_bytes = bytes;
+      ctx->alloc_gen++;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->d_capcnt, 0, bytes, ctx->stream));
+  }
   const AllTaps at = pack_taps(taps, P.noct);
   LaunchScope ls(ctx, "refine");
   // 16 candidates per workgroup and round: a batch keeps 64 workgroups per frame busy for many rounds; a single frame
   // wants its ~10 k candidates done in one (every round is a dependent chain of 11 loads)
   const int gx = P.nframes <= ctx->small_frames ? 1024 / P.nframes : 64;
   hipLaunchKernelGGL(refine_all_kernel, dim3(gx, P.nframes), dim3(256), 0, ctx->stream, scratch, P, at, R,
-                     ctx->d_counters, ctx->d_cand, ctx->d_det);
+                     ctx->d_counters, ctx->d_cand, ctx->d_det, ctx->d_capcnt);
   return ls.finish();
 }
 

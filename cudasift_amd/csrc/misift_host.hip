@@ -83,7 +83,7 @@ struct PendingProf { int slot; hipEvent_t a, b; };
 // 1000 times, mainSift.cpp:64-69; a tracker calls with the same buffers every frame) replays a captured hipGraph.
 struct CallKey {
   const void *imgs; float *scratch; void *pts;
-  int src_u8, nframes, width, height, pitch, num_octaves, scale_up, max_pts, fused, texfrac, fixnum, determ, alloc_gen;
+  int src_u8, nframes, width, height, pitch, num_octaves, scale_up, max_pts, fused, texfrac, fixnum, determ, refcap, alloc_gen;
   long long frame_stride;
   float init_blur, thresh, lowest_scale;
   // field by field: the struct has padding, and plain assignment need not preserve padding bytes
@@ -92,7 +92,7 @@ struct CallKey {
     return imgs == o.imgs && scratch == o.scratch && pts == o.pts && src_u8 == o.src_u8 && nframes == o.nframes &&
            width == o.width && height == o.height && pitch == o.pitch && num_octaves == o.num_octaves &&
            scale_up == o.scale_up && max_pts == o.max_pts && fused == o.fused && texfrac == o.texfrac &&
-           fixnum == o.fixnum && determ == o.determ && alloc_gen == o.alloc_gen && frame_stride == o.frame_stride &&
+           fixnum == o.fixnum && determ == o.determ && refcap == o.refcap && alloc_gen == o.alloc_gen && frame_stride == o.frame_stride &&
            init_blur == o.init_blur && thresh == o.thresh && lowest_scale == o.lowest_scale;
   }
 };
@@ -335,7 +335,7 @@ static const KnobName KNOBS[] = {
   {"lds_pad_lpd", "MISIFT_LDS_PAD_LPD"}, {"lds_pad_scan", "MISIFT_LDS_PAD_SCAN"}, {"lds_pad_orient", "MISIFT_LDS_PAD_ORIENT"},
   {"lds_pad_descr", "MISIFT_LDS_PAD_DESCR"}, {"lowpass_tile", "MISIFT_LOWPASS_TILE"}, {"strip_rows_small", "MISIFT_STRIP_ROWS_SMALL"},
   {"scan_rows_small_coarse", "MISIFT_SCAN_ROWS_SMALL_COARSE"}, {"scan_rows_small", "MISIFT_SCAN_ROWS_SMALL"},
-  {"host_spin", "MISIFT_HOST_SPIN"},
+  {"host_spin", "MISIFT_HOST_SPIN"}, {"refcap_limit", "MISIFT_TEST_REFCAP_LIMIT"},
 };
 static bool tunables_from_env()
 {
@@ -374,6 +374,7 @@ static int apply_knob(misift_ctx *ctx, const char *name, double v)
   else if (is("scan_rows_small_coarse")) ctx->scan_rows_small_coarse = i > 0 ? i : 2;
   else if (is("scan_rows_small")) ctx->scan_rows_small = i > 0 ? i : 4;
   else if (is("host_spin")) ctx->host_spin = i != 0;
+  else if (is("refcap_limit")) ctx->refcap_limit = i >= 0 && i <= 240 ? i : 32;
   else { misift_set_error("misift_test_set_knob: unknown knob '%s'", name); return MISIFT_EINVAL; }
   return MISIFT_OK;
 }
@@ -428,6 +429,7 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   ctx->balance_frames = 1;       // r05: on by default (full GPU suite + bench A/B both ways: profiles/r05_balance_*); 0 restores per-frame grids
   ctx->fold_descr_tail = 1;
   ctx->patch_reach = 17.9f;                   // = PATCH_REACH of kernels_points.hip: what the LDS window of descr_all covers
+  ctx->refcap_limit = 32;                     // MEMWID of FindPointsMultiNew (tests lower it so that natural frames reach it)
   ctx->lowpass_tile = 1;
   ctx->strip_rows_small = 6;
   // (r04 sweep, profiles/r04_single_call_sweep_step5.txt: fine / coarse rows 9/9 31.0 us, 9/4 25.2, 6/4 23.2, 4/3 21.8, 4/2 21.2, 3/3 22.5)
@@ -654,6 +656,7 @@ extern "C" void misift_ctx_destroy(misift_ctx *ctx)
   if (ctx->d_own_scratch) misift_dev_free(ctx->d_own_scratch);
   if (ctx->d_match_tmp) misift_dev_free(ctx->d_match_tmp);
   if (ctx->d_refcap) misift_dev_free(ctx->d_refcap);
+  if (ctx->d_capcnt) misift_dev_free(ctx->d_capcnt);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
@@ -809,6 +812,31 @@ hipError_t misift_dev_alloc(void **out, size_t bytes, const char *tag)
   *out = base + MISIFT_GUARD_BYTES;
   return hipSuccess;
 }
+// bands of one guarded allocation: 0 = intact, 1 = damaged (the first damage of a process is described in g_guard_first), -1 = copy failed
+static int g_guard_freed_damaged = 0, g_guard_freed_checked = 0;
+static char g_guard_first[256];
+static int guard_check_one(const GuardRec &r)
+{
+  const size_t padded = (r.bytes + 255) / 256 * 256;
+  const size_t rear = padded - r.bytes + MISIFT_GUARD_BYTES;
+  std::vector<unsigned char> host(MISIFT_GUARD_BYTES + rear);
+  if (hipMemcpy(host.data(), r.base, MISIFT_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(host.data() + MISIFT_GUARD_BYTES, r.base + MISIFT_GUARD_BYTES + r.bytes, rear, hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  for (size_t i = 0; i < host.size(); i++)
+    if (host[i] != GUARD_BAND_BYTE) {
+      if (!g_guard_first[0]) {
+        if (i < MISIFT_GUARD_BYTES)
+          snprintf(g_guard_first, sizeof(g_guard_first), "guard band damaged: allocation '%s' (%zu bytes), %zu bytes IN FRONT of the payload",
+                   r.tag, r.bytes, (size_t)MISIFT_GUARD_BYTES - i);
+        else
+          snprintf(g_guard_first, sizeof(g_guard_first), "guard band damaged: allocation '%s' (%zu bytes), %zu bytes BEHIND the payload's end",
+                   r.tag, r.bytes, i - MISIFT_GUARD_BYTES);
+      }
+      return 1;
+    }
+  return 0;
+}
 hipError_t misift_dev_free(void *ptr)
 {
   if (!ptr) return hipSuccess;
@@ -816,6 +844,11 @@ hipError_t misift_dev_free(void *ptr)
     std::lock_guard<std::mutex> lk(g_guard_mu);
     auto it = g_guard_map.find(ptr);
     if (it != g_guard_map.end()) {
+      // a guarded buffer is verified when it goes, too: the caller's images / scratch arenas / record arrays usually live
+      // for one call only and are gone by the time anyone asks misift_test_check_guards
+      (void)hipDeviceSynchronize();
+      g_guard_freed_checked++;
+      if (guard_check_one(it->second) != 0) g_guard_freed_damaged++;
       char *base = it->second.base;
       g_guard_map.erase(it);
       return hipFree(base);
@@ -838,33 +871,16 @@ extern "C" int misift_test_check_guards(int *allocations)
 {
   if (hipDeviceSynchronize() != hipSuccess) { misift_set_error("misift_test_check_guards: hipDeviceSynchronize failed"); return -MISIFT_EHIP; }
   std::lock_guard<std::mutex> lk(g_guard_mu);
-  std::vector<unsigned char> host;
-  int bad = 0, n = 0;
+  int bad = g_guard_freed_damaged, n = g_guard_freed_checked;       // allocations freed since the last check were verified as they went
+  g_guard_freed_damaged = 0; g_guard_freed_checked = 0;
   for (auto &kv : g_guard_map) {
-    const GuardRec &r = kv.second;
-    const size_t padded = (r.bytes + 255) / 256 * 256;
-    const size_t rear = padded - r.bytes + MISIFT_GUARD_BYTES;
-    host.resize(MISIFT_GUARD_BYTES + rear);
-    if (hipMemcpy(host.data(), r.base, MISIFT_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(host.data() + MISIFT_GUARD_BYTES, r.base + MISIFT_GUARD_BYTES + r.bytes, rear, hipMemcpyDeviceToHost) != hipSuccess) {
-      misift_set_error("misift_test_check_guards: copy of the bands of '%s' failed", r.tag);
-      return -MISIFT_EHIP;
-    }
+    const int r = guard_check_one(kv.second);
+    if (r < 0) { misift_set_error("misift_test_check_guards: copy of the bands of '%s' failed", kv.second.tag); return -MISIFT_EHIP; }
     n++;
-    for (size_t i = 0; i < host.size(); i++)
-      if (host[i] != GUARD_BAND_BYTE) {
-        if (bad == 0) {
-          if (i < MISIFT_GUARD_BYTES)
-            misift_set_error("guard band damaged: allocation '%s' (%zu bytes), %zu bytes IN FRONT of the payload", r.tag, r.bytes,
-                             (size_t)MISIFT_GUARD_BYTES - i);
-          else
-            misift_set_error("guard band damaged: allocation '%s' (%zu bytes), %zu bytes BEHIND the payload's end", r.tag, r.bytes,
-                             i - MISIFT_GUARD_BYTES);
-        }
-        bad++;
-        break;
-      }
+    bad += r;
   }
+  if (bad) misift_set_error("%s", g_guard_first);
+  g_guard_first[0] = 0;
   if (allocations) *allocations = n;
   return bad;
 }
@@ -1128,11 +1144,13 @@ struct Level { int w, h, p; float *img; };   // img = frame-0 pointer of that py
 // at any width >= 1.  The merged-octave kernels (tiled prefilter, cone chain, strips sized for whole wavefronts) are
 // built for images that fill at least a strip and never see such calls.  A level that integer division has shrunk to
 // 0 pixels holds nothing and is skipped (CUDA itself refuses a zero-sized grid there).
-// ... and so do calls with options.reference_cap: the cap is defined on the TRUE extrema of a block, which only the dense
-// detect_kernel lists (the fused scan's list holds pre-candidates).
+// (options.reference_cap no longer sends a call here, r06: the fused path counts the true extrema of every 30 x 8 block in
+//  refine_all and only a frame in which a block reaches a 33rd is redone on the dense kernels — the candidate-overflow
+//  mechanism — where launch_refcap applies the cap in the reference's order.)
 static bool dense_call(misift_ctx *ctx, int width, int height, int num_octaves)
 {
-  return misift_tiny_call(width, height, num_octaves) || (ctx && ctx->opt.reference_cap);
+  (void)ctx;
+  return misift_tiny_call(width, height, num_octaves);
 }
 bool misift_tiny_call(int width, int height, int num_octaves)
 {
@@ -1153,8 +1171,8 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
   ARG_CHECK(nframes >= 1 && width >= 1 && height >= 1 && pitch >= width);
   ARG_CHECK(num_octaves >= 1 && num_octaves <= MISIFT_MAX_OCTAVES);       // before the shifts below
   const bool tiny = misift_tiny_call(width, height, num_octaves);
-  // the entry points route tiny calls and calls with the reference's extremum cap to the dense kernels (TinyScope)
-  ARG_CHECK(!((tiny || ctx->opt.reference_cap) && ctx->opt.fused));
+  // the entry points route tiny calls to the dense kernels (TinyScope)
+  ARG_CHECK(!(tiny && ctx->opt.fused));
   ARG_CHECK(max_pts >= 1);
   ARG_CHECK(width * (scale_up ? 2 : 1) < 16384 && height * (scale_up ? 2 : 1) < 16384);
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1575,7 +1593,7 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
       key.imgs = d_imgs; key.scratch = d_scratch; key.pts = pts;
       key.src_u8 = src_u8; key.nframes = nframes; key.width = width; key.height = height; key.pitch = pitch;
       key.num_octaves = num_octaves; key.scale_up = scale_up; key.max_pts = max_pts; key.fused = ctx->opt.fused;
-      key.texfrac = ctx->opt.texfrac_bits; key.fixnum = ctx->opt.fix_numpts; key.determ = ctx->opt.deterministic; key.alloc_gen = ctx->alloc_gen;
+      key.texfrac = ctx->opt.texfrac_bits; key.fixnum = ctx->opt.fix_numpts; key.determ = ctx->opt.deterministic; key.refcap = ctx->opt.reference_cap; key.alloc_gen = ctx->alloc_gen;
       key.frame_stride = frame_stride; key.init_blur = init_blur; key.thresh = thresh; key.lowest_scale = lowest_scale;
       queued = enqueue_via_graph(ctx, key, d_imgs, frame_stride, d_scratch, pts);
     }

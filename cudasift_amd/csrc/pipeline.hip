@@ -248,8 +248,9 @@ extern "C" int misift_pipe_submit(misift_pipe *p, const void *host_frames, int n
   ctx->stream = p->s_compute;
   ctx->split_tail = 0;          // the pipe already overlaps batches on its own streams; the split measured -6 % here
   const int fused_saved = ctx->opt.fused;
-  // the cap is defined on the dense kernels' extremum list (misift.h); tiny frames / deep pyramids run there as well
-  if (ctx->opt.reference_cap || misift_tiny_call(p->width, p->height, p->num_octaves)) ctx->opt.fused = 0;
+  // tiny frames / deep pyramids run on the dense kernels (reference_cap: counted on the fused path, a frame that needs the
+  // cap applied comes back as overflowed and is redone by misift_pipe_collect like any overflowed frame)
+  if (misift_tiny_call(p->width, p->height, p->num_octaves)) ctx->opt.fused = 0;
   int rc = misift_extract_enqueue(ctx, s.d_frames, p->src_u8, nframes, (long long)p->frame_elems, p->width, p->height,
                                   p->width, p->num_octaves, p->init_blur, p->thresh, p->lowest_scale, 0, p->d_scratch,
                                   p->d_pts, p->max_pts);

@@ -40,6 +40,14 @@ static void make_ctx(int dev)
 {
   SAFE(misift_ctx_create(dev, nullptr, &g_ctx));
   SAFE(misift_ctx_set_early_return(g_ctx, 1));
+  // reference-identical by default (r06): the 32-extrema-per-block cap of FindPointsMultiNew (cudaSiftD.cu:1369-1377) is
+  // ON behind this API unless the environment says otherwise — at the fused kernels' speed, see misift.h reference_cap
+  if (!getenv("MISIFT_REFERENCE_CAP")) {
+    misift_options o;
+    SAFE(misift_get_options(g_ctx, &o));
+    o.reference_cap = 1;
+    SAFE(misift_set_options(g_ctx, &o));
+  }
 }
 
 static misift_ctx *ctx()

@@ -73,8 +73,13 @@ typedef struct misift_options {
                             keeps its first 32 extrema (by column, then row) and
                             drops the rest (cudaSiftD.cu:1369-1377; SURVEY
                             Appendix B #4).  Natural images never reach 32 per
-                            240 pixels; calls with the cap run on the dense
-                            per-level kernels (also MISIFT_REFERENCE_CAP=1)    */
+                            240 pixels.  Costs nothing since r06: the fused path
+                            counts the true extrema of every block and only a
+                            frame in which one reaches a 33rd is redone on the
+                            dense per-level kernels, which apply the cap in the
+                            reference's order.  The cudaSift.h shim switches it ON
+                            (reference-identical by default); the C-ABI default is
+                            0 (also MISIFT_REFERENCE_CAP=1)                      */
 } misift_options;
 
 /* ------------------------------------------------------------------ runtime */
@@ -492,8 +497,9 @@ const char *misift_test_knob_names(void);
  * allocation the library makes — misift_malloc for the caller, and its own counters, candidate lists, detection staging,
  * block tables, matcher scratch, pipeline buffers — carries 64 KiB of a byte pattern in front of and behind the payload,
  * and the payload starts out filled with 0xFF (NaN as a float, -1 as an int: nothing may rely on fresh memory being zero).
- * misift_test_check_guards synchronises the device, verifies the bands of every live guarded allocation and returns the
- * number of damaged ones (0 = intact; misift_last_error() names the first), negative on error.  MISIFT_GUARD=1 in the
+ * misift_test_check_guards synchronises the device, verifies the bands of every live guarded allocation — those freed
+ * since the previous check were verified as they were freed — and returns the number of damaged ones (0 = intact;
+ * misift_last_error() names the first), negative on error.  MISIFT_GUARD=1 in the
  * environment switches the mode on from the first allocation.  Allocations made while the mode is off are not guarded. */
 int misift_test_set_guard(int on);                 /* returns the previous mode */
 int misift_test_check_guards(int *allocations);    /* allocations (optional): how many were checked */

@@ -24,6 +24,10 @@ def lib(flavour="off"):
         if not os.path.exists(path):
             _libs[flavour] = None
             return None
+        from oracle.pyoracle import cpu_budget        # team sizes for the CPUs this process may use (cgroup quota)
+        os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+        os.environ.setdefault("SIMT_THREADS", str(min(cpu_budget(), 32)))
         L = C.CDLL(path)
         vp = C.c_void_p
         L.refemul_sizeof_siftpoint.restype = C.c_int

@@ -13,6 +13,30 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _cpu_budget():
+    """CPUs this process may actually use: the GPU boxes show 256 logical CPUs behind a cgroup quota of 16.  The oracle's
+    OpenMP team defaults to one spinning thread per LOGICAL CPU — 256 threads on 16 CPUs' worth of time made every
+    orc.extract call take ~4 s whatever the image (r06: 55 of the 56 s of a tiny-image test; half the GPU suite's time)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+# before liboracle.so / the emulated reference (libgomp) are loaded
+os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_budget()))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("SIMT_THREADS", str(_cpu_budget()))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

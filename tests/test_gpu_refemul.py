@@ -180,9 +180,63 @@ def test_hip_keeps_what_the_reference_cap_drops(ctx):
     record("reference_32_per_block_cap", **counts)
 
 
+def test_reference_cap_at_the_fused_kernels_speed():
+    """options.reference_cap on the FUSED path (r06; r05 sent every such call to the dense kernels at 0.3x the speed):
+    refine_all counts the true extrema of every 30 x 8 block and scale; only a frame in which a block reaches one more than
+    the limit is redone on the dense kernels (where launch_refcap applies the cap in the reference's order).
+      limit 32 (the reference's MEMWID), natural frames: nothing is redone — the fused kernels ran, no dense ones;
+      limit 0 (test knob): every frame with an extremum is flagged and redone on the dense kernels;
+      limit 1, two blobs: redone iff both fall into the SAME block (block = 30 columns x 8 rows, the reference's tiling).
+    Same records as the oracle every time; single call, batch (only the flagged frames are redone) and packed-async."""
+    from cudasift_amd import capi
+    from oracle import pyoracle as orc
+    from util import compare_points
+    frames = np.stack([synth_frame(120 + i, 640, 480) for i in range(3)])
+    want = [orc.extract(f, 4, 1.0, 2.0) for f in frames]
+    for limit, dense_expected in ((32, False), (0, True)):
+        c = capi.Context(0)
+        try:
+            c.set_knob("refcap_limit", limit)
+            c.set_options(reference_cap=1)
+            c.profile_enable(True)
+            got, n, cnt = c.extract(frames[0], num_octaves=4, init_blur=1.0, thresh=2.0)
+            prof = c.profile_read()
+            assert ("laplace" in prof) == dense_expected and "dog_scan" in prof, (limit, sorted(prof))
+            assert n == want[0][1] and np.array_equal(cnt, want[0][2])
+            compare_points(want[0][0][:n], got[:n], "reference_cap_fused_limit%d" % limit, record)
+            bp, bn = c.extract_batch(frames, num_octaves=4, thresh=2.0)[:2]
+            for f in range(3):
+                assert bn[f] == want[f][1]
+                compare_points(want[f][0][:bn[f]], bp[f][:bn[f]], "reference_cap_fused_batch_limit%d_f%d" % (limit, f), record)
+        finally:
+            c.close()
+
+    def blobs(x1, y1, x2, y2):
+        yy, xx = np.mgrid[0:160, 0:240].astype(np.float32)
+        g = lambda x0, y0: 120.0 * np.exp(-((xx - x0) ** 2 + (yy - y0) ** 2) / (2 * 2.2 ** 2))
+        return (20.0 + g(x1, y1) + g(x2, y2)).astype(np.float32)
+    # blocks are [30 k, 30 k + 30) x [8 j, 8 j + 8): (63, 83) and (81, 85) share block (2, 10); (63, 83) and (93, 85) do not
+    for name, img, same in (("same_block", blobs(63, 83, 81, 85), True), ("other_block", blobs(63, 83, 93, 85), False)):
+        ref, rn, rc = orc.extract(img, 1, 1.0, 3.0)
+        assert rn == 2                 # (and exactly two true extrema over the threshold: both blob centres, DoG plane 4)
+        c = capi.Context(0)
+        try:
+            c.set_knob("refcap_limit", 1)
+            c.set_options(reference_cap=1)
+            c.profile_enable(True)
+            got, n, cnt = c.extract(img, num_octaves=1, init_blur=1.0, thresh=3.0)
+            prof = c.profile_read()
+            record("reference_cap_fused/" + name, keypoints=int(n), redone=bool("laplace" in prof))
+            assert n == rn and np.array_equal(cnt, rc)
+            compare_points(ref[:rn], got[:n], "reference_cap_fused_" + name, record)
+            assert ("laplace" in prof) == same, (name, sorted(prof))
+        finally:
+            c.close()
+
+
 def test_reference_cap_option_through_extract(ctx):
-    """options.reference_cap routes ExtractSift through the dense kernels + the cap; on a natural frame no block comes near
-    32 extrema, so the records are the default path's."""
+    """options.reference_cap through ExtractSift; on a natural frame no block comes near 32 extrema, so the records are the
+    default path's."""
     from oracle import pyoracle as orc
     from util import compare_points
     img = synth_frame(120, 640, 480)
