@@ -1799,17 +1799,18 @@ class Bench:
         alone = {n: e.get("alone_ms_per_step", e.get("ms_per_step")) for n, e in k.items() if isinstance(e, dict)}
         if alone and "lowpass_down" in alone and all(v is not None for v in alone.values()):
             tot = sum(alone.values())
-            t1 = tot - alone["lowpass_down"]
-            sd = alone.get("scaledown", 0.0)
-            td["T1"] = {"ms_per_step_one_batch_at_a_time": [round(t1, 4), round(t1 + 4.0 * sd / 1.3125, 4)],
-                        "frames_per_s": [round(self.world * self.B / (t1 + 4.0 * sd / 1.3125) * 1e3, 1), round(self.world * self.B / t1 * 1e3, 1)],
+            lp_share = 8.0 / 13.0          # lowpass_down's algorithmic bytes: LowPass 8 B/px + first ScaleDown 5 B per input px
+            t1_lo = tot - alone["lowpass_down"]
+            t1_hi = tot - lp_share * alone["lowpass_down"]
+            td["T1"] = {"ms_per_step_one_batch_at_a_time": [round(t1_lo, 4), round(t1_hi, 4)],
+                        "frames_per_s": [round(self.world * self.B / t1_hi * 1e3, 1), round(self.world * self.B / t1_lo * 1e3, 1)],
                         "T2_same_basis_ms": round(tot, 4),
                         "what": "the reference's `timer1` scope (cudaSiftH.cu:113-117): everything but the initial LowPass.  Here "
-                                "LowPass and the first ScaleDown are ONE launch (lowpass_down), so T1 is bracketed: summed "
+                                "LowPass and the first ScaleDown are ONE HBM-bound launch (lowpass_down), so T1 is bracketed: summed "
                                 "one-batch-at-a-time launch durations without lowpass_down (the first ScaleDown is missing: a lower "
-                                "bound on the time), and the same plus a first ScaleDown priced at the measured scaledown launches' "
-                                "rate (they process 1/4 + 1/16 + 1/64 of its pixels).  Same basis as T2_same_basis_ms, not as `value` "
-                                "(which overlaps batches)"}
+                                "bound on the time), and the same plus the ScaleDown's 5/13 share of that launch's algorithmic bytes.  "
+                                "Same basis as T2_same_basis_ms — launch durations summed although dog_scan's two launches and the "
+                                "scaledowns overlap — not as `value` (which also overlaps batches)"}
         return td
 
     def leg_config2(self):

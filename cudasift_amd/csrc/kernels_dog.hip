@@ -496,6 +496,9 @@ struct RegTaps {
 #ifndef SCAN_XCH_DPP
 #define SCAN_XCH_DPP 0           // SCAN_XCH: how many of the three scale pairs (the last ones) still use DPP
 #endif
+#ifndef SCAN_PREFETCH
+#define SCAN_PREFETCH 0          // 1 (needs SCAN_XCH: vertical passes first): the ring reads + pair sums of row y+1 are issued
+#endif                           //   between row y's vertical and horizontal passes, into the registers row y's sums just left
 #ifndef SCAN_TAPS_REG
 #define SCAN_TAPS_REG 0          // 1 = the 15 tap pairs live in 30 VGPRs across the row loop instead of being re-read from LDS
 #endif
@@ -605,9 +608,11 @@ __device__ __forceinline__ void scan_queue_finish(const unsigned *wq, unsigned q
   if (qn) scan_queue_store(wq, qn, s_qbase[wave], cnt, list, cand_cap);
 }
 // One row of the scan from the centre row `c` and the four vertical pair sums p1..p4 of its 9-row window.
-template <typename TAPS>
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <typename TAPS, typename MID = NoMid>
 __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx &g, const float4 c, const float4 p1,
-                                         const float4 p2, const float4 p3, const float4 p4, const int y, unsigned &qn)
+                                         const float4 p2, const float4 p3, const float4 p4, const int y, unsigned &qn,
+                                         const MID &mid = MID())
 {
   const bool tester = g.tester;
   const int q = g.q;
@@ -637,6 +642,7 @@ __device__ __forceinline__ void scan_row(const TAPS &taps_src, const ScanRowCtx 
     const Pair4 v2 = vert_pair(taps_src.pair(2), c, p1, p2, p3, p4);
     if (SCAN_XCH_DPP < 2) n1 = xch_get(g.xch);
     if (SCAN_XCH_DPP < 1) { xch_put(g.xch, v2); n2 = xch_get(g.xch); }
+    mid();                              // c, p1..p4 are dead from here on: the caller may fetch the next row's window (SCAN_PREFETCH)
     if (SCAN_XCH_DPP >= 3) n0 = dpp_get(v0);
     b0 = horiz_pair(taps_src.pair(0), v0, n0);
     if (SCAN_XCH_DPP >= 2) n1 = dpp_get(v1);
@@ -869,6 +875,28 @@ __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int
 #pragma unroll
   for (int k = 0; k < RING_ROWS; k++) mine[k * 64] = ld(y0 - 4 + k);          // slot k = row y0 - 4 + k
   float4 n = ld(y0 + 5);                                                      // one row ahead, in registers
+#if SCAN_PREFETCH
+  // window sums of the row about to be computed (formed during the PREVIOUS row, see below)
+  float4 wc = mine[4 * 64], w1 = add4p(mine[3 * 64], mine[5 * 64]), w2 = add4p(mine[2 * 64], mine[6 * 64]),
+         w3 = add4p(mine[1 * 64], mine[7 * 64]), w4 = add4p(mine[0], mine[8 * 64]);
+  // one row: o0..o8 = slots (in float4 units) of rows y-4 .. y+4.  Row y's sums are in wc, w1..w4 already; slot o0 (row
+  // y-4, consumed when they were formed) takes row y+5 at once, and the sums of row y+1 — slots o1..o8 and o0 — are
+  // fetched in the middle of this row, when the vertical passes have released wc, w1..w4.
+  auto row = [&](const int o0, const int o1, const int o2, const int o3, const int o4, const int o5, const int o6,
+                 const int o7, const int o8, const int y) __attribute__((always_inline)) {
+    (void)o4;
+    mine[o0] = n;
+    n = ld(y + 6);
+    const float4 c = wc, p1 = w1, p2 = w2, p3 = w3, p4 = w4;
+    scan_row(taps_src, rc, c, p1, p2, p3, p4, y, qn, [&]() __attribute__((always_inline)) {
+      wc = mine[o5];
+      w1 = add4p(mine[o4], mine[o6]);
+      w2 = add4p(mine[o3], mine[o7]);
+      w3 = add4p(mine[o2], mine[o8]);
+      w4 = add4p(mine[o1], mine[o0]);
+    });
+  };
+#else
   // one row: o0..o8 = slots (in float4 units) of rows y-4 .. y+4
   auto row = [&](const int o0, const int o1, const int o2, const int o3, const int o4, const int o5, const int o6,
                  const int o7, const int o8, const int y) __attribute__((always_inline)) {
@@ -880,6 +908,7 @@ __device__ __forceinline__ void scan_strip_ring(const float *img, int width, int
     mine[o0] = n;                              // row y+5 (loaded one row ago) takes the slot of row y-4,
     n = ld(y + 6);                             // then ITS registers take the next prefetch: no second set, no copies
   };
+#endif
 #define RING_SLOT(J, K) ((((J) + (K)) % RING_ROWS) * 64)
 #define RING_STEP(J)                                                                                                  \
   row(RING_SLOT(J, 0), RING_SLOT(J, 1), RING_SLOT(J, 2), RING_SLOT(J, 3), RING_SLOT(J, 4), RING_SLOT(J, 5),            \
@@ -915,7 +944,7 @@ __global__ __launch_bounds__(256, OCC) void dog_scan_kernel(const float *__restr
   __shared__ unsigned s_cq[WAVES_PER_BLOCK][CQ_CAP];
   if (threadIdx.x < NUM_SCAN_PAIRS * 5) s_taps[threadIdx.x] = scan_pair_tap(taps, threadIdx.x);
   float4 *xch = nullptr;
-#if SCAN_XCH
+#if SCAN_XCH && SCAN_XCH_DPP < 3
   __shared__ float4 s_xch[WAVES_PER_BLOCK][XCH_FLOAT4S];
   {
     const int w_ = threadIdx.x >> 6, l_ = threadIdx.x & 63;
@@ -1001,7 +1030,7 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   // (register window: the embedded chain gets an LDS area of its own in the CHAIN instantiations)
   __shared__ float s_chain_lds[CHAIN ? CHAIN_LDS_FLOATS_EMBED : 4];
 #endif
-#if SCAN_XCH
+#if SCAN_XCH && SCAN_XCH_DPP < 3
   __shared__ float4 s_xch[WAVES_PER_BLOCK][XCH_FLOAT4S];
 #endif
   // no XCD remap here: items of different levels cost differently, and the hardware's round-robin
@@ -1011,7 +1040,7 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
   const int lane = threadIdx.x & 63;
   bool chain_failed = false;
   float4 *xch = nullptr;
-#if SCAN_XCH
+#if SCAN_XCH && SCAN_XCH_DPP < 3
   if (lane < 4) s_xch[wave][(lane >> 1) * XCH_PLANE + (lane & 1) * (XCH_PLANE - 1)] = make_float4(0.f, 0.f, 0.f, 0.f);
   xch = &s_xch[wave][lane];
 #endif

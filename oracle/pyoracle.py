@@ -244,11 +244,12 @@ def descriptor_bounds(img, pts, n, num_octaves=5, init_blur=1.0, ulps=3.0, dthet
     return bound, flips, wraps
 
 
-def descriptor_explain(img, pts, targets, target_orient=None, num_octaves=5, init_blur=1.0, ulps=3.0, scale_up=False,
+def descriptor_explain(img, pts, targets, target_recs=None, num_octaves=5, init_blur=1.0, ulps=3.0, scale_up=False,
                        coord_scale=None, tol=1e-5, max_flips=48):
     """orc_descriptor_explains: for each record, search for the set of tie-weight roundings / seam decisions that turns
-    this side's descriptor (sampled on the grid of the OTHER side's orientation, target_orient) into `targets` (the other
-    side's descriptor).  Returns (residual[n], overrides used[n], candidates[n])."""
+    this side's descriptor — sampled on the OTHER side's grid: position, scale and orientation of target_recs (structured
+    records, or an array of orientations only) — into `targets` (the other side's descriptor).
+    Returns (residual[n], overrides used[n], candidates[n])."""
     img = _f32(img)
     h, w = img.shape
     n = len(pts)
@@ -258,10 +259,18 @@ def descriptor_explain(img, pts, targets, target_orient=None, num_octaves=5, ini
     nset, ncand = np.zeros(n, np.int32), np.zeros(n, np.int32)
     L = lib()
     L.orc_descriptor_explains.restype = None
-    to = None if target_orient is None else np.ascontiguousarray(target_orient, np.float32)
+    geom = None
+    if target_recs is not None:
+        geom = np.zeros((n, 4), np.float32)
+        if getattr(target_recs, "dtype", None) is not None and target_recs.dtype.names:
+            for k, f in enumerate(("xpos", "ypos", "scale", "orientation")):
+                geom[:, k] = target_recs[f]
+        else:                                             # orientations only: our own position and scale
+            geom[:, 0], geom[:, 1], geom[:, 2] = pts["xpos"], pts["ypos"], pts["scale"]
+            geom[:, 3] = np.asarray(target_recs, np.float32)
     cs = None if coord_scale is None else np.ascontiguousarray(coord_scale, np.float32)
     L.orc_descriptor_explains(_p(img), w, h, w, num_octaves, C.c_float(init_blur), int(bool(scale_up)), _p(pts), n,
-                              None if cs is None else _p(cs), _p(targets), None if to is None else _p(to),
+                              None if cs is None else _p(cs), _p(targets), None if geom is None else _p(geom),
                               C.c_float(ulps), C.c_float(tol), int(max_flips), _p(res), _p(nset), _p(ncand))
     return res, nset, ncand
 

@@ -1025,11 +1025,11 @@ void orc_descriptor_bounds(const float *img, int width, int height, int pitch, i
 }
 float orc_descriptor_explain(const float *img, int w, int h, int pitch, const SiftPoint *p, const float *target,
                              float ulps, float extra, float tol, int max_flips, int *nset, int *ncand);
-/* targets[n][128], target_orient[n]: the other side's descriptors and orientations; residual[n] = max |difference| the search leaves, nset / ncand: overrides
+/* targets[n][128], target_geom[n][4]: the other side's descriptors and {xpos, ypos, scale, orientation}; residual[n] = max |difference| the search leaves, nset / ncand: overrides
  * used / candidates per record */
 void orc_descriptor_explains(const float *img, int width, int height, int pitch, int numOctaves, float initBlur, int scaleUp,
                              const SiftPoint *pts, int n, const float *coord_scale, const float *targets,
-                             const float *target_orient, float ulps, float tol, int max_flips, float *residual, int *nset,
+                             const float *target_geom, float ulps, float tol, int max_flips, float *residual, int *nset,
                              int *ncand)
 {
   float *lev[16];
@@ -1039,9 +1039,17 @@ void orc_descriptor_explains(const float *img, int width, int height, int pitch,
   for (int i = 0; i < n; i++) {
     int k;
     SiftPoint q = level_record(pts, i, coord_scale, numOctaves, &k);
-    /* the other side sampled ITS grid: turned by its own orientation (the two may differ by a few ulp of libm vs the
-     * written-out atan2 in the histogram peak) — no allowance needed, the angle is known */
-    if (target_orient) q.orientation = target_orient[i];
+    /* the other side sampled ITS grid: centred on its own position, spaced by its own scale, turned by its own orientation
+     * (each may differ from ours in the last bits: libm vs the written-out exp2 / atan2, contraction of the refinement) —
+     * no allowance needed, they are known: target_geom[i] = {xpos, ypos, scale, orientation} of the other record */
+    if (target_geom) {
+      SiftPoint t = pts[i];
+      t.xpos = target_geom[4 * i + 0]; t.ypos = target_geom[4 * i + 1]; t.scale = target_geom[4 * i + 2];
+      int k2;
+      const SiftPoint tq = level_record(&t, 0, coord_scale ? &coord_scale[i] : NULL, numOctaves, &k2);
+      q.xpos = tq.xpos; q.ypos = tq.ypos; q.scale = tq.scale;
+      q.orientation = target_geom[4 * i + 3];
+    }
     residual[i] = orc_descriptor_explain(lev[k], lw[k], lh[k], lp[k], &q, targets + (size_t)128 * i, ulps, 0.0f, tol, max_flips,
                                          nset ? &nset[i] : NULL, ncand ? &ncand[i] : NULL);
   }

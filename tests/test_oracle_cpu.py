@@ -619,7 +619,7 @@ def test_descriptor_explanation_accepts_ties_and_rejects_anything_else(stereo):
     a, b = A[ia], p23[:n23][ib]
     sel = np.where(np.abs(a["data"] - b["data"]).max(axis=1) > 1e-4)[0][:40]
     assert len(sel) >= 20
-    res, _, _ = orc.descriptor_explain(img, a[sel], b["data"][sel], b["orientation"][sel], 4, 1.0, ulps=util.EXPLAIN_ULPS,
+    res, _, _ = orc.descriptor_explain(img, a[sel], b["data"][sel], b[sel], 4, 1.0, ulps=util.EXPLAIN_ULPS,
                                        tol=util.EXPLAIN_TOL)
     assert res.min() > util.EXPLAIN_PARTIAL, res.min()
     rng = np.random.default_rng(1)

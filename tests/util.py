@@ -158,7 +158,7 @@ def descriptor_tail_bound(img, recs_a, recs_b, noct, init_blur, scale_up=False, 
     somewhere (north_star's tolerance):
 
     1. EXPLANATION (r06, the tight form).  oracle.descriptor_explain() samples this side's record on the OTHER side's grid
-       (its orientation) and searches for the few 8-bit texture weights on a rounding tie (within EXPLAIN_ULPS ulp of the
+       (its position, scale and orientation: each may differ in the last bits) and searches for the few 8-bit texture weights on a rounding tie (within EXPLAIN_ULPS ulp of the
        coordinate) and seam samples (angi = 8 <-> 0, Appendix B #6) whose other rounding REPRODUCES the other side's
        descriptor: residual <= EXPLAIN_TOL (1e-5) for all but a budgeted few, <= EXPLAIN_PARTIAL for every one.  The
        typical record needs ONE toggle and ends at 1e-7.  A difference of any other origin leaves its residual and fails.
@@ -175,9 +175,9 @@ def descriptor_tail_bound(img, recs_a, recs_b, noct, init_blur, scale_up=False, 
         return 0, 0.0, 0, 0.0
     cs = None if coord_scale is None else np.asarray(coord_scale, np.float32)[big]
     kw = dict(num_octaves=noct, init_blur=init_blur, scale_up=scale_up, coord_scale=cs)
-    selfres, _, _ = orc.descriptor_explain(img, recs_a[big], recs_a["data"][big], recs_a["orientation"][big], ulps=0.0, tol=1.0, **kw)
+    selfres, _, _ = orc.descriptor_explain(img, recs_a[big], recs_a["data"][big], recs_a[big], ulps=0.0, tol=1.0, **kw)
     assert selfres.max() <= 2e-6, ("the explanation model does not reproduce this side's own descriptors", float(selfres.max()))
-    res, nset, ncand = orc.descriptor_explain(img, recs_a[big], recs_b["data"][big], recs_b["orientation"][big],
+    res, nset, ncand = orc.descriptor_explain(img, recs_a[big], recs_b["data"][big], recs_b[big],
                                               ulps=EXPLAIN_ULPS, tol=EXPLAIN_TOL, **kw)
     partly = np.where(res > EXPLAIN_TOL)[0]
     info = [{"xpos": float(recs_a["xpos"][big[j]]), "ypos": float(recs_a["ypos"][big[j]]), "diff": float(dd[big[j]].max()),

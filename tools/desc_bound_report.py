@@ -54,7 +54,7 @@ for name, img, noct, th in cases:
         r = (dd[big] / (bound + util.BOUND_SLACK)).max(axis=1)
         ratios += r.tolist()
         # the tight form (r06): the reference's descriptor REPRODUCED by flipping a few tie weights / seam decisions
-        res, nset, ncand = orc.descriptor_explain(img, A[big], B["data"][big], B["orientation"][big], noct, 1.0,
+        res, nset, ncand = orc.descriptor_explain(img, A[big], B["data"][big], B[big], noct, 1.0,
                                                   ulps=util.EXPLAIN_ULPS, tol=util.EXPLAIN_TOL)
         residuals += res.tolist(); toggles += nset.tolist()
         tot["explained"] += int((res <= util.EXPLAIN_TOL).sum()); tot["unexplained"] += int((res > util.EXPLAIN_TOL).sum())

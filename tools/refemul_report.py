@@ -53,7 +53,7 @@ def stats(o_pts, o_cnt, r_pts, r_cnt, noct, img=None, init_blur=1.0, scale_up=Fa
             if scale_up:         # records below numPts were halved by RescalePositions (cudaSiftD.cu:753-761)
                 cs = np.where(np.asarray(ia)[ok][big] < int(o_cnt[2 * noct]), 2.0, 1.0).astype(np.float32)
             # the tight form (r06): the other side's descriptor reproduced by flipping a few tie weights / seam decisions
-            res, nset, _ = orc.descriptor_explain(img, Ab, Bb["data"], Bb["orientation"], noct, init_blur, ulps=util.EXPLAIN_ULPS,
+            res, nset, _ = orc.descriptor_explain(img, Ab, Bb["data"], Bb, noct, init_blur, ulps=util.EXPLAIN_ULPS,
                                                   scale_up=scale_up, coord_scale=cs, tol=util.EXPLAIN_TOL)
             st["desc_explained"] = int((res <= util.EXPLAIN_TOL).sum())
             st["desc_partly_explained"] = int(((res > util.EXPLAIN_TOL) & (res <= util.EXPLAIN_PARTIAL)).sum())

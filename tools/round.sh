@@ -28,6 +28,8 @@ if [ -z "$quick" ]; then
   MATCH_REPS=8 python tools/match_prof.py | tail -1 | tee gpurun_out/${tag}_match_plain.txt
   (cd /tmp && rm -rf /tmp/mt && rocprofv3 --kernel-trace --stats -d /tmp/mt -o m --output-format csv -- python $root/tools/match_prof.py > /dev/null 2>&1); find /tmp/mt -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_match_kernel_stats.csv \;
   head -3 gpurun_out/${tag}_match_kernel_stats.csv
+  (cd /tmp && rm -rf /tmp/mp && MATCH_REPS=2 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA -d /tmp/mp -o m --output-format csv -- python $root/tools/match_prof.py > /dev/null 2>&1)
+  python tools/pmc_sq.py /tmp/mp > gpurun_out/${tag}_match_pmc.csv; cat gpurun_out/${tag}_match_pmc.csv | grep -v rocclr
   bash tools/single_call.sh $tag 200 > /dev/null 2>&1; cat gpurun_out/${tag}_single_call_wall.jsonl
   timeout 300 python bench.py --selftest-dist --steps 20 --warmup 5 --no-pmc --no-match --no-pcie --no-latency > gpurun_out/${tag}_selftest_dist.json 2> gpurun_out/${tag}_selftest_dist.err; echo "selftest-dist rc=$?"
   timeout 600 python bench.py --emulate-ranks 8 > gpurun_out/${tag}_emulate_ranks8.json 2> gpurun_out/${tag}_emulate_ranks8.err; echo "emulate rc=$?"
