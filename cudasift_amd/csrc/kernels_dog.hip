@@ -995,6 +995,10 @@ struct ScanAllGeom {
   unsigned wait_ticks;                        // CHAIN: the wait gives up after this many ticks of the 100 MHz wall clock
   long long frame_stride, total_items;
   unsigned cand_stride;                       // candidate words per frame (all octaves)
+  // options.reference_cap: refine_all's per-block extremum counters, cleared HERE (grid-stride, a few words per workgroup)
+  // instead of by a hipMemsetAsync of their own — two more dispatches on the single call's critical path, +10 us (r06)
+  unsigned *cap_clear;
+  unsigned cap_clear_words;
   ScanOct o[MISIFT_MAX_OCTAVES];              // o[0] = finest level: the long items are dispatched first
 };
 
@@ -1033,6 +1037,8 @@ __global__ __launch_bounds__(256, SCAN_OCC) void dog_scan_all_kernel(const float
 #if SCAN_XCH && SCAN_XCH_DPP < 3
   __shared__ float4 s_xch[WAVES_PER_BLOCK][XCH_FLOAT4S];
 #endif
+  if (G.cap_clear_words)
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < G.cap_clear_words; i += gridDim.x * 256u) G.cap_clear[i] = 0u;
   // no XCD remap here: items of different levels cost differently, and the hardware's round-robin
   // block -> XCD placement is what keeps the eight XCDs evenly loaded across the level boundaries
   unsigned lb = blockIdx.x;
@@ -1667,6 +1673,35 @@ static AllTaps pack_taps(const LaplaceTaps *taps, int noct)
   return a;
 }
 
+// options.reference_cap on the fused path: layout of the per-block extremum counters (bytes, four to a word) and their buffer
+struct CapLayout { unsigned words; unsigned off[MISIFT_MAX_OCTAVES + 1]; int tx[MISIFT_MAX_OCTAVES + 1], ty[MISIFT_MAX_OCTAVES + 1]; };
+static CapLayout cap_layout(const PyramidInfo &P)
+{
+  CapLayout L;
+  memset(&L, 0, sizeof(L));
+  unsigned n = 0;
+  for (int o = 1; o <= P.noct; o++) {
+    L.off[o] = n;
+    L.tx[o] = (P.o[o].w + REFCAP_W - 1) / REFCAP_W;
+    L.ty[o] = (P.o[o].h + REFCAP_H - 1) / REFCAP_H;
+    n += (unsigned)NUM_SCALES * L.tx[o] * L.ty[o];
+  }
+  L.words = (n + 3u) / 4u;
+  return L;
+}
+static int ensure_capcnt(misift_ctx *ctx, const PyramidInfo &P, const CapLayout &L)
+{
+  const size_t bytes = sizeof(unsigned) * (size_t)L.words * P.nframes;
+  if (bytes > ctx->capcnt_bytes) {
+    if (ctx->d_capcnt) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(misift_dev_free(ctx->d_capcnt)); }
+    ctx->d_capcnt = nullptr; ctx->capcnt_bytes = 0;
+    HIP_TRY(misift_dev_alloc((void **)&ctx->d_capcnt, bytes, "refcap_counts"));
+    ctx->capcnt_bytes = bytes;
+    ctx->alloc_gen++;
+  }
+  return MISIFT_OK;
+}
+
 // lev_begin..lev_end: pyramid levels to scan, 0 = finest (all levels: 0, P.noct)
 int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, const LaplaceTaps *taps,
                         float thresh, int lev_begin, int lev_end, const ChainGeom *chain, const float *k5)
@@ -1719,6 +1754,13 @@ int launch_dog_scan_all(misift_ctx *ctx, const float *scratch, const PyramidInfo
     if ((L.w & 3) != 0) ragged = true;          // some level's width is not a multiple of 4 (e.g. 1000 -> 250 -> 125)
   }
   G.total_items = items;
+  if (ctx->opt.reference_cap && lev_begin == 0) {        // the launch that holds the finest level clears refine_all's counters
+    const CapLayout L = cap_layout(P);
+    const int rc = ensure_capcnt(ctx, P, L);
+    if (rc) return rc;
+    G.cap_clear = ctx->d_capcnt;
+    G.cap_clear_words = L.words * (unsigned)P.nframes;
+  }
   const AllTaps at = pack_taps(taps, P.noct);
   ChainGeom C;
   Taps5 t5;
@@ -1762,25 +1804,13 @@ int launch_refine_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &
   for (int o = 1; o <= P.noct; o++) cand_stride += P.o[o].cand_cap;
   R.cand_stride = cand_stride;
   R.cap_words = 0;
-  if (ctx->opt.reference_cap) {
-    unsigned n = 0;
-    for (int o = 1; o <= P.noct; o++) {
-      R.cap_off[o] = n;
-      R.cap_tx[o] = (P.o[o].w + REFCAP_W - 1) / REFCAP_W;
-      R.cap_ty[o] = (P.o[o].h + REFCAP_H - 1) / REFCAP_H;
-      n += (unsigned)NUM_SCALES * R.cap_tx[o] * R.cap_ty[o];
-    }
-    R.cap_words = (n + 3u) / 4u;
+  if (ctx->opt.reference_cap) {                    // (cleared by the scan launch that ran before: launch_dog_scan_all)
+    const CapLayout L = cap_layout(P);
+    const int rc = ensure_capcnt(ctx, P, L);
+    if (rc) return rc;
+    for (int o = 1; o <= P.noct; o++) { R.cap_off[o] = L.off[o]; R.cap_tx[o] = L.tx[o]; R.cap_ty[o] = L.ty[o]; }
+    R.cap_words = L.words;
     R.cap_limit = (unsigned)ctx->refcap_limit;
-    const size_t bytes = sizeof(unsigned) * (size_t)R.cap_words * P.nframes;
-    if (bytes > ctx->capcnt_bytes) {
-      if (ctx->d_capcnt) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(misift_dev_free(ctx->d_capcnt)); }
-      ctx->d_capcnt = nullptr; ctx->capcnt_bytes = 0;
-      HIP_TRY(misift_dev_alloc((void **)&ctx->d_capcnt, bytes, "refcap_counts"));
-      ctx->capcnt_bytes = bytes;
-      ctx->alloc_gen++;
-    }
-    HIP_TRY(hipMemsetAsync(ctx->d_capcnt, 0, bytes, ctx->stream));
   }
   const AllTaps at = pack_taps(taps, P.noct);
   LaunchScope ls(ctx, "refine");
