@@ -211,6 +211,28 @@ def test_reference_cap_at_the_fused_kernels_speed():
         finally:
             c.close()
 
+    # the host-fed pipeline and the packed-async entry point: a flagged frame comes back as count -1 and is redone
+    c = capi.Context(0)
+    try:
+        c.set_knob("refcap_limit", 0)
+        c.set_options(reference_cap=1)
+        u8 = np.clip(np.rint(frames), 0, 255).astype(np.uint8)
+        want8 = [orc.extract(f.astype(np.float32), 4, 1.0, 2.0, max_pts=8192) for f in u8]
+        pin = capi.PinnedArray(u8.shape, np.uint8)
+        pin.array[...] = u8
+        out = capi.PinnedArray((3 * 8192,), capi.POINT_DTYPE)
+        pipe = capi.Pipe(c, 640, 480, 3, src_u8=True, num_octaves=4, thresh=2.0, max_pts=8192, depth=2)
+        pipe.submit(pin.ptr, 3)
+        counts, nrec = pipe.collect(out.ptr, 3 * 8192)
+        pipe.close()
+        off = 0
+        for f in range(3):
+            assert counts[f] == want8[f][1]
+            compare_points(want8[f][0][:counts[f]], out.array[off:off + counts[f]], "reference_cap_fused_pipe_f%d" % f, record)
+            off += counts[f]
+    finally:
+        c.close()
+
     def blobs(x1, y1, x2, y2):
         yy, xx = np.mgrid[0:160, 0:240].astype(np.float32)
         g = lambda x0, y0: 120.0 * np.exp(-((xx - x0) ** 2 + (yy - y0) ** 2) / (2 * 2.2 ** 2))
