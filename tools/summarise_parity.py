@@ -26,7 +26,8 @@ def parity(src, dst):
         for f, agg in (("pos_relerr_max", max), ("scale_relerr_max", max), ("sharp_relerr_max", max), ("desc_maxabs_all", max),
                        ("desc_max", max), ("orient_maxdiff_deg_all", max), ("orientation_deg", max), ("maxabs", max),
                        ("desc_min_cos", min), ("desc_min_cos_same_orient", min), ("orientation_flips", max),
-                       ("desc_over_1e-4", max), ("desc_over_1e-3", max)):
+                       ("desc_over_1e-4", max), ("desc_over_1e-3", max), ("desc_bound_checked", max), ("desc_explained", max),
+                       ("desc_worst_residual", max), ("allocations_checked", max)):
             if isinstance(v.get(f), (int, float)):
                 e[f] = agg(e[f], v[f]) if f in e else v[f]
     out = {"what": "tests -m gpu: parity report summarised per group of cases (worst value of every statistic over the group); "
