@@ -173,6 +173,39 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
   // ---- B staging: thread -> (column scol + 8j, float4 index f4), j = 0..7
   const int scol = tid >> 5, f4 = tid & 31;
   float4 stage[MT_STAGE];
+#ifndef MT_LEAN_STAGING
+#define MT_LEAN_STAGING 1
+#endif
+#if MT_LEAN_STAGING
+  // r06: the staging costs the SIMD VALU time the matrix pipe does not get back (SQ counters: MFMA busy + VALU issuing ~ 1 of
+  // the launch's SIMD-cycles).  (a) one 32-bit byte offset per thread and load (clamp + v_mad_u32_u24) against a wave-uniform
+  // (SGPR) tile base instead of clamp + 64-bit multiply-add + 64-bit shift-add per load; (b) the even-k / odd-k halves of a staged float4 go to LDS as ds_write2_b32
+  // x,z | y,w — two separate registers each — instead of ds_write2_b64 of register PAIRS the compiler has to assemble with
+  // three v_mov per float4.  24 + 8 of the ~196 non-MFMA VALU instructions per super-tile and wavefront.
+  const unsigned vconst = (unsigned)G.data_off2 * 4u + (unsigned)f4 * 16u;
+  auto gload = [&](int st) {
+    const int c0 = tile_col0(G, st);                                         // wave-uniform
+    const char *sb = reinterpret_cast<const char *>(set2) + (size_t)c0 * (size_t)G.stride2 * 4u;
+    const int last = G.n2 - 1 - c0;                                          // (scalar) the clamp matters in a partial last super-tile only
+#pragma unroll
+    for (int j = 0; j < MT_STAGE; j++) {
+      const unsigned rel = (unsigned)min(scol + 2 * MT_WG_WAVES * j, last);
+      stage[j] = *reinterpret_cast<const float4 *>(sb + (__umul24(rel, (unsigned)G.stride2 * 4u) + vconst));
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < MT_STAGE; j++) {
+      float *d = &Bs[buf][(scol + 2 * MT_WG_WAVES * j) * MT_BSTRIDE + 2 * f4];       // k = 4*f4 .. 4*f4+3
+      const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) float *)d;
+      asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(a), "v"(stage[j].x), "v"(stage[j].z) : "memory");            // even k -> half 0
+      asm volatile("ds_write2_b32 %0, %1, %2 offset0:64 offset1:65" :: "v"(a), "v"(stage[j].y), "v"(stage[j].w) : "memory"); // odd k -> half 1
+    }
+  };
+  // the compiler's wait-count bookkeeping does not see the DS stores issued from inline asm: before a barrier that publishes
+  // them, wait for them by hand
+#define MT_LDS_STORES_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
   auto gload = [&](int st) {
 #pragma unroll
     for (int j = 0; j < MT_STAGE; j++) {
@@ -188,6 +221,8 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
       *reinterpret_cast<float2 *>(d + 64) = make_float2(stage[j].y, stage[j].w);   // odd k  -> half 1
     }
   };
+#define MT_LDS_STORES_DONE() do { } while (0)
+#endif
 
 #ifndef MT_PIPE_EPILOGUE
 #define MT_PIPE_EPILOGUE 1
@@ -219,6 +254,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
 #endif
     lstore(0);
   }
+  MT_LDS_STORES_DONE();
   __syncthreads();
   MT_STAMP_MAX(3);                 // first super-tile staged
 #if MT_PIPE_EPILOGUE
@@ -296,6 +332,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
     lstore(buf ^ 1);
 #endif
 #if !MT_EXP_NOBARRIER
+    MT_LDS_STORES_DONE();
     __syncthreads();
 #endif
   };
@@ -377,6 +414,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
       for (int r = 0; r < 16; r++) top2_update(acc1[r], c1, mx[r], sec[r], ix[r]);
     }
     lstore(buf ^ 1);
+    MT_LDS_STORES_DONE();
     __syncthreads();
   }
 
