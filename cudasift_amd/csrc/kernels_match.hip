@@ -176,6 +176,9 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
 #ifndef MT_LEAN_STAGING
 #define MT_LEAN_STAGING 1
 #endif
+#ifndef MT_TOP2_FILTER
+#define MT_TOP2_FILTER 0
+#endif
 #if MT_LEAN_STAGING
   // r06: the staging costs the SIMD VALU time the matrix pipe does not get back (SQ counters: MFMA busy + VALU issuing ~ 1 of
   // the launch's SIMD-cycles).  (a) one 32-bit byte offset per thread and load (clamp + v_mad_u32_u24) against a wave-uniform
@@ -288,6 +291,29 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
       // four slots of this tile's k-loop, columns 32-63 (chain 1) during the last four; four rows per slot
       {
         const int t4 = 4 * ((i >> 1) & 3);
+#if MT_TOP2_FILTER
+        // r06: a score changes a lane's top two only if it beats the running SECOND best — after a few hundred columns that
+        // is rare (2/n per lane), so the three instructions behind the compare run only when some lane of the wavefront needs
+        // them (wave-uniform branch): on 100 000 columns ~17 % of the row updates.  Exact: a score that is not above `sec`
+        // (or is NaN) leaves (mx, sec, ix) untouched in top2_update as well.
+        if (i < 8) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float sc = prev0[t4 + r];
+            if (__builtin_amdgcn_ballot_w64(do0 && sc > sec[t4 + r]) != 0ull) {
+              if (do0) top2_update(sc, pc0, mx[t4 + r], sec[t4 + r], ix[t4 + r]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float sc = prev1[t4 + r];
+            if (__builtin_amdgcn_ballot_w64(do1 && sc > sec[t4 + r]) != 0ull) {
+              if (do1) top2_update(sc, pc1, mx[t4 + r], sec[t4 + r], ix[t4 + r]);
+            }
+          }
+        }
+#else
         if (i < 8) {
           if (do0) {
 #pragma unroll
@@ -299,6 +325,7 @@ __global__ __launch_bounds__(64 * MT_WG_WAVES, 8 / MT_WG_WAVES) void match_kerne
             for (int r = 0; r < 4; r++) top2_update(prev1[t4 + r], pc1, mx[t4 + r], sec[t4 + r], ix[t4 + r]);
           }
         }
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * i + 2], p0.z, acc0, 0, 0, 0);
