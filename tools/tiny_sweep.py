@@ -2,7 +2,7 @@
 """Every input the reference accepts: N random small shapes (width, height in [1, 48], 1-6 octaves, white noise, low
 thresholds) through misift_extract on the GPU and through the reference's own ExtractSift on the CPU SIMT emulator
 (oracle/_ref, prebuilt) — numPts, the 17 counters (duplicate counters +-1: tests/util.py compare_tiny) and every keypoint.
--> gpurun_out/r05_tiny_sweep.json"""
+-> gpurun_out/r06_tiny_sweep.json"""
 import json
 import os
 import sys
@@ -41,5 +41,5 @@ out = {"shapes": N, "failures": len(bad), "failed": bad[:20], "keypoints_total":
        "smallest": [int(min(s[0] for s in shapes)), int(min(s[1] for s in shapes))],
        "what": "misift_extract (MI355X) vs the emulated reference on random shapes 1..48 x 1..48, 1-6 octaves, 10 % with scaleUp"}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_tiny_sweep.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r06_tiny_sweep.json"), "w"), indent=1)
 print(json.dumps(out)[:1500])
