@@ -385,7 +385,7 @@ struct misift_ctx {
   // dealt out in proportion to the frames' counts through a block -> (frame, sub-block, sub-blocks) table that
   // frame_shares_kernel writes behind refine_all; off: every frame gets the same number of workgroups
   int balance_frames;           // 1 = batches of more than small_frames frames use the table
-  int cur_balanced;             // this call's orient_all built the tables (descr_all uses the second one)
+  int cur_balanced;             // this call's block tables are built: by the extra workgroup of bin_detections, or by frame_shares_kernel (orient_all uses the first, descr_all the second)
   int4 *d_block_map;            // [map_t_orient | map_t_descr] entries
   int block_map_cap, map_t_orient, map_t_descr;
   int want_export, exported;    // host export of the counters by the last kernel: asked for by misift_extract_sync / done

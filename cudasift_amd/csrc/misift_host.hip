@@ -1376,7 +1376,7 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     //  nothing — the keypoints of one frame share the caches anyway)
     const bool binned = (ctx->bin_detections && nframes >= ctx->bin_min_frames) || ctx->opt.deterministic;
     ctx->cur_binned = binned ? 1 : 0;
-    ctx->cur_balanced = 0;              // set by launch_orient_all when it builds the block tables
+    ctx->cur_balanced = 0;              // set by launch_bin_detections (its extra workgroup builds the block tables) or, without binning, by build_block_maps
     if (binned) {                       // spatial order for the per-keypoint kernels (L1/L2 reuse between neighbours);
       rc = launch_bin_detections(ctx, P, max_pts);      // deterministic mode: a total order
       if (rc) return rc;
