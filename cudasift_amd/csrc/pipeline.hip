@@ -206,6 +206,10 @@ extern "C" int misift_pipe_create(misift_ctx *ctx, int width, int height, int ba
   const size_t S = misift_scratch_floats(width, height, num_octaves, 0);
   PIPE_TRY(misift_dev_alloc((void **)&p->d_scratch, sizeof(float) * S * batch_frames, "pipe_scratch"));
   PIPE_TRY(misift_dev_alloc((void **)&p->d_pts, sizeof(SiftPointD) * (size_t)max_pts * batch_frames, "pipe_points"));
+  // ExtractSift does not write a record's match fields (score ... match_error: MatchSiftData's), and the records collected
+  // from this staging array carry them along: start them out as zeros instead of whatever the allocation held (r06: found
+  // by running the suite under MISIFT_GUARD=1, where fresh memory is 0xFF)
+  PIPE_TRY(hipMemset(p->d_pts, 0, sizeof(SiftPointD) * (size_t)max_pts * batch_frames));
   p->slots.resize(depth);
   for (PipeSlot &s : p->slots) memset(&s, 0, sizeof(s));
   const size_t elem = src_u8 ? 1 : sizeof(float);

@@ -71,6 +71,18 @@ def record(name, **kw):
     _DIAG.setdefault(name, {}).update({k: conv(v) for k, v in kw.items()})
 
 
+@pytest.fixture(autouse=True)
+def _guard_bands_intact():
+    """With MISIFT_GUARD=1 in the environment EVERY device allocation of the run is guarded (64 KiB bands, NaN-poisoned payload):
+    the bands are verified after each test (buffers freed meanwhile were verified as they went), so the whole GPU suite doubles as
+    an out-of-bounds check:  MISIFT_GUARD=1 python -m pytest tests -m gpu"""
+    yield
+    if os.environ.get("MISIFT_GUARD") == "1":
+        from cudasift_amd import capi
+        if capi.device_count() >= 1:
+            capi.check_guards()
+
+
 def pytest_sessionfinish(session, exitstatus):
     if _DIAG:
         try:                                   # diagnostics only: never let the report fail a green session
