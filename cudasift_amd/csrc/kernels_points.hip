@@ -959,6 +959,9 @@ __global__ __launch_bounds__(256) void renumber_dups_kernel(PyramidInfo P, const
     if (d[i].dupslot >= 0) d[i].dupslot = run++;
 }
 
+#ifndef ORIENT_FETCH_CONST
+#define ORIENT_FETCH_CONST 0
+#endif
 template <bool Q8>
 __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                          unsigned *__restrict__ counters,
@@ -982,7 +985,11 @@ __global__ __launch_bounds__(256) void orient_all_kernel(const float *__restrict
   auto fetch = [&](const float4 &k, const OctaveInfo &L, float (&T)[4]) {
     const float *img = scratch + (long long)frame * P.frame_stride + L.img_off;
     const bool sane = k.x > -64.0f && k.y > -64.0f && k.x < (float)(L.w + 64) && k.y < (float)(L.h + 64);
+#if ORIENT_FETCH_CONST      // timing experiment only (wrong results): every window is the image's corner, i.e. L2-resident —
+    const int x0 = (sane ? 0 : 1) - 7, y0 = -7;      // the upper bound of what sharing descr_all's window could save here
+#else
     const int x0 = (int)floorf(sane ? k.x : 0.0f) - 7, y0 = (int)floorf(sane ? k.y : 0.0f) - 7;
+#endif
     const unsigned col = (unsigned)clampi(x0 + tc, 0, L.w - 1);
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -1119,6 +1126,46 @@ __device__ __forceinline__ float footprint_sum2(const float *base, const float *
   return acc;
 }
 
+// r06, the default (DESCR_FOOT_LITERAL=1): the same sum with the 64 weights as instruction literals — they are compile-time
+// constants — four rows at a time behind a scheduling barrier (8 b128 loads in flight, like footprint_sum2): no weight reads
+// from LDS at all (16 wave-uniform ds_read_b128 per pass; an LDS instruction holds the issuing SIMD for 5-9 cycles, r06
+// counters).  Same products, same FMA order: bit-identical records.  descr_all 0.321 -> 0.302 ms per 64 x 1080p step,
+// +1.5...2.7 % frames/s (profiles/r06_footlit_ab.txt).
+__device__ __forceinline__ float footprint_sum3(const float *base, float acc)
+{
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int my = 4 * h + r;
+      const float4 lo = *reinterpret_cast<const float4 *>(base + my * SMP_W);
+      const float4 hi = *reinterpret_cast<const float4 *>(base + my * SMP_W + 4);
+      // the literal is part of the instruction (an integer literal in an f32 operand is its bit pattern): written through the
+      // compiler's own fma the 64 constants are hoisted into 64 VGPRs across the orientation loop and the kernel spills
+#define FOOT_FMAC(M, V) asm("v_fmac_f32 %0, %2, %1" : "+v"(acc) : "v"(V), "n"(__builtin_bit_cast(unsigned, spatial_w(my) * spatial_w(M))))
+      FOOT_FMAC(0, lo.x);
+      FOOT_FMAC(1, lo.y);
+      FOOT_FMAC(2, lo.z);
+      FOOT_FMAC(3, lo.w);
+      FOOT_FMAC(4, hi.x);
+      FOOT_FMAC(5, hi.y);
+      FOOT_FMAC(6, hi.z);
+      FOOT_FMAC(7, hi.w);
+#undef FOOT_FMAC
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+#ifndef DESCR_FOOT_LITERAL
+#define DESCR_FOOT_LITERAL 1
+#endif
+#if DESCR_FOOT_LITERAL
+#define FOOTPRINT_SUM(base, wt, acc) footprint_sum3((base), (acc))
+#else
+#define FOOTPRINT_SUM(base, wt, acc) footprint_sum2((base), (wt), (acc))
+#endif
+
 // Votes -> normalised descriptor bins (8*cell + (lane&3)) and (+4).  tbl: FOUR per-bin planes [bin][20][20] over the
 // 16x16 sample grid (2-sample zero border), all zero on entry and on exit; bins 0..3 first, then the same planes are
 // re-used for bins 4..7 (see the comment above SMP_W).  Sample j of this lane sits at plane position pos_j.
@@ -1144,7 +1191,7 @@ __device__ __forceinline__ void descr_accumulate(float *tbl, const float *wt, in
     if (by[j] < 4) tbl[by[j] * SMP_PLANE + pos[j]] = vy[j];
   }
   wave_sync();
-  float acc0 = footprint_sum2(mine, wt, 0.0f);
+  float acc0 = FOOTPRINT_SUM(mine, wt, 0.0f);
   wave_sync();
   // ---- bins 4..7 re-use planes 0..3 (a lane's pass-A and pass-B slots never coincide: different plane or position)
 #pragma unroll
@@ -1155,7 +1202,7 @@ __device__ __forceinline__ void descr_accumulate(float *tbl, const float *wt, in
     if (by[j] >= 4) tbl[(by[j] - 4) * SMP_PLANE + pos[j]] = vy[j];
   }
   wave_sync();
-  float acc1 = footprint_sum2(mine, wt, 0.0f);
+  float acc1 = FOOTPRINT_SUM(mine, wt, 0.0f);
   wave_sync();
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -1173,7 +1220,7 @@ __device__ __forceinline__ void descr_accumulate(float *tbl, const float *wt, in
     wave_sync();
     if ((lane & 3) == 0 && cell >= 1) {
       const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
-      acc0 = footprint_sum2(tbl + (4 * pcy) * SMP_W + 4 * pcx, wt, acc0);
+      acc0 = FOOTPRINT_SUM(tbl + (4 * pcy) * SMP_W + 4 * pcx, wt, acc0);
     }
     wave_sync();
 #pragma unroll
@@ -1243,7 +1290,7 @@ struct alignas(16) DescrWaveLds {
   float buf[PATCH_FLOATS];      // window, then vote table
   float park[12 * 64];          // votes of a first orientation while the second is sampled
   float gauss[16];
-  float wtab[64];               // footprint weights wy(row) * wx(column)
+  float wtab[64];               // footprint weights wy(row) * wx(column) (DESCR_FOOT_LITERAL=0 only)
 };
 template <bool Q8, bool BAL>
 __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch, const PyramidInfo &P,
@@ -1268,7 +1315,7 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   float *buf = s_w[wave].buf;
   const float *gauss = s_w[wave].gauss;
   if (lane < 16) s_w[wave].gauss[lane] = det_exp(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
-  footprint_weights_init(s_w[wave].wtab, lane);
+  if (!DESCR_FOOT_LITERAL) footprint_weights_init(s_w[wave].wtab, lane);
   // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
   if (fs.sub == 0 && threadIdx.x == 0) {                 // publish the reference's counters (cudaSiftD.cu:14)
     unsigned b = 0;                                      // (write-through: a workgroup on another XCD may export them)
