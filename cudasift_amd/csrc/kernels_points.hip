@@ -105,6 +105,9 @@ __device__ __forceinline__ PatchGeom patch_geom(float xpos, float ypos, float ps
 // Texel t = lane + 64*k of the window is (row t / 40, column t % 40); 320 = 8 rows, so k = 5m + j is row r_j + 8m,
 // column c_j with five lane constants (r_j, c_j).  Clamp-to-edge is applied here, once per texel, instead of in every
 // bilinear fetch.  A load instruction covers 64 consecutive texels = 1.6 rows: 4..6 cache lines.
+#ifndef PATCH_LANE_MUL24
+#define PATCH_LANE_MUL24 1
+#endif
 struct PatchLane { int r[5], c[5]; };
 __device__ __forceinline__ PatchLane patch_lane(int lane)
 {
@@ -112,8 +115,16 @@ __device__ __forceinline__ PatchLane patch_lane(int lane)
 #pragma unroll
   for (int j = 0; j < 5; j++) {
     const int t = lane + 64 * j;
+#if PATCH_LANE_MUL24
+    // t / 40 for t < 1600 as a full-rate 24-bit multiply and a shift (1639 / 65536 = 1/40 + 9.2e-6: exact below 2 730); the
+    // compiler's own division by a constant is v_mul_hi_i32 + v_mad_u64_u32, both quarter-rate (r06: 10 per keypoint)
+    static_assert(PW == 40, "1639 / 65536 stands for 1 / 40");
+    pl.r[j] = (int)(__umul24((unsigned)t, 1639u) >> 16);
+    pl.c[j] = __mul24(pl.r[j], -PW) + t;                           // v_mad_i32_i24
+#else
     pl.r[j] = t / PW;
     pl.c[j] = t - pl.r[j] * PW;
+#endif
   }
   return pl;
 }
@@ -1127,34 +1138,33 @@ __device__ __forceinline__ float footprint_sum2(const float *base, const float *
 }
 
 // r06, the default (DESCR_FOOT_LITERAL=1): the same sum with the 64 weights as instruction literals — they are compile-time
-// constants — four rows at a time behind a scheduling barrier (8 b128 loads in flight, like footprint_sum2): no weight reads
-// from LDS at all (16 wave-uniform ds_read_b128 per pass; an LDS instruction holds the issuing SIMD for 5-9 cycles, r06
+// constants: no weight reads from LDS at all (16 wave-uniform ds_read_b128 per pass; an LDS instruction holds the issuing SIMD for 5-9 cycles, r06
 // counters).  Same products, same FMA order: bit-identical records.  descr_all 0.321 -> 0.302 ms per 64 x 1080p step,
 // +1.5...2.7 % frames/s (profiles/r06_footlit_ab.txt).
 __device__ __forceinline__ float footprint_sum3(const float *base, float acc)
 {
+  // the literal is part of the instruction (an integer literal in an f32 operand is its bit pattern): written through the
+  // compiler's own fma the 64 constants are hoisted into 64 VGPRs across the orientation loop and the kernel spills.
+  // One asm statement per half row (the compiler pads every statement with an s_nop); row r + 1 is loaded before row r's
+  // FMAs, pinned by the scheduling barrier — left alone the compiler re-uses the row's eight registers: no load in flight.
+#define FOOT_W(M) "n"(__builtin_bit_cast(unsigned, spatial_w(my) * spatial_w(M)))
+  float4 lo = *reinterpret_cast<const float4 *>(base), hi = *reinterpret_cast<const float4 *>(base + 4);
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int my = 4 * h + r;
-      const float4 lo = *reinterpret_cast<const float4 *>(base + my * SMP_W);
-      const float4 hi = *reinterpret_cast<const float4 *>(base + my * SMP_W + 4);
-      // the literal is part of the instruction (an integer literal in an f32 operand is its bit pattern): written through the
-      // compiler's own fma the 64 constants are hoisted into 64 VGPRs across the orientation loop and the kernel spills
-#define FOOT_FMAC(M, V) asm("v_fmac_f32 %0, %2, %1" : "+v"(acc) : "v"(V), "n"(__builtin_bit_cast(unsigned, spatial_w(my) * spatial_w(M))))
-      FOOT_FMAC(0, lo.x);
-      FOOT_FMAC(1, lo.y);
-      FOOT_FMAC(2, lo.z);
-      FOOT_FMAC(3, lo.w);
-      FOOT_FMAC(4, hi.x);
-      FOOT_FMAC(5, hi.y);
-      FOOT_FMAC(6, hi.z);
-      FOOT_FMAC(7, hi.w);
-#undef FOOT_FMAC
+  for (int my = 0; my < 8; my++) {
+    float4 nlo = lo, nhi = hi;
+    if (my < 7) {
+      nlo = *reinterpret_cast<const float4 *>(base + (my + 1) * SMP_W);
+      nhi = *reinterpret_cast<const float4 *>(base + (my + 1) * SMP_W + 4);
     }
     __builtin_amdgcn_sched_barrier(0);
+    asm("v_fmac_f32 %0, %5, %1\n\tv_fmac_f32 %0, %6, %2\n\tv_fmac_f32 %0, %7, %3\n\tv_fmac_f32 %0, %8, %4"
+        : "+v"(acc) : "v"(lo.x), "v"(lo.y), "v"(lo.z), "v"(lo.w), FOOT_W(0), FOOT_W(1), FOOT_W(2), FOOT_W(3));
+    asm("v_fmac_f32 %0, %5, %1\n\tv_fmac_f32 %0, %6, %2\n\tv_fmac_f32 %0, %7, %3\n\tv_fmac_f32 %0, %8, %4"
+        : "+v"(acc) : "v"(hi.x), "v"(hi.y), "v"(hi.z), "v"(hi.w), FOOT_W(4), FOOT_W(5), FOOT_W(6), FOOT_W(7));
+    __builtin_amdgcn_sched_barrier(0);
+    lo = nlo; hi = nhi;
   }
+#undef FOOT_W
   return acc;
 }
 #ifndef DESCR_FOOT_LITERAL
@@ -1236,6 +1246,81 @@ __device__ __forceinline__ void descr_accumulate(float *tbl, const float *wt, in
   out0 = c0 * rs2;
   out1 = c1 * rs2;
 }
+
+// r06 (DESCR_SCATTER_SELECT): the same accumulation with every vote owning ONE table slot for both passes — plane
+// (bin & 3), its sample's position — written unconditionally three times: the vote or 0 (bins 0..3), 0 or the vote (bins
+// 4..7), 0.  The conditional form above costs, per store, a compare into an SGPR pair, s_and_saveexec, a v_mad_u64_u32 for
+// bin * 400 + position (a quarter-rate instruction: the compiler has no full-rate 32-bit multiply-add), the store and the
+// exec restore — 32 of them per descriptor; here: 8 v_mad_u32_u24 once, 24 stores, 16 selects.  The slots of different
+// votes never coincide (different sample = different position; a sample's two votes = adjacent bins = different planes)
+// except for the angi == 8 vote (plane 0 like its partner's bin 0), which goes to a per-lane dump slot instead.
+// Same table contents in every pass, same footprint sums: bit-identical records.
+__device__ __forceinline__ void descr_accumulate_sel(float *tbl, const int dump, int lane, const float (&vx)[4],
+                                                     const float (&vy)[4], const int (&ang)[4], float &out0, float &out1)
+{
+  const int cell = lane >> 2, cx = cell & 3, cy = cell >> 2;
+  const float *mine = tbl + (lane & 3) * SMP_PLANE + (4 * cy) * SMP_W + 4 * cx;
+  const unsigned pos0 = (unsigned)(((lane >> 4) + 2) * SMP_W + (lane & 15) + 2);       // sample j: + 4 * SMP_W * j
+  unsigned sx[4], sy[4];
+  bool has8 = false;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned bx = (unsigned)ang[j];
+    const unsigned by = ang[j] >= 7 ? 0u : bx + 1u;
+    const unsigned pos = pos0 + 4 * SMP_W * j;
+    sx[j] = ang[j] >= 8 ? (unsigned)dump : __umul24(bx & 3u, SMP_PLANE) + pos;
+    sy[j] = __umul24(by & 3u, SMP_PLANE) + pos;
+    has8 |= ang[j] >= 8;
+  }
+  // ---- bins 0..3
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    tbl[sx[j]] = ang[j] < 4 ? vx[j] : 0.0f;
+    tbl[sy[j]] = (ang[j] < 3 || ang[j] >= 7) ? vy[j] : 0.0f;          // by < 4
+  }
+  wave_sync();
+  float acc0 = FOOTPRINT_SUM(mine, nullptr, 0.0f);
+  wave_sync();
+  // ---- bins 4..7 in the same planes
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    tbl[sx[j]] = ang[j] < 4 ? 0.0f : vx[j];                           // (angi == 8: the dump slot)
+    tbl[sy[j]] = (ang[j] < 3 || ang[j] >= 7) ? 0.0f : vy[j];
+  }
+  wave_sync();
+  float acc1 = FOOTPRINT_SUM(mine, nullptr, 0.0f);
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    tbl[sx[j]] = 0.0f;
+    tbl[sy[j]] = 0.0f;
+  }
+  if (__any(has8)) {                                                  // rare: see descr_accumulate
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (ang[j] >= 8) tbl[pos0 + 4 * SMP_W * j] = vx[j];
+    wave_sync();
+    if ((lane & 3) == 0 && cell >= 1) {
+      const int pc = cell - 1, pcx = pc & 3, pcy = pc >> 2;
+      acc0 = FOOTPRINT_SUM(tbl + (4 * pcy) * SMP_W + 4 * pcx, nullptr, acc0);
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (ang[j] >= 8) tbl[pos0 + 4 * SMP_W * j] = 0.0f;
+  }
+  const float tsum1 = wave_sum(acc0 * acc0 + acc1 * acc1);
+  const float rs1 = 1.0f / sqrtf(tsum1);
+  const float c0 = fminf(acc0 * rs1, 0.2f), c1 = fminf(acc1 * rs1, 0.2f);
+  const float tsum2 = wave_sum(c0 * c0 + c1 * c1);
+  const float rs2 = 1.0f / sqrtf(tsum2);
+  out0 = c0 * rs2;
+  out1 = c1 * rs2;
+}
+#ifndef DESCR_SCATTER_SELECT
+#define DESCR_SCATTER_SELECT 1      // descr_all 0.300 -> 0.285 ms per 64 x 1080p step (profiles/r06_scatter_ab.txt)
+#endif
 
 // Write one finished record (both targets: the per-frame array and / or the packed array).
 __device__ __forceinline__ void descr_write(SiftPointD *sift, SiftPointD *pack_dst, int pack_off, unsigned pack_cnt,
@@ -1434,7 +1519,9 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
         float *z = buf + 4 * lane_i;                      // 6 x b128 (1536 floats) + 1 x b32 (64), immediate offsets
 #pragma unroll
         for (int k = 0; k < 6; k++) *reinterpret_cast<float4 *>(z + 256 * k) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        buf[1536 + lane_i] = 0.0f;
+        int lane_k = lane;                                // its own opaque copy: derived from z the address is z - 12 * lane,
+        asm volatile("" : "+v"(lane_k));                  // which the compiler forms with a quarter-rate v_mad_u64_u32
+        buf[1536 + lane_k] = 0.0f;
       }
       wave_sync();
       // accumulation: the orientation sampled last first (its votes are in registers), then the parked one
@@ -1450,7 +1537,12 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
         }
         const bool first = k == 0 && doA;
         float o0, o1v;
+#if DESCR_SCATTER_SELECT && DESCR_FOOT_LITERAL
+        descr_accumulate_sel(buf, (int)((offsetof(DescrWaveLds, wtab) - offsetof(DescrWaveLds, buf)) / sizeof(float)) + lane, lane,
+                             vx, vy, ang, o0, o1v);                   // wtab: unused with literal weights, the dump slots
+#else
         descr_accumulate(buf, s_w[wave].wtab, lane, vx, vy, ang, o0, o1v);
+#endif
         descr_write(sift, pack_dst, pack_off, pack_cnt, first ? dstA : dstB, lane, o0, o1v, d, first ? d.ori1 : d.ori2,
                     subsampling, (!first && o == P.noct && !P.fix_numpts) ? 1.0f : P.out_scale);
       }
