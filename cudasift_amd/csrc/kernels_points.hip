@@ -169,6 +169,9 @@ __device__ __forceinline__ void patch_store(float *tile, int lane, const float (
 #ifndef TILE_FRACT
 #define TILE_FRACT 1
 #endif
+#ifndef TILE_MAD24
+#define TILE_MAD24 1
+#endif
 // `porg` = tile - (y0 * TW + x0): the address of texel (0, 0) of the level, so that a fetch at integer (ifx, ify) is
 // porg[ify * TW + ifx] — one v_mad_i32_i24 and one v_lshl_add_u32 per fetch instead of two subtractions, a shift, a
 // multiply and a three-operand add (r03: -3 of 27 instructions per bilinear fetch, 1 024 fetches per descriptor).
@@ -195,7 +198,13 @@ __device__ __forceinline__ float tex2d_tile(const float *porg, float x, float y,
     a = __builtin_fmaf(a, 256.0f, 12582912.0f) - 12582912.0f;
     b = __builtin_fmaf(b, 256.0f, 12582912.0f) - 12582912.0f;
   }
+#if TILE_MAD24
+  int tidx;                    // left to itself the compiler forms ify * (4 TW) + (ifx << 2) + porg: three instructions
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(tidx) : "v"(ify), "n"(TW), "v"(ifx));
+  const float *p = porg + tidx;
+#else
   const float *p = porg + (__mul24(ify, TW) + ifx);
+#endif
   const float t00 = p[0], t10 = p[1], t01 = p[TW], t11 = p[TW + 1];
   const float one = frac8 ? 256.0f : 1.0f;
   const float ia = one - a, ib = one - b;
