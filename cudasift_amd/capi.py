@@ -46,6 +46,7 @@ SIGNATURES = {
     "misift_ctx_sync": (_i, [_vp]),
     "misift_ctx_set_early_return": (_i, [_vp, _i]),
     "misift_ctx_chain_fallbacks": (_i, [_vp]),
+    "misift_ctx_fuse_fallbacks": (_i, [_vp]),
     "misift_ctx_last_call_balanced": (_i, [_vp]),
     "misift_ctx_descr_big_fallbacks": (_i, [_vp]),
     "misift_last_error": (C.c_char_p, []),
@@ -274,6 +275,9 @@ class Context:
 
     def chain_fallbacks(self):
         return lib().misift_ctx_chain_fallbacks(self.h)
+
+    def fuse_fallbacks(self):
+        return lib().misift_ctx_fuse_fallbacks(self.h)
 
     def sync(self):
         check(lib().misift_ctx_sync(self.h), "misift_ctx_sync")

@@ -28,6 +28,8 @@
 #define CNT_SPARE_BLOCKS 9    // counter blocks behind the last frame's: flags and ticket words of the call (dog_scan_all_kernel)
 #define CNT_BIG    48         // keypoints deferred to descr_big_kernel (descriptor window larger than descr_all's LDS tile)
 #define CNT_TICKET 49         // frame 0's block only: workgroups of the last kernel that have finished (host export)
+#define CNT_ORIDONE 50        // CNT_ORIDONE + octave : orientations finished (orient_descr_fused_kernel: the octaves coarser than the finest)
+#define CNT_FUSETMO 31        // frame 0's block only: workgroups of the fused kernel whose bounded wait for the coarser octaves' orientations expired
 
 struct alignas(16) SiftPointD {   // device view of the 576-byte record
   float xpos, ypos, scale, sharpness, edgeness, orientation, score, ambiguity;
@@ -374,6 +376,9 @@ struct misift_ctx {
   int chain_embed;              // 1 = that chain runs inside the scan launch when one chain covers all levels (MISIFT_CHAIN_EMBED)
   unsigned chain_wait_ticks;    // bound of the in-launch wait for that chain, 100 MHz ticks (MISIFT_CHAIN_WAIT_US; default 100 ms)
   int chain_fallbacks;          // calls re-run with a stand-alone chain launch because the bound expired (misift_ctx_chain_fallbacks)
+  int fuse_orient;              // 1 = single calls: orientations and descriptors in ONE launch (orient_descr_fused_kernel; MISIFT_FUSE_ORIENT)
+  unsigned fuse_wait_ticks;     // bound of its in-launch wait for the coarser octaves' orientations, 100 MHz ticks (MISIFT_FUSE_WAIT_US)
+  int fuse_fallbacks;           // calls re-run with the two separate launches because that bound expired (misift_ctx_fuse_fallbacks)
   int bin_min_frames;           // >= this many frames: bin_detections runs (MISIFT_BIN_MIN_FRAMES)
   int small_frames;             // <= this many frames: short scan segments, wide refine / per-keypoint grids (MISIFT_SMALL_FRAMES)
   int lowpass_tile;             // 1 = such batches: the LDS-tiled prefilter + first ScaleDown (MISIFT_LOWPASS_TILE)
@@ -487,6 +492,7 @@ int launch_sort_segments(misift_ctx *ctx, SiftPointD *pts, int max_pts, int nfra
 int launch_bin_detections(misift_ctx *ctx, const PyramidInfo &P, int max_pts);
 int launch_renumber_dups(misift_ctx *ctx, const PyramidInfo &P, int max_pts);
 int launch_orient_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts);
+int launch_orient_descr_fused(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts);
 int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts,
                      const int *pack_offsets, SiftPointD *pack_dst);
 // counts / offsets from the STAGED per-octave counters (valid once orient_all has run, before descr_all)

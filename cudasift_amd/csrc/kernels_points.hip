@@ -1386,13 +1386,19 @@ struct alignas(16) DescrWaveLds {
   float gauss[16];
   float wtab[64];               // footprint weights wy(row) * wx(column) (DESCR_FOOT_LITERAL=0 only)
 };
-template <bool Q8, bool BAL>
+// FUSE (orient_descr_fused_kernel): the orientations were computed by THIS launch — the duplicate counts of the coarser
+// octaves come from `fdup` (LDS, filled behind the launch's in-kernel wait), a keypoint's own orientation fields are read
+// back with vector loads (the scalar cache may hold the record's line from before they were written), and the reference's
+// counters are published by the launch's last workgroup instead of its first.
+struct NoWait { __device__ __forceinline__ bool operator()() const { return true; } };
+template <bool Q8, bool BAL, bool FUSE = false, typename WAIT = NoWait>
 __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch, const PyramidInfo &P,
                                                unsigned *__restrict__ counters, const Detection *__restrict__ det,
                                                SiftPointD *__restrict__ pts, int max_pts,
                                                const int *__restrict__ pack_offsets, SiftPointD *__restrict__ pack_dst,
                                                unsigned *__restrict__ big_list, unsigned big_stride, DescrWaveLds *s_w,
-                                               const int4 *__restrict__ block_map)
+                                               const int4 *__restrict__ block_map, const unsigned *fdup = nullptr,
+                                               int fuse_items = 0, const WAIT &fuse_wait = WAIT())
 {
   static_assert(PATCH_FLOATS == 4 * SMP_PLANE, "the window and the four vote planes share one buffer");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1411,7 +1417,7 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   if (lane < 16) s_w[wave].gauss[lane] = det_exp(-(lane - 7.5f) * (lane - 7.5f) / 128.0f);
   if (!DESCR_FOOT_LITERAL) footprint_weights_init(s_w[wave].wtab, lane);
   // segment layout of the reference: detections of octave o start where octave o-1 (incl. its duplicates) ended
-  if (fs.sub == 0 && threadIdx.x == 0) {                 // publish the reference's counters (cudaSiftD.cu:14)
+  if (!FUSE && fs.sub == 0 && threadIdx.x == 0) {       // publish the reference's counters (cudaSiftD.cu:14)
     unsigned b = 0;                                      // (write-through: a workgroup on another XCD may export them)
     for (int k = 1; k <= P.noct; k++) {
       __hip_atomic_store(&cnt[2 * k - 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1421,7 +1427,9 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
       __hip_atomic_store(&cnt[2 * k + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  const int stride = fs.nsub * WAVES_PER_BLOCK;
+  // FUSE: a wavefront takes `fuse_items` CONSECUTIVE keypoints instead (see orient_descr_fused_kernel: what a workgroup
+  // waits for then belongs to workgroups with lower indices)
+  const int stride = FUSE ? 1 : fs.nsub * WAVES_PER_BLOCK;
   // Keypoints of a frame are numbered octave after octave (coarsest first); a wavefront takes every stride-th one.
   // (octave, index) advance incrementally — the per-octave counts are re-read only when an octave is exhausted.
   auto ndet = [&](int k) -> int {
@@ -1444,10 +1452,11 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   // three-deep software pipeline over this wavefront's keypoints:
   //   Detection record of keypoint n+2 | window of keypoint n+1 (global -> registers) | keypoint n (LDS)
   int o = 1, i = 0, lim = ndet(1), o1, i1, lim1, o2, i2, lim2;
-  bool more = advance(o, i, lim, __builtin_amdgcn_readfirstlane(fs.sub * WAVES_PER_BLOCK + wave));
-  if (!more) return;
+  bool more = advance(o, i, lim, __builtin_amdgcn_readfirstlane(fs.sub * WAVES_PER_BLOCK + wave) * (FUSE ? fuse_items : 1));
+  if (!more) { if (FUSE) fuse_wait(); return; }           // (the wait holds workgroup barriers: every wavefront takes part)
+  int taken = 0;                                          // FUSE: keypoints of this wavefront's range behind the current one
   o1 = o; i1 = i; lim1 = lim;
-  bool more1 = advance(o1, i1, lim1, stride);
+  bool more1 = (!FUSE || 1 < fuse_items) && advance(o1, i1, lim1, stride);
   o2 = o1; i2 = i1; lim2 = lim1;
   // of the keypoints ahead only the first 16 bytes of the record (xpos, ypos, scale: what the window needs) are held;
   // the full record is (re)loaded when the keypoint becomes current — scalar loads, the line is in the scalar cache
@@ -1460,11 +1469,21 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   PatchGeom g = patch_geom(h0.x, h0.y, h0.z, P.o[o].w, P.o[o].h, P.patch_reach), g1 = g;
   float R[PATCH_LOADS];
   if (g.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + P.o[o].img_off, P.o[o].w, P.o[o].h, P.o[o].p, g, lane, R);
+  if (FUSE && !fuse_wait()) return;                       // the first window is on its way while the workgroup waits
   int cur_o = 0;
   unsigned bdet = 0, bdup = 0;                            // segment bases of octave cur_o in the reference layout
   while (more) {
     const float subsampling = P.o[o].subsampling;
-    const Detection d = fdet[(size_t)(o - 1) * max_pts + i];
+    Detection d = fdet[(size_t)(o - 1) * max_pts + i];
+    if (FUSE) {                                           // written by this wavefront a moment ago: not through the scalar cache
+      const unsigned *rec = reinterpret_cast<const unsigned *>(&fdet[(size_t)(o - 1) * max_pts + i]);
+      static_assert(offsetof(Detection, ori1) == 20 && offsetof(Detection, ori2) == 24 && offsetof(Detection, dupslot) == 28, "");
+      unsigned v = 0u;                                    // ONE load: lanes 0..2 fetch ori1, ori2, dupslot
+      if (lane < 3) v = __hip_atomic_load(rec + 5 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      d.ori1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)v, 0));
+      d.ori2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)v, 1));
+      d.dupslot = __builtin_amdgcn_readlane((int)v, 2);
+    }
     if (g.fits) patch_store(buf, lane, R);
     wave_sync();
     // ---- keypoint n+1: window loads into the registers just drained; keypoint n+2: the head of its record
@@ -1478,13 +1497,15 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
       g1 = patch_geom(h1.x, h1.y, h1.z, L1.w, L1.h, P.patch_reach);
       if (g1.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + L1.img_off, L1.w, L1.h, L1.p, g1, lane_i, R);
     }
-    const bool more2 = more1 && advance(o2, i2, lim2, stride);
+    const bool more2 = more1 && (!FUSE || taken + 2 < fuse_items) && advance(o2, i2, lim2, stride);
+    taken++;
     if (more2) h2 = head(o2, i2);
     // ---- keypoint n
     if (o != cur_o) {                                     // octave changed: segment bases (cudaSiftD.cu:1297-1300)
       unsigned b = 0;
       for (int k = 1; k < o; k++)
-        b += __builtin_amdgcn_readfirstlane(cnt[CNT_DET + k]) + __builtin_amdgcn_readfirstlane(cnt[CNT_DUP + k]);
+        b += __builtin_amdgcn_readfirstlane(cnt[CNT_DET + k]) +
+             __builtin_amdgcn_readfirstlane(FUSE ? fdup[k] : cnt[CNT_DUP + k]);
       bdet = b;
       bdup = b + __builtin_amdgcn_readfirstlane(cnt[CNT_DET + o]);
       cur_o = o;
@@ -1609,8 +1630,10 @@ __device__ __forceinline__ void export_counters_host(const unsigned *counters, u
   const unsigned nwords = nframes * CNT_STRIDE;
   // (agent-scope atomic loads: the counters were written by other workgroups — atomics, or the write-through stores of
   //  publish_counters — and must not be served from this XCD's L2)
+  // (system scope since r06: the fused kernel's workgroups poll words of these blocks while other workgroups of the SAME
+  //  launch still add to them, so a line of them may sit in this XCD's L2 from before the last update)
   for (unsigned w = threadIdx.x; w < nwords; w += blockDim.x)
-    host_out[w] = __hip_atomic_load(counters + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    host_out[w] = __hip_atomic_load(counters + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(host_out + nwords, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1713,16 +1736,14 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
 // tile), 4 waves/SIMD.  Selected with MISIFT_TILE=0 (A/B measurements, docs/LOG.md section 9).
 // 90 VGPRs: 5 waves/SIMD (the kernel is bound by the dependent LDS / shuffle chain of one keypoint per wavefront, so
 // every extra resident wavefront helps)
-template <bool Q8, bool BAL>
-__global__ __launch_bounds__(256, 5) void orient_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
-                                                         unsigned *__restrict__ counters,
-                                                         Detection *__restrict__ det, int max_pts, int frac8,
-                                                         const int4 *__restrict__ block_map)
+// (s_done: orient_descr_fused_kernel only — the workgroup's finished orientations per octave, for the octaves some other
+//  wavefront will wait for, i.e. all but the finest)
+template <bool Q8, bool BAL, bool FUSE = false>
+__device__ __forceinline__ void orient_gather_body(const float *__restrict__ scratch, const PyramidInfo &P,
+                                                   unsigned *__restrict__ counters, Detection *__restrict__ det, int max_pts,
+                                                   const int4 *__restrict__ block_map, float *hist, float *gauss, float2 *smp,
+                                                   float *tgrid, unsigned *s_done = nullptr, int fuse_items = 0)
 {
-  __shared__ float s_hist[WAVES_PER_BLOCK][64];
-  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
-  __shared__ float2 s_smp[WAVES_PER_BLOCK][128];
-  __shared__ float s_tgrid[WAVES_PER_BLOCK][176];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const FrameShare fs = frame_share<BAL>(block_map);
   if (BAL && fs.frame < 0) return;
@@ -1730,10 +1751,11 @@ __global__ __launch_bounds__(256, 5) void orient_all_gather_kernel(const float *
   unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
   Detection *fdet = det + (size_t)frame * MISIFT_MAX_OCTAVES * max_pts;
   const bool q8 = Q8;
-  if (lane >= 57) s_smp[wave][64 + lane] = make_float2(-1.0f, 0.0f);
+  if (lane >= 57) smp[64 + lane] = make_float2(-1.0f, 0.0f);
   const FrameCounts fc = load_frame_counts(cnt, P.noct, max_pts, false);
-  const int stride = fs.nsub * WAVES_PER_BLOCK;
-  int idx = __builtin_amdgcn_readfirstlane(fs.sub * WAVES_PER_BLOCK + wave);
+  const int stride = FUSE ? 1 : fs.nsub * WAVES_PER_BLOCK;      // FUSE: `fuse_items` consecutive keypoints per wavefront
+  int idx = __builtin_amdgcn_readfirstlane(fs.sub * WAVES_PER_BLOCK + wave) * (FUSE ? fuse_items : 1);
+  const int end = idx + fuse_items;
   int o, i;
   bool more = flat_to_octave(fc, P.noct, idx, o, i);
   // the next keypoint's record is fetched while the current one is processed (its ~1 us load latency was exposed
@@ -1746,15 +1768,194 @@ __global__ __launch_bounds__(256, 5) void orient_all_gather_kernel(const float *
     Detection *d = &fdet[(size_t)(o - 1) * max_pts + i];
     const int co = o;
     idx += stride;
-    more = flat_to_octave(fc, P.noct, idx, o, i);
+    more = (!FUSE || idx < end) && flat_to_octave(fc, P.noct, idx, o, i);
     if (more) nxt = *reinterpret_cast<const float4 *>(&fdet[(size_t)(o - 1) * max_pts + i]);
-    const OrientResult r = orient_core(img, L.w, L.h, L.p, q8, cur.x, cur.y, cur.z, s_hist[wave],
-                                       s_gauss[wave], s_smp[wave], s_tgrid[wave], lane);
+    const OrientResult r = orient_core(img, L.w, L.h, L.p, q8, cur.x, cur.y, cur.z, hist, gauss, smp, tgrid, lane);
     if (lane == 0) {
       d->ori1 = r.ori1;
       d->ori2 = r.ori2;
-      d->dupslot = r.has2 ? (int)atomicAdd(&cnt[CNT_DUP + co], 1u) : -1;
+      d->dupslot = r.has2 ? (int)atomicAdd(&cnt[CNT_DUP + co], 1u) : -1;     // (returns: performed before anything below)
+      if (FUSE && co < P.noct) atomicAdd(&s_done[co], 1u);                     // LDS
     }
+  }
+}
+
+template <bool Q8, bool BAL>
+__global__ __launch_bounds__(256, 5) void orient_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                         unsigned *__restrict__ counters,
+                                                         Detection *__restrict__ det, int max_pts, int frac8,
+                                                         const int4 *__restrict__ block_map)
+{
+  __shared__ float s_hist[WAVES_PER_BLOCK][64];
+  __shared__ float s_gauss[WAVES_PER_BLOCK][16];
+  __shared__ float2 s_smp[WAVES_PER_BLOCK][128];
+  __shared__ float s_tgrid[WAVES_PER_BLOCK][176];
+  const int wave = threadIdx.x >> 6;
+  orient_gather_body<Q8, BAL>(scratch, P, counters, det, max_pts, block_map, s_hist[wave], s_gauss[wave], s_smp[wave],
+                              s_tgrid[wave]);
+}
+
+// orient_descr_fused_kernel — ONE launch for the orientations and the descriptors of a single call (a frame or two; r05
+// review: "persistent orientation + descriptor kernel").  A record's slot in the reference's layout is
+// sum_{k<o}(det_k + dup_k) + i: a descriptor of octave o can be written once every orientation of the COARSER octaves is
+// known.  So every wavefront first computes the orientations of ITS keypoints (orient_gather_body, nothing to wait for),
+// the workgroup reports how many it finished per octave (one agent-scope atomic per octave and workgroup — same-address
+// atomics are served one at a time, 10-50 ns each — and none for the finest octave, which nobody waits for), waits until
+// the coarser octaves are complete, and goes on with the descriptors of the same keypoints (descr_all_body).
+// FORWARD PROGRESS needs no co-residency, only dispatch in index order: a wavefront takes a range of CONSECUTIVE keypoints
+// (coarsest octave first), a workgroup waits — after all its own orientations — for the octaves coarser than its LAST
+// keypoint's, and every keypoint of those lies in the range of a workgroup with a lower index, whose orientation pass waits
+// for nothing.  (r06's first version waited for all octaves but the finest: under HSA_CU_MASK=0:0-7 the 32 resident
+// workgroups waited for orientations of workgroups that could not start.)  The wait is bounded all
+// the same (`wait_ticks` of the 100 MHz clock): on expiry the workgroup skips its descriptors and raises CNT_FUSETMO; the
+// host re-runs the call with the two separate launches and keeps them on that context (misift_ctx_fuse_fallbacks).
+// Polling reads with SYSTEM scope: an agent-scope load may be served from this XCD's L2, which does not see the other
+// XCDs' atomics (dog_scan_all_kernel's chain wait learnt that); 32 lanes fetch the block's words 32..63 in one instruction.
+// What it saves is a dependent dispatch and the second kernel's ramp: r06 measurements in DESIGN.md section 4.
+#ifndef FUSE_POLL_SLEEP
+#define FUSE_POLL_SLEEP 32
+#endif
+#ifndef FUSE_STAMPS
+#define FUSE_STAMPS 0            // developer build (tools/variants.sh -DFUSE_STAMPS=1): 100 MHz time stamps, tools/fuse_stamps.py
+#endif
+#if FUSE_STAMPS
+__device__ unsigned g_fuse_stamp[16];
+#define FUSE_STAMP_MAX(slot) do { if (threadIdx.x == 0) atomicMax(&g_fuse_stamp[slot], (unsigned)wall_clock64()); } while (0)
+#define FUSE_STAMP_MIN(slot) do { if (threadIdx.x == 0) atomicMin(&g_fuse_stamp[slot], (unsigned)wall_clock64()); } while (0)
+extern "C" int misift_debug_fuse_stamps(unsigned *out16)
+{
+  unsigned init[16];
+  for (int i = 0; i < 16; i++) init[i] = (i == 0 || i == 8 || i == 9) ? 0xffffffffu : 0u;      // minima
+  HIP_TRY(hipDeviceSynchronize());
+  if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fuse_stamp), sizeof(init)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_stamp), init, sizeof(init)));
+  return MISIFT_OK;
+}
+#else
+#define FUSE_STAMP_MAX(slot) do { } while (0)
+#define FUSE_STAMP_MIN(slot) do { } while (0)
+#endif
+template <bool Q8, int OCC>
+__global__ __launch_bounds__(256, OCC) void orient_descr_fused_kernel(const float *__restrict__ scratch, PyramidInfo P,
+                                                                 unsigned *__restrict__ counters, Detection *__restrict__ det,
+                                                                 SiftPointD *__restrict__ pts, int max_pts,
+                                                                 unsigned *__restrict__ big_list, unsigned big_stride,
+                                                                 unsigned wait_ticks, unsigned *__restrict__ tail_host_out,
+                                                                 unsigned tail_seq)
+{
+  __shared__ DescrWaveLds s_w[WAVES_PER_BLOCK];
+  __shared__ unsigned s_done[MISIFT_MAX_OCTAVES + 1], s_fdup[MISIFT_MAX_OCTAVES + 1], s_ok;
+  static_assert(64 + 16 + 2 * 128 + 176 <= 12 * 64, "the orientation's LDS arrays borrow the descriptor's parking area");
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  unsigned *cnt = counters + (size_t)frame * CNT_STRIDE;
+  FUSE_STAMP_MIN(0); FUSE_STAMP_MAX(1);
+#if FUSE_STAMPS
+  const unsigned long long t_wg = wall_clock64();
+#endif
+  if (threadIdx.x <= MISIFT_MAX_OCTAVES) { s_done[threadIdx.x] = 0u; s_fdup[threadIdx.x] = 0u; }
+  if (threadIdx.x == 0) s_ok = 1u;
+  __syncthreads();
+  // keypoints per wavefront: consecutive ranges, coarsest octave first — whatever a workgroup will wait for (octaves
+  // coarser than its own last keypoint's) lies in the ranges of workgroups with LOWER indices
+  int per_wave, omax = 0;                      // omax: octave of the workgroup's last keypoint (0: it has none)
+  {
+    const FrameCounts fc = load_frame_counts(cnt, P.noct, max_pts, false);
+    int total = 0;
+#pragma unroll
+    for (int k = 1; k <= MISIFT_MAX_OCTAVES; k++) total += fc.ndet[k];       // (0 beyond P.noct)
+    const int nwaves = (int)gridDim.x * WAVES_PER_BLOCK;
+    per_wave = max(1, (total + nwaves - 1) / nwaves);
+    const int first = (int)blockIdx.x * WAVES_PER_BLOCK * per_wave;
+    const int last = min(first + WAVES_PER_BLOCK * per_wave, total) - 1;
+    int oi;
+    if (last >= first) flat_to_octave(fc, P.noct, last, omax, oi);
+  }
+  {
+    float *park = s_w[wave].park;            // hist[64] | gauss[16] | smp[128] (float2: 8-byte aligned at float 80) | tgrid[176]
+    orient_gather_body<Q8, false, true>(scratch, P, counters, det, max_pts, nullptr, park, park + 64,
+                                        reinterpret_cast<float2 *>(park + 80), park + 80 + 256, s_done, per_wave);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's orientation fields are on their way to the L2
+#if FUSE_STAMPS
+  if (lane == 0 && omax >= 1) atomicMax(&g_fuse_stamp[7], (unsigned)(wall_clock64() - t_wg));    // longest orientation pass of a wavefront
+#endif
+  // ---- report, then wait for the octaves coarser than the workgroup's last keypoint's (called by descr_all_body once its
+  // first window fetch is in flight; every wavefront of the workgroup calls it exactly once)
+  const auto wait_coarser = [&]() -> bool {
+    __syncthreads();
+    if (omax >= 1) { FUSE_STAMP_MAX(2); FUSE_STAMP_MIN(8); if (omax < P.noct) FUSE_STAMP_MAX(6); }   // orientations of a workgroup done
+    if (wave == 0) {
+      if (lane >= 1 && lane < P.noct && s_done[lane] != 0u)
+        __hip_atomic_fetch_add(&cnt[CNT_ORIDONE + lane], s_done[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef FUSE_NOWAIT
+#define FUSE_NOWAIT 0              // timing experiment only (wrong record positions): no wait at all
+#endif
+      if (omax > 1 && !FUSE_NOWAIT) {              // (workgroup-uniform: the octaves 1 .. omax-1 must be complete)
+        const unsigned long long t0 = wall_clock64();
+        unsigned ok = wait_ticks != 0u ? 1u : 0u;           // (a bound of 0 expires before the first poll: the test of the fallback)
+        // (the polled words 48..63 share no cache line with CNT_DUP, which the orientation passes of the other workgroups
+        //  still add to: polling THAT line stretched their atomics — and the launch's orientation phase — from 13 to 58 us)
+        const unsigned det = lane < 16 ? cnt[32 + lane] : 0u;                // CNT_DET: final since refine_all
+        while (ok) {
+          unsigned v = 0u;
+          if (lane < 16) v = __hip_atomic_load(&cnt[48 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          bool all = true;
+          for (int k = 1; k < omax; k++) {
+            const unsigned need = min((unsigned)__builtin_amdgcn_readlane((int)det, CNT_DET - 32 + k), (unsigned)max_pts);
+            all = all && (unsigned)__builtin_amdgcn_readlane((int)v, CNT_ORIDONE - 48 + k) >= need;
+          }
+          if (all) break;
+          if (wall_clock64() - t0 > (unsigned long long)wait_ticks) { ok = 0u; break; }
+          __builtin_amdgcn_s_sleep(FUSE_POLL_SLEEP);          // x 64 cycles
+        }
+        if (ok) {
+          // the duplicate counts, read AFTER the completion counts were seen (another cache line: one load could see them
+          // in either order)
+          unsigned u = 0u;
+          if (lane < 16) u = __hip_atomic_load(&cnt[32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (lane >= CNT_DUP - 32 + 1 && lane < CNT_DUP - 32 + omax) s_fdup[lane - (CNT_DUP - 32)] = u;
+        } else if (lane == 0) {
+          atomicAdd(&counters[CNT_FUSETMO], 1u);
+          s_ok = 0u;
+        }
+      }
+    }
+    __syncthreads();
+    if (omax > 1) { FUSE_STAMP_MAX(3); FUSE_STAMP_MIN(9); }                     // through the wait
+#ifdef FUSE_SKIP_DESCR             // timing experiment only: the orientation pass alone in this kernel
+    return false;
+#endif
+    return s_ok != 0u;
+  };
+  descr_all_body<Q8, false, true>(scratch, P, counters, det, pts, max_pts, nullptr, nullptr, big_list, big_stride, s_w, nullptr,
+                                  s_fdup, per_wave, wait_coarser);
+  if (omax >= 1) FUSE_STAMP_MAX(4);                                            // descriptors of a workgroup written
+  // ---- the launch's last workgroup publishes the reference's counters (cudaSiftD.cu:14) and, on request, hands the blocks
+  // to the host
+  if (last_workgroup_2level(counters + (size_t)P.nframes * CNT_STRIDE)) {
+    // (wavefront f does frame f — a single call has at most WAVES_PER_BLOCK... see the loop —: one load for all the counts,
+    //  the prefix sums by lane, one store for all 2 * noct + 1 slots; system scope: these words were updated by atomics of
+    //  workgroups on other XCDs during this launch)
+    for (int f = wave; f < P.nframes; f += WAVES_PER_BLOCK) {
+      unsigned *fc = counters + (size_t)f * CNT_STRIDE;
+      unsigned v = 0u;
+      if (lane < 16) v = __hip_atomic_load(&fc[32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // slot s = 2k - 1 (+0: start of octave k, +1: behind its detections), s = 2 noct + 1: behind everything
+      unsigned b = 0u, mine = 0u;
+      for (int k = 1; k <= P.noct; k++) {
+        if (lane == 2 * k - 1) mine = b;
+        b += (unsigned)__builtin_amdgcn_readlane((int)v, CNT_DET - 32 + k);
+        if (lane == 2 * k) mine = b;
+        b += (unsigned)__builtin_amdgcn_readlane((int)v, CNT_DUP - 32 + k);
+        if (lane == 2 * k + 1) mine = b;
+      }
+      if (lane >= 1 && lane <= 2 * P.noct + 1) __hip_atomic_store(&fc[lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tail_host_out) export_counters_host(counters, (unsigned)P.nframes, tail_host_out, tail_seq);
+    FUSE_STAMP_MAX(5);
   }
 }
 
@@ -2096,6 +2297,44 @@ int launch_descr_all(misift_ctx *ctx, const float *scratch, const PyramidInfo &P
   } else
     LAUNCH_Q8(descr_all_gather_kernel, grid, dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts, 0, pack_offsets,
               pack_dst);
+  return ls.finish();
+}
+
+// A single call's orientations + descriptors as ONE launch (orient_descr_fused_kernel).  Always the call's last kernel in the
+// sense of launch_descr_all's `fold`: its last workgroup publishes the counters and, on request, exports them; descr_big
+// follows at once when nobody will look at the exported counters first.
+int launch_orient_descr_fused(misift_ctx *ctx, const float *scratch, const PyramidInfo &P, SiftPointD *pts, int max_pts)
+{
+  LaunchScope ls(ctx, "orient_descr");
+  Detection *det = ctx->d_det;
+  const dim3 grid(points_grid_x(ctx, P.nframes), P.nframes);
+  unsigned big_stride = 0;
+  for (int o = 1; o <= P.noct; o++) big_stride += P.o[o].cand_cap;
+  unsigned *host_out = nullptr;
+  if (ctx->want_export && !ctx->in_capture) {
+    host_out = ctx->h_counters;
+    ctx->export_seq++;
+    ctx->exported = 1;
+  }
+  const bool fold = host_out && ctx->fold_descr_tail;
+  unsigned *tail_out = fold ? host_out : nullptr;
+  const bool q8 = ctx->opt.texfrac_bits == 8;
+#define FUSED_LAUNCH(Q, O) hipLaunchKernelGGL((orient_descr_fused_kernel<Q, O>), grid, dim3(256), (size_t)ctx->lds_pad_descr, ctx->stream, \
+                                              scratch, P, ctx->d_counters, det, pts, max_pts, ctx->d_cand, big_stride,                \
+                                              ctx->fuse_wait_ticks, tail_out, ctx->export_seq)
+  if (!q8) FUSED_LAUNCH(false, 3);               // (full-precision weights at 4 workgroups per CU would spill 17 registers)
+  else if (ctx->descr_occ >= 4) FUSED_LAUNCH(true, 4);
+  else FUSED_LAUNCH(true, 3);
+#undef FUSED_LAUNCH
+  PendingBig &pb = ctx->pending_big;
+  pb.valid = 0;
+  if (fold) {
+    pb.valid = 1; pb.scratch = scratch; pb.P = P; pb.det = det; pb.pts = pts; pb.max_pts = max_pts;
+    pb.pack_offsets = nullptr; pb.pack_dst = nullptr; pb.big_stride = big_stride;
+  } else {
+    LAUNCH_Q8(descr_big_kernel, dim3(2, P.nframes), dim3(256), scratch, P, ctx->d_counters, det, pts, max_pts,
+              (const int *)nullptr, (SiftPointD *)nullptr, ctx->d_cand, big_stride, host_out, ctx->export_seq);
+  }
   return ls.finish();
 }
 

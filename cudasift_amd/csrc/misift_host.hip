@@ -335,7 +335,8 @@ static const KnobName KNOBS[] = {
   {"lds_pad_lpd", "MISIFT_LDS_PAD_LPD"}, {"lds_pad_scan", "MISIFT_LDS_PAD_SCAN"}, {"lds_pad_orient", "MISIFT_LDS_PAD_ORIENT"},
   {"lds_pad_descr", "MISIFT_LDS_PAD_DESCR"}, {"lowpass_tile", "MISIFT_LOWPASS_TILE"}, {"strip_rows_small", "MISIFT_STRIP_ROWS_SMALL"},
   {"scan_rows_small_coarse", "MISIFT_SCAN_ROWS_SMALL_COARSE"}, {"scan_rows_small", "MISIFT_SCAN_ROWS_SMALL"},
-  {"host_spin", "MISIFT_HOST_SPIN"}, {"refcap_limit", "MISIFT_TEST_REFCAP_LIMIT"},
+  {"host_spin", "MISIFT_HOST_SPIN"}, {"refcap_limit", "MISIFT_TEST_REFCAP_LIMIT"}, {"fuse_orient", "MISIFT_FUSE_ORIENT"},
+  {"fuse_wait_us", "MISIFT_FUSE_WAIT_US"},
 };
 static bool tunables_from_env()
 {
@@ -375,6 +376,8 @@ static int apply_knob(misift_ctx *ctx, const char *name, double v)
   else if (is("scan_rows_small")) ctx->scan_rows_small = i > 0 ? i : 4;
   else if (is("host_spin")) ctx->host_spin = i != 0;
   else if (is("refcap_limit")) ctx->refcap_limit = i >= 0 && i <= 240 ? i : 32;
+  else if (is("fuse_orient")) ctx->fuse_orient = i != 0;
+  else if (is("fuse_wait_us")) ctx->fuse_wait_ticks = (unsigned)(v * 100.0);
   else { misift_set_error("misift_test_set_knob: unknown knob '%s'", name); return MISIFT_EINVAL; }
   return MISIFT_OK;
 }
@@ -428,6 +431,9 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   ctx->small_frames = 4;
   ctx->balance_frames = 1;       // r05: on by default (full GPU suite + bench A/B both ways: profiles/r05_balance_*); 0 restores per-frame grids
   ctx->fold_descr_tail = 1;
+  ctx->fuse_orient = 0;                       // r06: a single call's orientations + descriptors as ONE launch — built, parity-green,
+                                              // and 12-30 us SLOWER than the two launches: off
+  ctx->fuse_wait_ticks = 10000000u;           // 100 ms, like the chain's
   ctx->patch_reach = 17.9f;                   // = PATCH_REACH of kernels_points.hip: what the LDS window of descr_all covers
   ctx->refcap_limit = 32;                     // MEMWID of FindPointsMultiNew (tests lower it so that natural frames reach it)
   ctx->lowpass_tile = 1;
@@ -585,6 +591,7 @@ extern "C" int misift_ctx_last_call_balanced(misift_ctx *ctx) { return ctx ? ctx
 extern "C" int misift_ctx_descr_big_fallbacks(misift_ctx *ctx) { return ctx ? ctx->descr_big_fallbacks : -1; }
 
 extern "C" int misift_ctx_chain_fallbacks(misift_ctx *ctx) { return ctx ? ctx->chain_fallbacks : -1; }
+extern "C" int misift_ctx_fuse_fallbacks(misift_ctx *ctx) { return ctx ? ctx->fuse_fallbacks : -1; }
 
 extern "C" int misift_ctx_get_batches_in_flight(misift_ctx *ctx)
 {
@@ -1381,6 +1388,11 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
       rc = launch_bin_detections(ctx, P, max_pts);      // deterministic mode: a total order
       if (rc) return rc;
     }
+    // a frame or two: orientations and descriptors in one launch (the descriptor pass of a workgroup waits in the kernel for
+    // the coarser octaves' orientations, whose duplicate counts decide where its records go)
+    if (ctx->fuse_orient && !binned && !ctx->pack_dst && nframes <= ctx->small_frames && ctx->tile_descr && !ctx->tile_orient &&
+        !ctx->in_capture && max_pts <= 65535)
+      return launch_orient_descr_fused(ctx, d_scratch, P, pts, max_pts);
     rc = launch_orient_all(ctx, d_scratch, P, pts, max_pts);
     if (rc) return rc;
     if (ctx->opt.deterministic) {       // second-orientation slots in keypoint order instead of atomic order
@@ -1461,6 +1473,7 @@ static int wait_host_flag(misift_ctx *ctx, unsigned *word, unsigned seq)
 }
 
 #define MISIFT_RETRY_CHAIN 1000      // internal to this file: never returned to a caller
+#define MISIFT_RETRY_FUSE 1001
 static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pts, int *num_pts_out,
                        bool *cand_overflow)
 {
@@ -1486,6 +1499,7 @@ static int read_counts(misift_ctx *ctx, int nframes, int num_octaves, int max_pt
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   if (ctx->h_counters[CNT_CHAINTMO]) return MISIFT_RETRY_CHAIN;      // dog_scan_all_kernel: the bounded in-launch wait expired
+  if (ctx->h_counters[CNT_FUSETMO]) return MISIFT_RETRY_FUSE;        // orient_descr_fused_kernel: likewise
   const int slot = 2 * num_octaves + (ctx->opt.fix_numpts ? 1 : 0);
   for (int f = 0; f < nframes; f++) {
     const unsigned c = ctx->h_counters[(size_t)f * CNT_STRIDE + slot];
@@ -1620,7 +1634,19 @@ int misift_extract_sync(misift_ctx *ctx, const void *d_imgs, int src_u8, int nfr
       attempt--;
       continue;
     }
-    if (rc == MISIFT_RETRY_CHAIN) rc = MISIFT_EHIP;
+    if (rc == MISIFT_RETRY_FUSE && ctx->fuse_orient) {
+      // Some workgroup of the fused orientation + descriptor launch gave up waiting for the coarser octaves' orientations and
+      // skipped its descriptors.  Never again on this context: two launches, and this call is redone that way.
+      if (!ctx->opt.quiet)
+        fprintf(stderr, "misift: the in-launch wait of the fused orientation + descriptor kernel expired; this context now "
+                        "launches the two kernels separately\n");
+      ctx->fuse_orient = 0;
+      ctx->fuse_fallbacks++;
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      attempt--;
+      continue;
+    }
+    if (rc == MISIFT_RETRY_CHAIN || rc == MISIFT_RETRY_FUSE) rc = MISIFT_EHIP;
     if (rc) { ctx->opt.fused = fused_saved; return rc; }
     if (!ovf) break;
     if (ctx->opt.fused && attempt == 0) {

@@ -111,6 +111,10 @@ int misift_ctx_set_early_return(misift_ctx *ctx, int on);
 /* Diagnostics: calls this context re-ran with a stand-alone ScaleDown chain launch because the bounded in-launch wait
  * of the single-call path expired (never on a healthy device; MISIFT_CHAIN_WAIT_US sets the bound, default 100000). */
 int misift_ctx_chain_fallbacks(misift_ctx *ctx);
+/* Diagnostics: calls this context re-ran with separate orientation and descriptor launches because the bounded in-launch
+ * wait of the fused kernel of the single-call path (r06) expired (never on a healthy device; MISIFT_FUSE_WAIT_US sets the
+ * bound, default 100000; MISIFT_FUSE_ORIENT=0 keeps the two launches). */
+int misift_ctx_fuse_fallbacks(misift_ctx *ctx);
 /* Diagnostics: 1 if the last extraction enqueued on this context dealt the workgroups of its per-keypoint kernels out
  * in proportion to the frames' keypoint counts (batches of more than MISIFT_SMALL_FRAMES frames, MISIFT_BALANCE != 0). */
 int misift_ctx_last_call_balanced(misift_ctx *ctx);

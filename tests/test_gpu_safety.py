@@ -36,7 +36,7 @@ for seed, w, h in ((3, 1920, 1080), (4, 1280, 960), (5, 1920, 1080)):
     pts, n, cnt = ctx.extract(img, num_octaves=5, thresh=3.0)
     k = [pts[:n][f].view(np.uint32) for f in ("orientation", "scale", "ypos", "xpos")]
     out.append({"n": int(n), "cnt": cnt.tolist(), "sha": hashlib.sha256(pts[:n][np.lexsort(k)].tobytes()).hexdigest()})
-print("RESULT " + json.dumps({"frames": out, "fallbacks": ctx.chain_fallbacks()}))
+print("RESULT " + json.dumps({"frames": out, "fallbacks": ctx.chain_fallbacks(), "fuse_fallbacks": ctx.fuse_fallbacks()}))
 """
 
 
@@ -61,6 +61,37 @@ def test_expired_wait_falls_back_to_a_stand_alone_chain(baseline):
     assert "in-launch wait for the ScaleDown chain expired" in err
     assert res["frames"] == baseline["frames"]
     record("chain_wait_fallback", fallbacks=res["fallbacks"])
+
+
+def test_fused_orientation_and_descriptor_launch_equals_the_two_launches(baseline):
+    """r06: orient_descr_fused_kernel — a single call's orientations and descriptors as ONE launch whose descriptor pass
+    waits in the kernel for the coarser octaves' orientations.  Built, bit-identical, deadlock-free under CU masks, and
+    SLOWER than the two launches, hence off by default: MISIFT_FUSE_ORIENT=1 selects it."""
+    assert baseline["fuse_fallbacks"] == 0
+    res, _ = _child({"MISIFT_FUSE_ORIENT": "1"})
+    assert res["fuse_fallbacks"] == 0 and res["frames"] == baseline["frames"]
+    record("fused_orient_descr", keypoints=[f["n"] for f in res["frames"]], fuse_fallbacks=res["fuse_fallbacks"])
+
+
+def test_expired_fuse_wait_falls_back_to_two_launches(baseline):
+    """A bound of zero expires before the first poll: every workgroup that has to wait skips its descriptors and raises
+    CNT_FUSETMO, the host re-runs the call with separate launches and keeps them on that context."""
+    res, err = _child({"MISIFT_FUSE_ORIENT": "1", "MISIFT_FUSE_WAIT_US": "0"})
+    assert res["fuse_fallbacks"] == 1, res
+    assert "fused orientation + descriptor kernel expired" in err
+    assert res["frames"] == baseline["frames"]
+    record("fuse_wait_timeout", fuse_fallbacks=res["fuse_fallbacks"])
+
+
+@pytest.mark.parametrize("mask", ["0:0-7", "0:0-31"])
+def test_fused_launch_under_a_reduced_cu_mask(baseline, mask):
+    """Forward progress without co-residency: a workgroup waits only for workgroups with lower indices (8 CUs hold 32 of the
+    launch's 1 024 workgroups).  r06's first version waited for all coarser octaves in every workgroup and sat here until
+    the bound expired."""
+    res, _ = _child({"MISIFT_FUSE_ORIENT": "1", "HSA_CU_MASK": mask})
+    assert res["fallbacks"] == 0 and res["fuse_fallbacks"] == 0, res
+    assert res["frames"] == baseline["frames"]
+    record("fuse_wait_cu_mask/" + mask, fuse_fallbacks=res["fuse_fallbacks"])
 
 
 @pytest.mark.parametrize("mask", ["0:0-7", "0:0-31"])
