@@ -1390,15 +1390,14 @@ struct alignas(16) DescrWaveLds {
 // octaves come from `fdup` (LDS, filled behind the launch's in-kernel wait), a keypoint's own orientation fields are read
 // back with vector loads (the scalar cache may hold the record's line from before they were written), and the reference's
 // counters are published by the launch's last workgroup instead of its first.
-struct NoWait { __device__ __forceinline__ bool operator()() const { return true; } };
-template <bool Q8, bool BAL, bool FUSE = false, typename WAIT = NoWait>
+template <bool Q8, bool BAL, bool FUSE = false>
 __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch, const PyramidInfo &P,
                                                unsigned *__restrict__ counters, const Detection *__restrict__ det,
                                                SiftPointD *__restrict__ pts, int max_pts,
                                                const int *__restrict__ pack_offsets, SiftPointD *__restrict__ pack_dst,
                                                unsigned *__restrict__ big_list, unsigned big_stride, DescrWaveLds *s_w,
                                                const int4 *__restrict__ block_map, const unsigned *fdup = nullptr,
-                                               int fuse_items = 0, const WAIT &fuse_wait = WAIT())
+                                               int fuse_items = 0)
 {
   static_assert(PATCH_FLOATS == 4 * SMP_PLANE, "the window and the four vote planes share one buffer");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1453,7 +1452,7 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   //   Detection record of keypoint n+2 | window of keypoint n+1 (global -> registers) | keypoint n (LDS)
   int o = 1, i = 0, lim = ndet(1), o1, i1, lim1, o2, i2, lim2;
   bool more = advance(o, i, lim, __builtin_amdgcn_readfirstlane(fs.sub * WAVES_PER_BLOCK + wave) * (FUSE ? fuse_items : 1));
-  if (!more) { if (FUSE) fuse_wait(); return; }           // (the wait holds workgroup barriers: every wavefront takes part)
+  if (!more) return;
   int taken = 0;                                          // FUSE: keypoints of this wavefront's range behind the current one
   o1 = o; i1 = i; lim1 = lim;
   bool more1 = (!FUSE || 1 < fuse_items) && advance(o1, i1, lim1, stride);
@@ -1469,7 +1468,6 @@ __device__ __forceinline__ void descr_all_body(const float *__restrict__ scratch
   PatchGeom g = patch_geom(h0.x, h0.y, h0.z, P.o[o].w, P.o[o].h, P.patch_reach), g1 = g;
   float R[PATCH_LOADS];
   if (g.fits) patch_fetch(scratch + (long long)frame * P.frame_stride + P.o[o].img_off, P.o[o].w, P.o[o].h, P.o[o].p, g, lane, R);
-  if (FUSE && !fuse_wait()) return;                       // the first window is on its way while the workgroup waits
   int cur_o = 0;
   unsigned bdet = 0, bdup = 0;                            // segment bases of octave cur_o in the reference layout
   while (more) {
@@ -1774,7 +1772,11 @@ __device__ __forceinline__ void orient_gather_body(const float *__restrict__ scr
     if (lane == 0) {
       d->ori1 = r.ori1;
       d->ori2 = r.ori2;
+#ifdef FUSE_NO_DUP_ATOMIC          // timing experiment only (wrong duplicate slots)
+      d->dupslot = r.has2 ? 0 : -1;
+#else
       d->dupslot = r.has2 ? (int)atomicAdd(&cnt[CNT_DUP + co], 1u) : -1;     // (returns: performed before anything below)
+#endif
       if (FUSE && co < P.noct) atomicAdd(&s_done[co], 1u);                     // LDS
     }
   }
@@ -1880,8 +1882,9 @@ __global__ __launch_bounds__(256, OCC) void orient_descr_fused_kernel(const floa
 #if FUSE_STAMPS
   if (lane == 0 && omax >= 1) atomicMax(&g_fuse_stamp[7], (unsigned)(wall_clock64() - t_wg));    // longest orientation pass of a wavefront
 #endif
-  // ---- report, then wait for the octaves coarser than the workgroup's last keypoint's (called by descr_all_body once its
-  // first window fetch is in flight; every wavefront of the workgroup calls it exactly once)
+  // ---- report, then wait for the octaves coarser than the workgroup's last keypoint's.  (NOT with the first descriptor
+  // window already in flight: the window fetches of the waiting workgroups stream through the 16 KB vector caches that the
+  // orientations of the others gather from — the launch went from 40 to 59 us that way, r06_fused_orient_descr.txt.)
   const auto wait_coarser = [&]() -> bool {
     __syncthreads();
     if (omax >= 1) { FUSE_STAMP_MAX(2); FUSE_STAMP_MIN(8); if (omax < P.noct) FUSE_STAMP_MAX(6); }   // orientations of a workgroup done
@@ -1928,8 +1931,9 @@ __global__ __launch_bounds__(256, OCC) void orient_descr_fused_kernel(const floa
 #endif
     return s_ok != 0u;
   };
-  descr_all_body<Q8, false, true>(scratch, P, counters, det, pts, max_pts, nullptr, nullptr, big_list, big_stride, s_w, nullptr,
-                                  s_fdup, per_wave, wait_coarser);
+  if (wait_coarser())
+    descr_all_body<Q8, false, true>(scratch, P, counters, det, pts, max_pts, nullptr, nullptr, big_list, big_stride, s_w, nullptr,
+                                    s_fdup, per_wave);
   if (omax >= 1) FUSE_STAMP_MAX(4);                                            // descriptors of a workgroup written
   // ---- the launch's last workgroup publishes the reference's counters (cudaSiftD.cu:14) and, on request, hands the blocks
   // to the host
