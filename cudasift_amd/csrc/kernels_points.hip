@@ -1732,8 +1732,8 @@ __global__ __launch_bounds__(256) void descr_big_kernel(const float *__restrict_
 
 // ---- the r01 forms of the two merged-octave kernels: bilinear fetches straight from global memory (no staged
 // tile), 4 waves/SIMD.  Selected with MISIFT_TILE=0 (A/B measurements, docs/LOG.md section 9).
-// 90 VGPRs: 5 waves/SIMD (the kernel is bound by the dependent LDS / shuffle chain of one keypoint per wavefront, so
-// every extra resident wavefront helps)
+// 80 VGPRs: 6 waves/SIMD (the kernel is bound by the dependent LDS / shuffle chain of one keypoint per wavefront, so
+// every extra resident wavefront helps; 5 until r06)
 // (s_done: orient_descr_fused_kernel only — the workgroup's finished orientations per octave, for the octaves some other
 //  wavefront will wait for, i.e. all but the finest)
 template <bool Q8, bool BAL, bool FUSE = false>
@@ -1782,8 +1782,11 @@ __device__ __forceinline__ void orient_gather_body(const float *__restrict__ scr
   }
 }
 
+#ifndef ORIENT_OCC
+#define ORIENT_OCC 6             // r06: 80 VGPRs fit six wavefronts per SIMD; with orient_blocks_per_cu = 6: orient_all 0.133 -> 0.123 ms
+#endif
 template <bool Q8, bool BAL>
-__global__ __launch_bounds__(256, 5) void orient_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
+__global__ __launch_bounds__(256, ORIENT_OCC) void orient_all_gather_kernel(const float *__restrict__ scratch, PyramidInfo P,
                                                          unsigned *__restrict__ counters,
                                                          Detection *__restrict__ det, int max_pts, int frac8,
                                                          const int4 *__restrict__ block_map)

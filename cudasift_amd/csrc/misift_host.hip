@@ -354,7 +354,7 @@ static int apply_knob(misift_ctx *ctx, const char *name, double v)
   else if (is("tile")) ctx->tile_descr = ctx->tile_orient = i != 0;
   else if (is("tile_descr")) ctx->tile_descr = i != 0;
   else if (is("tile_orient")) ctx->tile_orient = i != 0;
-  else if (is("orient_blocks")) ctx->orient_blocks_per_cu = i > 0 ? i : 5;
+  else if (is("orient_blocks")) ctx->orient_blocks_per_cu = i > 0 ? i : 6;
   else if (is("point_blocks")) ctx->point_blocks_per_cu = i > 0 ? i : 8;
   else if (is("strip_waves")) ctx->strip_waves_per_cu = i > 0 ? i : 16;
   else if (is("scan_waves")) ctx->scan_waves_per_cu = i > 0 ? i : 16;
@@ -422,7 +422,7 @@ static int ctx_init(misift_ctx *ctx, CtxFull *f, int device, void *stream)
   ctx->descr_occ = 4;
   ctx->tile_descr = 1;
   ctx->tile_orient = 0;
-  ctx->orient_blocks_per_cu = 5;          // one round of resident workgroups: orient_all runs 5 waves/SIMD
+  ctx->orient_blocks_per_cu = 6;          // one round of resident workgroups: orient_all runs 6 waves/SIMD (r06; 5 before)
   ctx->point_blocks_per_cu = 8;
   ctx->chain_max_frames = 4;
   ctx->chain_embed = 1;
