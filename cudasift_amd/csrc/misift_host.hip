@@ -1390,8 +1390,9 @@ int misift_extract_enqueue(misift_ctx *ctx, const void *d_imgs, int src_u8, int 
     }
     // a frame or two: orientations and descriptors in one launch (the descriptor pass of a workgroup waits in the kernel for
     // the coarser octaves' orientations, whose duplicate counts decide where its records go)
+    // (off by default: measured 12 us slower than the two launches)
     if (ctx->fuse_orient && !binned && !ctx->pack_dst && nframes <= ctx->small_frames && ctx->tile_descr && !ctx->tile_orient &&
-        !ctx->in_capture && max_pts <= 65535)
+        !ctx->in_capture)
       return launch_orient_descr_fused(ctx, d_scratch, P, pts, max_pts);
     rc = launch_orient_all(ctx, d_scratch, P, pts, max_pts);
     if (rc) return rc;
